@@ -1,0 +1,836 @@
+/*
+ * oracle/ntedit.c -- CPU ORACLE (test infrastructure, never shipped).
+ * Stage B of the path: the ntEdit substitution / indel trial sweep for one
+ * contig against one Bloom filter, restated from
+ *   /root/reference/subprojects/ntedit/ntedit.cpp
+ *     findFirstAcceptedKmer :393-413      isRepeatInsertion :416-451
+ *     makeInsertion :481-569              makeDeletion :575-664
+ *     getCharacter :668-678               increment :682-699
+ *     findAcceptedKmer :703-756           getPrevInsertion :760-777
+ *     writeEditsToFile :781-936 (FASTA part only; VCF/TSV are commented out)
+ *     roll :940-969   makeEdit :973-1154  tryDeletion :1158-1234
+ *     tryIndels :1238-1411                kmerizeAndCorrect :1415-1771
+ * PARITY UNPINNED: ntedit.cpp includes btllib/bloom_filter.hpp, which this
+ * image lacks, so the reference cannot be compiled here; every quirk below is
+ * restated from reading (including the ones that look like defects: the
+ * repeat-insertion path that drops nodes, upper-casing on revert, the shared
+ * hash scratch, unsigned wrap-arounds).
+ * Not restated (never enabled by GoldPolish: scripts/goldpolish-ntedit:27):
+ * -s SNV mode and the -e secondary filter.
+ */
+#include "gpo.h"
+
+#include <ctype.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    int type; /* -1 unset, 0 = [s,e] of the contig, 1 = one inserted char */
+    size_t s, e;
+    unsigned char c;
+    unsigned sup;
+} node_t;
+
+typedef struct {
+    const gpo_ntedit_params* p;
+    const uint8_t* bf;
+    size_t bf_bytes;
+    char* seq; /* mutable copy of the contig */
+    uint32_t len;
+    node_t* nd;
+    size_t nn, ncap;
+    uint64_t fh, rh;
+    uint64_t hv[16]; /* shared scratch, like the reference's hVal */
+    uint64_t probes;
+} ed_t;
+
+static const node_t NODE_UNSET = { -1, 0, 0, 0, 0 };
+
+static void nd_push(ed_t* e, node_t n)
+{
+    if (e->nn == e->ncap) {
+        e->ncap = e->ncap ? e->ncap * 2 : 64;
+        e->nd = (node_t*)realloc(e->nd, e->ncap * sizeof(node_t));
+    }
+    e->nd[e->nn++] = n;
+}
+
+static void nd_put(ed_t* e, size_t i, node_t n)
+{
+    if (i < e->nn)
+        e->nd[i] = n;
+    else
+        nd_push(e, n);
+}
+
+/* reads past the live nodes are undefined in the reference; the oracle reads an
+ * unset node there instead of crashing */
+static const node_t* nd_at(const ed_t* e, uint32_t i)
+{
+    return i < e->nn ? &e->nd[i] : &NODE_UNSET;
+}
+
+static int is_acgt(unsigned char c) { return c == 'A' || c == 'T' || c == 'G' || c == 'C'; }
+
+static int is_accepted(unsigned char c)
+{
+    switch (c) {
+    case 'A': case 'T': case 'G': case 'C': case 'R': case 'Y': case 'S':
+    case 'W': case 'K': case 'M': case 'B': case 'D': case 'H': case 'V':
+        return 1;
+    default:
+        return 0;
+    }
+}
+
+static char rc_char(unsigned char c)
+{
+    switch (c) {
+    case 'A': case 'a': return 'T';
+    case 'T': case 't': return 'A';
+    case 'G': case 'g': return 'C';
+    case 'C': case 'c': return 'G';
+    default: return 'N';
+    }
+}
+
+/* polish_bases_array (:158-174) */
+static unsigned sub_bases(unsigned char draft, unsigned char out[4])
+{
+    const char* s;
+    switch (draft) {
+    case 'A': s = "TCG"; break;
+    case 'T': s = "ACG"; break;
+    case 'C': s = "ATG"; break;
+    case 'G': s = "ATC"; break;
+    case 'R': s = "TC"; break;
+    case 'Y': s = "AG"; break;
+    case 'S': s = "AT"; break;
+    case 'W': s = "CG"; break;
+    case 'K': s = "AC"; break;
+    case 'M': s = "TG"; break;
+    case 'B': s = "A"; break;
+    case 'D': s = "C"; break;
+    case 'H': s = "G"; break;
+    case 'V': s = "T"; break;
+    case 'N': s = "ATCG"; break;
+    default: s = ""; break; /* unordered_map::operator[] -> empty vector */
+    }
+    unsigned n = 0;
+    for (; s[n]; n++)
+        out[n] = (unsigned char)s[n];
+    return n;
+}
+
+/* multi_possible_bases[first][i] (:198-343): all strings of length 1..5 that
+ * start with `first`, shortest first, then lexicographic over A<C<G<T. */
+static const int NUM_TRIES[6] = { 0, 1, 5, 21, 85, 341 };
+static unsigned indel_string(unsigned char first, int i, char out[6])
+{
+    unsigned L = 1;
+    while (i >= NUM_TRIES[L])
+        L++;
+    int j = i - NUM_TRIES[L - 1];
+    out[0] = (char)first;
+    for (unsigned q = L - 1; q >= 1; q--) {
+        out[q] = "ACGT"[j & 3];
+        j >>= 2;
+    }
+    out[L] = 0;
+    return L;
+}
+
+static void hash_init(ed_t* e, const char* kmer)
+{
+    e->fh = gpo_ntf64(kmer, e->p->k);
+    e->rh = gpo_ntr64(kmer, e->p->k);
+    gpo_extend(e->fh + e->rh, e->p->k, e->p->h, e->hv);
+}
+
+static void hash_roll(ed_t* e, uint64_t* fh, uint64_t* rh, unsigned char out, unsigned char in)
+{
+    *fh = gpo_ntf64_roll(*fh, e->p->k, out, in);
+    *rh = gpo_ntr64_roll(*rh, e->p->k, out, in);
+    gpo_extend(*fh + *rh, e->p->k, e->p->h, e->hv);
+}
+
+static void hash_changelast(ed_t* e, uint64_t* fh, uint64_t* rh, unsigned char out,
+                            unsigned char in)
+{
+    *fh = gpo_ntf64_changelast(*fh, e->p->k, out, in);
+    *rh = gpo_ntr64_changelast(*rh, e->p->k, out, in);
+    gpo_extend(*fh + *rh, e->p->k, e->p->h, e->hv);
+}
+
+static int bf_has(ed_t* e)
+{
+    e->probes++;
+    return gpo_bf_contains(e->bf, e->bf_bytes, e->hv, e->p->h);
+}
+
+/* :393-413 */
+static uint32_t find_first_accepted_kmer(const ed_t* e, uint32_t b)
+{
+    const uint32_t k = e->p->k;
+    for (uint32_t i = b; i + k < e->len;) {
+        if (is_accepted((unsigned char)toupper((unsigned char)e->seq[i]))) {
+            int good = 1;
+            for (uint32_t j = i + 1; j < i + k; j++) {
+                if (!is_accepted((unsigned char)toupper((unsigned char)e->seq[j]))) {
+                    good = 0;
+                    i = j + 1;
+                    break;
+                }
+            }
+            if (good)
+                return i;
+        } else {
+            i++;
+        }
+    }
+    return e->len - 1;
+}
+
+/* :416-451  border (KMP failure function) periodicity test */
+static int is_repeat_insertion(const char* s, int n)
+{
+    if (n <= 0)
+        return 0; /* lps[n-1] on an empty vector: the caller never passes n==0 with effect */
+    int* lps = (int*)malloc((size_t)n * sizeof(int));
+    int len = 0, i = 1;
+    lps[0] = 0;
+    while (i < n) {
+        if (s[i] == s[len]) {
+            lps[i++] = ++len;
+        } else if (len != 0) {
+            len = lps[len - 1];
+        } else {
+            lps[i++] = 0;
+        }
+    }
+    len = lps[n - 1];
+    free(lps);
+    return len > 0 && n % (n - len) == 0;
+}
+
+/* :668-678 */
+static unsigned char get_char(const ed_t* e, uint32_t pos, const node_t* n)
+{
+    if (n->type == 0)
+        return pos < e->len ? (unsigned char)e->seq[pos] : 0; /* .at() would throw */
+    if (n->type == 1)
+        return n->c;
+    return 0;
+}
+
+/* :682-699 */
+static void increment(const ed_t* e, uint32_t* pos, uint32_t* ni)
+{
+    const node_t* n = nd_at(e, *ni);
+    if (n->type == 0) {
+        (*pos)++;
+        if (*pos > n->e) {
+            (*ni)++;
+            if (*ni < e->nn && e->nd[*ni].type == 0)
+                *pos = (uint32_t)e->nd[*ni].s;
+        }
+    } else if (n->type == 1) {
+        (*ni)++;
+        if (*ni < e->nn && e->nd[*ni].type == 0)
+            *pos = (uint32_t)e->nd[*ni].s;
+    }
+}
+
+/* :940-969 */
+static int roll(const ed_t* e, uint32_t* hi, uint32_t* ti, uint32_t* hn, uint32_t* tn,
+                unsigned char* out, unsigned char* in)
+{
+    if (*hi >= e->len || *hn >= e->nn)
+        return 0;
+    *out = get_char(e, *hi, &e->nd[*hn]);
+    increment(e, hi, hn);
+    if (*ti >= e->len || *tn >= e->nn)
+        return 0;
+    increment(e, ti, tn);
+    if (*ti >= e->len || *tn >= e->nn)
+        return 0;
+    *in = get_char(e, *ti, &e->nd[*tn]);
+    return 1;
+}
+
+/* :481-569 */
+static void make_insertion(ed_t* e, uint32_t* tn, int insert_pos, const char* ins, unsigned nins,
+                           unsigned sup)
+{
+    node_t orig = e->nd[*tn];
+    node_t add[8];
+    for (unsigned i = 0; i < nins; i++) {
+        add[i].type = 1;
+        add[i].s = add[i].e = 0;
+        add[i].c = (unsigned char)ins[i];
+        add[i].sup = sup;
+    }
+    if (orig.type == 0 && !(insert_pos <= (int)orig.s)) {
+        /* split the position node around the insertion */
+        node_t after = { 0, (size_t)insert_pos, orig.e, 0, 0 };
+        e->nd[*tn].e = (size_t)insert_pos - 1;
+        for (unsigned i = 0; i < nins; i++)
+            nd_put(e, (size_t)*tn + i + 1, add[i]);
+        nd_put(e, (size_t)*tn + nins + 1, after);
+        (*tn)++;
+        return;
+    }
+    if (orig.type == 0 || orig.type == 1) {
+        /* lift the live tail out, drop the insertion in, put the tail back */
+        size_t i = *tn, nre = 0;
+        while (i < e->nn && e->nd[i].type != -1)
+            i++, nre++;
+        node_t* re = (node_t*)malloc((nre + 1) * sizeof(node_t));
+        for (size_t q = 0; q < nre; q++) {
+            re[q] = e->nd[*tn + q];
+            e->nd[*tn + q].type = -1;
+        }
+        for (unsigned q = 0; q < nins; q++)
+            nd_put(e, (size_t)*tn + q, add[q]);
+        for (size_t q = 0; q < nre; q++)
+            nd_put(e, (size_t)*tn + nins + q, re[q]);
+        free(re);
+    }
+}
+
+/* :575-664 */
+static void make_deletion(ed_t* e, uint32_t* tn, uint32_t* pos, unsigned num_del, unsigned sup)
+{
+    node_t orig = e->nd[*tn];
+    if (orig.type == 0) {
+        unsigned leftover = 0;
+        if (*pos <= orig.s) {
+            if ((uint32_t)(*pos + num_del) <= orig.e) {
+                e->nd[*tn].s = (uint32_t)(*pos + num_del);
+                e->nd[*tn].sup = sup;
+                *pos = (uint32_t)e->nd[*tn].s;
+                return;
+            }
+            leftover = (unsigned)((size_t)(uint32_t)(*pos + num_del) - orig.e);
+            *pos = (uint32_t)(orig.e + 1);
+            size_t i = (size_t)*tn + 1;
+            while (i < e->nn && e->nd[i].type != -1) {
+                e->nd[i - 1] = e->nd[i];
+                e->nd[i].type = -1;
+                i++;
+            }
+        } else {
+            if ((uint32_t)(*pos + num_del) <= orig.e) {
+                node_t split = { 0, (uint32_t)(*pos + num_del), orig.e, 0, sup };
+                e->nd[*tn].e = (size_t)*pos - 1;
+                *pos = (uint32_t)split.s;
+                (*tn)++;
+                nd_put(e, *tn, split);
+                return;
+            }
+            leftover = (unsigned)((size_t)(uint32_t)(*pos + num_del) - orig.e);
+            e->nd[*tn].e = (size_t)*pos - 1;
+            *pos = (uint32_t)(orig.e + 1);
+            (*tn)++;
+        }
+        if (leftover > 0 && *tn < e->nn && e->nd[*tn].type != -1) {
+            if (e->nd[*tn].type == 0)
+                *pos = (uint32_t)e->nd[*tn].s;
+            make_deletion(e, tn, pos, leftover, sup);
+        }
+    } else if (orig.type == 1) {
+        size_t i = *tn;
+        unsigned leftover = num_del;
+        while (i < e->nn && e->nd[i].type == 1 && leftover > 0) {
+            e->nd[i].type = -1;
+            leftover--;
+            i++;
+        }
+        size_t j = *tn;
+        while (i < e->nn && e->nd[i].type != -1) {
+            e->nd[j] = e->nd[i];
+            e->nd[i].type = -1;
+            i++;
+            j++;
+        }
+        if (leftover > 0 && *tn < e->nn && e->nd[*tn].type != -1) {
+            if (e->nd[*tn].type == 0)
+                *pos = (uint32_t)e->nd[*tn].s;
+            make_deletion(e, tn, pos, leftover, sup);
+        }
+    }
+}
+
+/* :703-756; returns 1 and fills kmer[k] on success */
+static int find_accepted_kmer(ed_t* e, uint32_t* hi, uint32_t* ti, uint32_t* hn, uint32_t* tn,
+                              char* kmer)
+{
+    const uint32_t k = e->p->k;
+    node_t cur = e->nd[*tn];
+    uint32_t ttn = *tn, thn = 0;
+    uint32_t i = *ti;
+    while (i < e->len && ttn < e->nn && e->nd[ttn].type != -1) {
+        unsigned char c = get_char(e, i, &cur);
+        if (is_accepted((unsigned char)toupper(c))) {
+            uint32_t n = 0;
+            kmer[n++] = (char)c;
+            thn = ttn;
+            uint32_t j = i;
+            increment(e, &j, &ttn);
+            while (j < e->len && ttn < e->nn && e->nd[ttn].type != -1) {
+                cur = e->nd[ttn];
+                c = get_char(e, j, &cur);
+                if (!is_accepted((unsigned char)toupper(c))) {
+                    i = j;
+                    break;
+                }
+                kmer[n++] = (char)c;
+                if (n == k)
+                    break;
+                increment(e, &j, &ttn);
+            }
+            if (n == k) {
+                *hi = i;
+                *ti = j;
+                *hn = thn;
+                *tn = ttn;
+                return 1;
+            }
+        }
+        increment(e, &i, &ttn);
+    }
+    *hi = e->len;
+    *ti = e->len;
+    return 0;
+}
+
+/* :760-777; writes the run (complemented, nearest char first) into buf */
+static unsigned get_prev_insertion(const ed_t* e, uint32_t ti, uint32_t tn, char* buf,
+                                   unsigned cap)
+{
+    unsigned n = 0;
+    if ((tn < e->nn && e->nd[tn].type == 0 && ti == e->nd[tn].s) || e->nd[tn].type == 1)
+        tn--; /* may wrap to UINT32_MAX, which ends the walk below */
+    while (tn < e->nn && e->nd[tn].type == 1) {
+        if (n < cap)
+            buf[n] = rc_char(e->nd[tn].c);
+        n++;
+        tn--;
+    }
+    return n;
+}
+
+/* the node-dropping loop shared by both repeat branches (:1041-1052, :1076-1087) */
+static void drop_repeat_nodes(ed_t* e, uint32_t tn, uint32_t ti, unsigned count)
+{
+    uint32_t j = 1;
+    if (e->nd[tn].type == 0 && ti == e->nd[tn].s)
+        j = 0;
+    for (unsigned i = count; i > 0; i--) {
+        if (i > tn)
+            continue; /* index underflow is undefined in the reference */
+        if ((size_t)tn + j < e->nn && e->nd[tn + j].type != -1) {
+            e->nd[tn - i] = e->nd[tn + j];
+            e->nd[tn + j].type = -1;
+            j++;
+        } else {
+            e->nd[tn - i].type = -1;
+        }
+    }
+}
+
+typedef struct {
+    unsigned type; /* 0 none, 1 sub, 2 ins, 3 del */
+    unsigned char sub_base;
+    char indel[8]; /* inserted string, or just a length holder for deletions */
+    unsigned indel_len;
+    unsigned sup;
+} best_t;
+
+/* :973-1154 */
+static void make_edit(ed_t* e, unsigned char draft, best_t* b, uint32_t* hi, uint32_t* ti,
+                      uint32_t* hn, uint32_t* tn)
+{
+    const unsigned k = e->p->k;
+    node_t tnode = e->nd[*tn];
+    switch (b->type) {
+    case 1:
+        if (tnode.type == 0)
+            e->seq[*ti] = (char)b->sub_base;
+        else if (tnode.type == 1)
+            e->nd[*tn].c = b->sub_base;
+        hash_changelast(e, &e->fh, &e->rh, draft, b->sub_base);
+        break;
+    case 2: {
+        int skipped = 0;
+        char prev[1024]; /* run is bounded by insertion_cap (<= 1.5*k) + 5 */
+        unsigned np = get_prev_insertion(e, *ti, *tn, prev, sizeof prev - 8);
+        if (np + b->indel_len >= k) {
+            char kmer[256];
+            if (is_repeat_insertion(prev, (int)np) || np + b->indel_len >= e->p->insertion_cap) {
+                drop_repeat_nodes(e, *tn, *ti, np);
+                if (find_accepted_kmer(e, hi, ti, hn, tn, kmer))
+                    hash_init(e, kmer);
+                skipped = 1;
+            } else {
+                for (unsigned w = 0; w < b->indel_len; w++) {
+                    memmove(prev + 1, prev, np);
+                    prev[0] = rc_char((unsigned char)b->indel[w]);
+                    np++;
+                    if (is_repeat_insertion(prev, (int)np)) {
+                        drop_repeat_nodes(e, *tn, *ti, np - w);
+                        if (find_accepted_kmer(e, hi, ti, hn, tn, kmer))
+                            hash_init(e, kmer);
+                        skipped = 1;
+                    }
+                }
+            }
+        }
+        if (!skipped) {
+            make_insertion(e, tn, (int)*ti, b->indel, b->indel_len, b->sup);
+            hash_changelast(e, &e->fh, &e->rh, draft, (unsigned char)b->indel[0]);
+        }
+        break;
+    }
+    case 3:
+        make_deletion(e, tn, ti, b->indel_len, b->sup);
+        hash_changelast(e, &e->fh, &e->rh, draft, get_char(e, *ti, nd_at(e, *tn)));
+        break;
+    case 0:
+        if (e->p->mask) {
+            unsigned char lo = (unsigned char)tolower(draft);
+            if (tnode.type == 0)
+                e->seq[*ti] = (char)lo;
+            else if (tnode.type == 1)
+                e->nd[*tn].c = lo;
+            hash_changelast(e, &e->fh, &e->rh, draft, lo);
+        }
+        break;
+    default:
+        break;
+    }
+}
+
+static int passes(const ed_t* e, unsigned count, int deletion)
+{
+    const gpo_ntedit_params* p = e->p;
+    if (!p->use_ratio)
+        return (float)count >= ((float)p->k / p->edit_threshold);
+    if (deletion)
+        return (float)count >= (1 + ((float)p->k / (float)p->jump)) * p->edit_ratio;
+    return (float)count >= ((float)p->k / (float)p->jump) * p->edit_ratio;
+}
+
+/* :1158-1234 */
+static unsigned try_deletion(ed_t* e, unsigned char draft, unsigned num_del, uint32_t hi,
+                             uint32_t ti, uint32_t hn, uint32_t tn)
+{
+    const unsigned k = e->p->k;
+    uint64_t fh = e->fh, rh = e->rh;
+    unsigned char out = 0, in = 0;
+    for (unsigned i = 0; i < num_del; i++)
+        increment(e, &ti, &tn);
+    hash_changelast(e, &fh, &rh, draft, get_char(e, ti, nd_at(e, tn)));
+    unsigned present = 0;
+    if (bf_has(e))
+        present++;
+    for (unsigned q = 1; q <= k - 2 && hi < e->len; q++) {
+        if (roll(e, &hi, &ti, &hn, &tn, &out, &in)) {
+            hash_roll(e, &fh, &rh, out, in);
+            if (q % e->p->jump == 0 && bf_has(e))
+                present++;
+        }
+    }
+    return passes(e, present, 1) ? present : 0;
+}
+
+/* :1238-1411 */
+static int try_indels(ed_t* e, unsigned char draft, unsigned char index_char, unsigned* num_del,
+                      uint32_t hi0, uint32_t ti0, uint32_t hn0, uint32_t tn0, best_t* best,
+                      unsigned* altsupp1)
+{
+    const gpo_ntedit_params* p = e->p;
+    const unsigned k = p->k;
+    best_t tbest;
+    memset(&tbest, 0, sizeof tbest);
+    unsigned talt_sup = 0;
+
+    for (int i = 0; i < NUM_TRIES[p->max_insertions]; i++) {
+        char ins[8];
+        unsigned L = indel_string(index_char, i, ins);
+        ins[L] = (char)draft; /* the draft base follows the inserted bases */
+        uint64_t fh = e->fh, rh = e->rh;
+        uint32_t hi = hi0, ti = ti0, hn = hn0, tn = tn0;
+        unsigned char out = 0, in = 0;
+        hash_changelast(e, &fh, &rh, draft, index_char);
+        unsigned present = 0, q = 0;
+        for (; q < L && hi < e->len; q++) {
+            hash_roll(e, &fh, &rh, get_char(e, hi, nd_at(e, hn)), (unsigned char)ins[q + 1]);
+            increment(e, &hi, &hn);
+            if (q % p->jump == 0 && bf_has(e))
+                present++;
+        }
+        for (; q < k - 1 && hi < e->len; q++) {
+            if (roll(e, &hi, &ti, &hn, &tn, &out, &in)) {
+                hash_roll(e, &fh, &rh, out, in);
+                if (q % p->jump == 0 && bf_has(e))
+                    present++;
+            }
+        }
+        if (passes(e, present, 0)) {
+            if (p->mode == 0) {
+                best->type = 2;
+                memcpy(best->indel, ins, L);
+                best->indel_len = L;
+                best->sup = present;
+                return 1;
+            }
+            if (present >= tbest.sup) {
+                if (tbest.sup)
+                    talt_sup = tbest.sup;
+                tbest.type = 2;
+                memcpy(tbest.indel, ins, L);
+                tbest.indel_len = L;
+                tbest.sup = present;
+            }
+        }
+        if (*num_del <= p->max_deletions) {
+            unsigned ds = try_deletion(e, draft, *num_del, hi0, ti0, hn0, tn0);
+            if (ds > 0) {
+                if (p->mode == 0) {
+                    best->type = 3;
+                    best->indel_len = *num_del;
+                    best->sup = ds;
+                    return 1;
+                }
+                if (ds >= tbest.sup) {
+                    if (tbest.sup)
+                        talt_sup = tbest.sup;
+                    tbest.type = 3;
+                    tbest.indel_len = *num_del;
+                    tbest.sup = ds;
+                }
+            }
+            (*num_del)++;
+        }
+    }
+    if (tbest.sup > 0) {
+        if ((p->mode == 2 && tbest.sup > best->sup) || p->mode == 1) {
+            best->type = tbest.type;
+            memcpy(best->indel, tbest.indel, sizeof tbest.indel);
+            best->indel_len = tbest.indel_len;
+            best->sup = tbest.sup;
+            *altsupp1 = talt_sup;
+        }
+        return 1;
+    }
+    return 0;
+}
+
+void gpo_ntedit_default_params(gpo_ntedit_params* p, unsigned k, unsigned h)
+{
+    /* scripts/goldpolish-ntedit:27: -d5 -i5 -m1 -X.5 -Y.5 -a1 */
+    memset(p, 0, sizeof *p);
+    p->k = k;
+    p->h = h;
+    p->max_insertions = 5;
+    p->max_deletions = 5;
+    p->mode = 1;
+    p->use_ratio = 1;
+    p->missing_ratio = 0.5f;
+    p->edit_ratio = 0.5f;
+    p->missing_threshold = 5.0f;
+    p->edit_threshold = 9.0f;
+    p->jump = 3;
+    p->min_contig_len = 100;
+    p->mask = 1;
+    p->insertion_cap = (unsigned)((float)k * 1.5f);
+}
+
+size_t gpo_ntedit_out_bound(size_t len) { return 2 * len + 64; }
+
+size_t gpo_ntedit_contig(const char* seq_in, size_t len, const uint8_t* bf, size_t bf_bytes,
+                         const gpo_ntedit_params* p, char* out, uint64_t* n_probes)
+{
+    ed_t E;
+    ed_t* e = &E;
+    memset(e, 0, sizeof E);
+    e->p = p;
+    e->bf = bf;
+    e->bf_bytes = bf_bytes;
+    e->len = (uint32_t)len;
+    e->seq = (char*)malloc(len + 1);
+    memcpy(e->seq, seq_in, len);
+    e->seq[len] = 0;
+    const uint32_t k = p->k;
+
+    unsigned char char_in = 0, char_out = 0;
+    uint32_t hi = find_first_accepted_kmer(e, 0);
+    uint32_t ti = hi + k - 1;
+    if (hi + k - 1 < e->len) {
+        hash_init(e, e->seq + hi);
+        char_in = (unsigned char)e->seq[ti];
+    }
+    node_t root = { 0, 0, (size_t)e->len - 1, 0, 0 };
+    nd_push(e, root);
+    uint32_t hn = 0, tn = 0;
+
+    int go = 1;
+    do {
+        if (hi + k - 1 >= e->len)
+            break;
+        if (!bf_has(e)) {
+            uint64_t tfh = e->fh, trh = e->rh;
+            uint32_t thi = hi, tti = ti, thn = hn, ttn = tn;
+            unsigned char draft = (unsigned char)toupper(char_in);
+            unsigned missing = 0;
+            int do_not_fix = 0;
+            for (unsigned q = 0; q < k && thi < e->len; q++) {
+                if (roll(e, &thi, &tti, &thn, &ttn, &char_out, &char_in)) {
+                    hash_roll(e, &tfh, &trh, char_out, char_in);
+                    if (!is_accepted((unsigned char)toupper(char_in))) {
+                        do_not_fix = 1;
+                        break;
+                    }
+                    if (q % p->jump == 0) {
+                        /* the reference probes once for check_missing and, for ACGT
+                         * drafts, once more for check_there (unused outside -s) */
+                        if (!bf_has(e))
+                            missing++;
+                        else if (is_acgt(draft))
+                            e->probes++;
+                    }
+                } else {
+                    do_not_fix = 1;
+                    break;
+                }
+            }
+            int confirmed;
+            if (!p->use_ratio)
+                confirmed = (float)missing >= ((float)k / p->missing_threshold);
+            else
+                confirmed = (float)missing >= (((float)k / (float)p->jump) * p->missing_ratio);
+            if (!do_not_fix && confirmed) {
+                unsigned num_del = 1;
+                best_t best;
+                memset(&best, 0, sizeof best);
+                unsigned altsupp1 = 0, altsupp2 = 0, altsupp3 = 0; /* only their zero-ness
+                    feeds back into control flow; bases are VCF-only */
+                unsigned char subs[4];
+                unsigned nsub = sub_bases(draft, subs);
+                for (unsigned si = 0; si < nsub; si++) {
+                    unsigned char sb = subs[si];
+                    tfh = e->fh;
+                    trh = e->rh;
+                    hash_changelast(e, &tfh, &trh, draft, sb);
+                    if (bf_has(e) || p->mode == 2) {
+                        thn = hn;
+                        ttn = tn;
+                        thi = hi;
+                        tti = ti;
+                        if (e->nd[tn].type == 0)
+                            e->seq[tti] = (char)sb;
+                        else if (e->nd[tn].type == 1)
+                            e->nd[tn].c = sb;
+                        unsigned present = 0;
+                        for (unsigned q = 0; q < k && thi < e->len && tti < e->len; q++) {
+                            if (roll(e, &thi, &tti, &thn, &ttn, &char_out, &char_in)) {
+                                hash_roll(e, &tfh, &trh, char_out, char_in);
+                                if (q % p->jump == 0 && bf_has(e))
+                                    present++;
+                            } else {
+                                break;
+                            }
+                        }
+                        /* revert -- with the UPPER-case draft base (:1608-1615) */
+                        if (e->nd[tn].type == 0)
+                            e->seq[ti] = (char)draft;
+                        else if (e->nd[tn].type == 1)
+                            e->nd[tn].c = draft;
+
+                        if (passes(e, present, 0)) {
+                            if (present >= best.sup) {
+                                if (altsupp2)
+                                    altsupp3 = altsupp2;
+                                if (altsupp1)
+                                    altsupp2 = altsupp1;
+                                if (best.sup)
+                                    altsupp1 = best.sup;
+                                best.type = 1;
+                                best.sub_base = sb;
+                                best.sup = present;
+                            } else {
+                                if (!altsupp1) {
+                                    altsupp1 = present;
+                                } else if (!altsupp2) {
+                                    if (present < altsupp1) {
+                                        altsupp2 = present;
+                                    } else {
+                                        altsupp2 = altsupp1;
+                                        altsupp1 = present;
+                                    }
+                                } else if (!altsupp3) {
+                                    if (present < altsupp2) {
+                                        altsupp3 = present;
+                                    } else if (present < altsupp1) {
+                                        altsupp3 = altsupp2;
+                                        altsupp2 = present;
+                                    } else {
+                                        altsupp3 = altsupp2;
+                                        altsupp2 = altsupp1;
+                                        altsupp1 = present;
+                                    }
+                                }
+                            }
+                            if (p->mode == 0 || p->mode == 1)
+                                continue;
+                        }
+                        if (p->mode == 2 || best.type != 1) {
+                            if (try_indels(e, draft, sb, &num_del, hi, ti, hn, tn, &best,
+                                           &altsupp1)) {
+                                if (p->mode == 0 || p->mode == 1)
+                                    break;
+                            }
+                        }
+                    }
+                }
+                make_edit(e, draft, &best, &hi, &ti, &hn, &tn);
+            }
+        }
+        /* roll on; after a non-accepted base keep rolling until it has left the window */
+        int target = -1;
+        do {
+            if (roll(e, &hi, &ti, &hn, &tn, &char_out, &char_in)) {
+                if (!is_accepted((unsigned char)toupper(char_in)))
+                    target = (int)ti + (int)k;
+                hash_roll(e, &e->fh, &e->rh, char_out, char_in);
+            } else {
+                go = 0;
+                break;
+            }
+        } while (target >= 0 && (int)ti != target);
+    } while (go);
+
+    /* writeEditsToFile, sequence line only */
+    size_t o = 0;
+    for (size_t ni = 0; ni < e->nn && e->nd[ni].type != -1; ni++) {
+        const node_t* n = &e->nd[ni];
+        if (n->type == 0) {
+            /* substr(s, e-s+1): clamps at the end of the string */
+            size_t s = n->s, cnt = n->e - n->s + 1;
+            if (s <= e->len) {
+                if (cnt > e->len - s)
+                    cnt = e->len - s;
+                memcpy(out + o, e->seq + s, cnt);
+                o += cnt;
+            }
+        } else {
+            out[o++] = (char)n->c;
+        }
+    }
+    if (n_probes)
+        *n_probes += e->probes;
+    free(e->seq);
+    free(e->nd);
+    return o;
+}

@@ -1,0 +1,174 @@
+/*
+ * oracle/pipeline.c -- CPU ORACLE (test infrastructure, never shipped).
+ * One GoldPolish batch end to end, as the reference strings its tools together:
+ *   filters   /root/reference/src/goldpolish_targeted_bfs.cpp:55-146 (serve_batch)
+ *   cascade   /root/reference/scripts/goldpolish-ntedit:20-40  (k order + 0.75 guard)
+ *   drop<100  /root/reference/subprojects/ntedit/ntedit.cpp:1850-1853
+ *   mask      /root/reference/scripts/goldpolish-make:65-66  (-s -k$(firstword K))
+ *   sealer    /root/reference/scripts/goldpolish-make:68-72
+ *   upper     /root/reference/scripts/goldpolish-make:46-47
+ */
+#include "gpo.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+void gpo_batch_default_params(gpo_batch_params* p)
+{
+    memset(p, 0, sizeof *p);
+    p->nk = 4;
+    p->k_values[0] = 32; /* scripts/goldpolish:189-190 */
+    p->k_values[1] = 28;
+    p->k_values[2] = 24;
+    p->k_values[3] = 20;
+    p->hash_num = 4;
+    p->cbf_bytes = 10ull * 1024 * 1024;
+    p->bf_bytes = 512ull * 1024;
+    p->ntedit_x = 0.5f;
+    p->ntedit_y = 0.5f;
+    p->sealer_P = 10;
+    p->sealer_B = 1000;
+    p->run_sealer = 1;
+}
+
+void gpo_free(void* p) { free(p); }
+
+/* bytes of one FASTA record as both btllib's writer and ntEdit emit it */
+static uint64_t rec_bytes(const char* name, uint64_t seq_len)
+{
+    return 1 + strlen(name) + 1 + seq_len + 1;
+}
+
+int gpo_polish_batch(const gpo_batch_params* bp, unsigned n_contigs, const char* const* names,
+                     const char* const* seqs, const uint64_t* lens, const uint32_t* read_begin,
+                     const char* const* read_seqs, const uint64_t* read_lens,
+                     const uint32_t* kmer_threshold, char** out_seq, uint64_t* out_len,
+                     uint8_t** out_bfs, gpo_batch_stats* st)
+{
+    const unsigned nk = bp->nk;
+    if (nk == 0 || nk > 8)
+        return -1;
+    gpo_batch_stats local;
+    if (!st)
+        st = &local;
+    memset(st, 0, sizeof *st);
+
+    /* ---- stage A: one counting filter + one Bloom filter per k, shared by the batch */
+    uint8_t* cbfs[8];
+    uint8_t* bfs[8];
+    for (unsigned i = 0; i < nk; i++) {
+        cbfs[i] = (uint8_t*)calloc(bp->cbf_bytes, 1);
+        bfs[i] = (uint8_t*)calloc(bp->bf_bytes, 1);
+    }
+    for (unsigned c = 0; c < n_contigs; c++) {
+        for (uint32_t r = read_begin[c]; r < read_begin[c + 1]; r++) {
+            if (gpo_fill_bfs(read_seqs[r], read_lens[r], bp->hash_num, nk, bp->k_values,
+                             kmer_threshold[c], cbfs, bp->cbf_bytes, bfs, bp->bf_bytes) != 0)
+                return -2;
+            for (unsigned i = 0; i < nk; i++)
+                if (read_lens[r] >= bp->k_values[i])
+                    st->a_ops += read_lens[r] - bp->k_values[i] + 1;
+        }
+    }
+    for (unsigned i = 0; i < nk; i++)
+        free(cbfs[i]);
+
+    /* ---- stage B: ntEdit cascade over the whole batch file */
+    char** cur = (char**)calloc(n_contigs, sizeof(char*));
+    uint64_t* cur_len = (uint64_t*)calloc(n_contigs, sizeof(uint64_t));
+    uint8_t* dropped = (uint8_t*)calloc(n_contigs, 1);
+    uint64_t in_bytes = 0;
+    for (unsigned c = 0; c < n_contigs; c++) {
+        cur[c] = (char*)malloc(lens[c] + 1);
+        memcpy(cur[c], seqs[c], lens[c]);
+        cur[c][lens[c]] = 0;
+        cur_len[c] = lens[c];
+        in_bytes += rec_bytes(names[c], lens[c]);
+    }
+    for (unsigned ki = 0; ki < nk; ki++) {
+        gpo_ntedit_params np;
+        gpo_ntedit_default_params(&np, bp->k_values[ki], bp->hash_num);
+        np.missing_ratio = bp->ntedit_x;
+        np.edit_ratio = bp->ntedit_y;
+        for (unsigned c = 0; c < n_contigs; c++) {
+            if (dropped[c])
+                continue;
+            if (cur_len[c] < np.min_contig_len) {
+                dropped[c] = 1;
+                continue;
+            }
+            char* o = (char*)malloc(gpo_ntedit_out_bound(cur_len[c]) + 1);
+            size_t ol = gpo_ntedit_contig(cur[c], cur_len[c], bfs[ki], bp->bf_bytes, &np, o,
+                                          &st->b_probes);
+            o[ol] = 0;
+            free(cur[c]);
+            cur[c] = o;
+            cur_len[c] = ol;
+        }
+    }
+    uint64_t out_bytes = 0;
+    for (unsigned c = 0; c < n_contigs; c++)
+        if (!dropped[c])
+            out_bytes += rec_bytes(names[c], cur_len[c]);
+    /* size_diff=$(echo "scale=4; $output_size / $input_size" | bc); skip if < 0.75 */
+    if (in_bytes > 0 && (out_bytes * 10000) / in_bytes < 7500) {
+        st->ntedit_skipped = 1;
+        for (unsigned c = 0; c < n_contigs; c++) {
+            free(cur[c]);
+            cur[c] = (char*)malloc(lens[c] + 1);
+            memcpy(cur[c], seqs[c], lens[c]);
+            cur[c][lens[c]] = 0;
+            cur_len[c] = lens[c];
+            dropped[c] = 0;
+        }
+    }
+
+    /* ---- mask, stage C, upper */
+    gpo_sealer_params sp;
+    gpo_sealer_default_params(&sp, bp->k_values[0]);
+    sp.max_paths = bp->sealer_P;
+    sp.max_branches = bp->sealer_B;
+    const uint8_t* cbfs_c[8];
+    for (unsigned i = 0; i < nk; i++)
+        cbfs_c[i] = bfs[i];
+    for (unsigned c = 0; c < n_contigs; c++) {
+        if (dropped[c]) {
+            out_seq[c] = NULL;
+            out_len[c] = 0;
+            free(cur[c]);
+            continue;
+        }
+        char* m = (char*)malloc(cur_len[c] + 2);
+        size_t ml = gpo_mask(cur[c], cur_len[c], bp->k_values[0], m);
+        free(cur[c]);
+        char* o;
+        size_t ol;
+        if (bp->run_sealer) {
+            gpo_sealer_stats ss;
+            memset(&ss, 0, sizeof ss);
+            o = (char*)malloc(gpo_sealer_out_bound(ml) + 1);
+            ol = gpo_sealer_record(m, ml, nk, bp->k_values, cbfs_c, bp->bf_bytes, bp->hash_num,
+                                   &sp, o, &ss);
+            st->c_vertex_tests += ss.vertex_tests;
+            st->gaps_found += ss.gaps_found;
+            st->gaps_closed += ss.gaps_closed;
+            free(m);
+        } else {
+            o = m;
+            ol = ml;
+        }
+        gpo_upper(o, ol);
+        o[ol] = 0;
+        out_seq[c] = o;
+        out_len[c] = ol;
+    }
+    for (unsigned i = 0; i < nk; i++) {
+        if (out_bfs && out_bfs[i])
+            memcpy(out_bfs[i], bfs[i], bp->bf_bytes);
+        free(bfs[i]);
+    }
+    free(cur);
+    free(cur_len);
+    free(dropped);
+    return 0;
+}
