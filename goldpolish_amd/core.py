@@ -1,0 +1,284 @@
+"""ctypes binding of libgpcore.so -- the C ABI in include/gpcore.h.
+
+This is plumbing for tests/ and bench.py: it hands numpy buffers to the library
+and gets bytes back.  There is no CPU fallback anywhere: if the shared library
+is missing, or no GPU is present when a context is created, it raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import pathlib
+
+import numpy as np
+
+_HERE = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libgpcore.so"
+
+GP_MAX_K = 8
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+
+# every symbol include/gpcore.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "gp_last_error", "gp_version", "gp_default_params", "gp_ctx_create", "gp_ctx_destroy",
+    "gp_ctx_stream", "gp_kmer_threshold", "gp_rank_reads", "gp_job_create", "gp_job_destroy",
+    "gp_job_polish", "gp_job_build_filters", "gp_job_ntedit_pass", "gp_job_ntedit_guard",
+    "gp_job_mask", "gp_job_sealer", "gp_job_upper", "gp_job_sync", "gp_job_get_filter",
+    "gp_job_set_filters", "gp_job_get_lengths", "gp_job_get_sequences", "gp_job_get_counters",
+    "gp_job_kernel_time",
+]
+
+
+class GpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libgpcore error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("n_k", C.c_uint32), ("k", C.c_uint32 * GP_MAX_K), ("hash_num", C.c_uint32),
+        ("cbf_bytes", C.c_uint64), ("bf_bytes", C.c_uint64),
+        ("max_insertions", C.c_uint32), ("max_deletions", C.c_uint32), ("mode", C.c_int32),
+        ("missing_ratio", C.c_float), ("edit_ratio", C.c_float), ("jump", C.c_uint32),
+        ("min_contig_len", C.c_uint32), ("soft_mask", C.c_int32),
+        ("sealer_max_gap", C.c_uint32), ("sealer_max_paths", C.c_uint32),
+        ("sealer_max_branches", C.c_uint32), ("sealer_max_cost", C.c_uint32),
+        ("run_sealer", C.c_int32),
+    ]
+
+
+class BatchSet(C.Structure):
+    _fields_ = [
+        ("n_batches", C.c_uint32), ("batch_contig_begin", u32p),
+        ("n_contigs", C.c_uint32), ("contig_buf", u8p), ("contig_off", u64p),
+        ("contig_name_len", u32p), ("contig_read_begin", u32p),
+        ("contig_kmer_threshold", u32p),
+        ("n_reads", C.c_uint32), ("read_buf", u8p), ("read_off", u64p),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "a_positions", "a_ops", "a_ordered_ops", "a_rounds", "b_scan_kmers", "b_sites",
+        "b_probes", "b_edits", "c_gaps", "c_closed", "c_vertex_tests")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def load_library(path=None):
+    path = pathlib.Path(path) if path else LIB_PATH
+    if not path.exists():
+        raise FileNotFoundError(
+            f"{path} is missing: build it with `make -C goldpolish_amd/csrc` "
+            "(or __graft_entry__.build()); libgpcore has no CPU fallback")
+    L = C.CDLL(str(path))
+    L.gp_last_error.restype = C.c_char_p
+    L.gp_version.restype = C.c_int
+    L.gp_default_params.argtypes = [C.POINTER(Params)]
+    L.gp_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.gp_ctx_destroy.argtypes = [C.c_void_p]
+    L.gp_ctx_stream.restype = C.c_void_p
+    L.gp_ctx_stream.argtypes = [C.c_void_p]
+    L.gp_kmer_threshold.restype = C.c_int
+    L.gp_kmer_threshold.argtypes = [C.c_uint64]
+    L.gp_rank_reads.restype = C.c_size_t
+    L.gp_rank_reads.argtypes = [C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_double), u64p,
+                                C.c_uint64, C.c_double, u32p, u64p]
+    L.gp_job_create.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(BatchSet),
+                                C.POINTER(C.c_void_p)]
+    L.gp_job_destroy.argtypes = [C.c_void_p]
+    for name in ("gp_job_polish", "gp_job_build_filters", "gp_job_ntedit_guard", "gp_job_mask",
+                 "gp_job_sealer", "gp_job_upper"):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_int]
+    L.gp_job_ntedit_pass.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+    L.gp_job_sync.argtypes = [C.c_void_p]
+    L.gp_job_get_filter.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, u8p]
+    L.gp_job_set_filters.argtypes = [C.c_void_p, u8p]
+    L.gp_job_get_lengths.argtypes = [C.c_void_p, u64p, u8p, u64p]
+    L.gp_job_get_sequences.argtypes = [C.c_void_p, u8p, C.c_uint64]
+    L.gp_job_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+    L.gp_job_kernel_time.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), u64p, u64p]
+    return L
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load_library()
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise GpError(rc, lib().gp_last_error().decode(errors="replace"))
+
+
+def default_params(k_values=None, **kw) -> Params:
+    p = Params()
+    lib().gp_default_params(C.byref(p))
+    if k_values is not None:
+        p.n_k = len(k_values)
+        for i, k in enumerate(k_values):
+            p.k[i] = k
+    for a, b in kw.items():
+        setattr(p, a, b)
+    return p
+
+
+def kmer_threshold(bases: int) -> int:
+    return lib().gp_kmer_threshold(int(bases))
+
+
+def rank_reads(ids, phred, lens, target_len, s):
+    n = len(ids)
+    cids = (C.c_char_p * max(n, 1))(*[i if isinstance(i, bytes) else i.encode() for i in ids])
+    ph = (C.c_double * max(n, 1))(*phred)
+    ln = (C.c_uint64 * max(n, 1))(*lens)
+    order = (C.c_uint32 * max(n, 1))()
+    bases = C.c_uint64(0)
+    m = lib().gp_rank_reads(n, cids, ph, ln, int(target_len), float(s), order, C.byref(bases))
+    return list(order[:m]), bases.value
+
+
+class Context:
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().gp_ctx_create(device, C.byref(self._h)))
+
+    @property
+    def stream(self):
+        return lib().gp_ctx_stream(self._h)
+
+    def close(self):
+        if self._h:
+            lib().gp_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def _arr(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class Job:
+    """A set of batches resident on the device."""
+
+    def __init__(self, ctx: Context, params: Params, *, contig_buf, contig_off, contig_read_begin,
+                 kmer_threshold, read_buf, read_off, batch_contig_begin=None, name_len=None):
+        self.ctx = ctx
+        self.params = params
+        n_contigs = len(contig_off) - 1
+        if batch_contig_begin is None:
+            batch_contig_begin = np.arange(n_contigs + 1)
+        self._keep = dict(
+            bcb=_arr(batch_contig_begin, np.uint32), cbuf=_arr(contig_buf, np.uint8),
+            coff=_arr(contig_off, np.uint64), crb=_arr(contig_read_begin, np.uint32),
+            thr=_arr(kmer_threshold, np.uint32), rbuf=_arr(read_buf, np.uint8),
+            roff=_arr(read_off, np.uint64),
+            nlen=_arr(name_len if name_len is not None else np.zeros(n_contigs), np.uint32))
+        k = self._keep
+        bs = BatchSet()
+        bs.n_batches = len(k["bcb"]) - 1
+        bs.batch_contig_begin = k["bcb"].ctypes.data_as(u32p)
+        bs.n_contigs = n_contigs
+        bs.contig_buf = k["cbuf"].ctypes.data_as(u8p)
+        bs.contig_off = k["coff"].ctypes.data_as(u64p)
+        bs.contig_name_len = k["nlen"].ctypes.data_as(u32p)
+        bs.contig_read_begin = k["crb"].ctypes.data_as(u32p)
+        bs.contig_kmer_threshold = k["thr"].ctypes.data_as(u32p)
+        bs.n_reads = len(k["roff"]) - 1
+        bs.read_buf = k["rbuf"].ctypes.data_as(u8p)
+        bs.read_off = k["roff"].ctypes.data_as(u64p)
+        self.n_batches, self.n_contigs = bs.n_batches, n_contigs
+        self._h = C.c_void_p()
+        _check(lib().gp_job_create(ctx._h, C.byref(params), C.byref(bs), C.byref(self._h)))
+
+    @classmethod
+    def from_workload(cls, ctx, params, w):
+        return cls(ctx, params, contig_buf=w.contig_buf, contig_off=w.contig_off,
+                   contig_read_begin=w.contig_read_begin, kmer_threshold=w.kmer_threshold,
+                   read_buf=w.read_buf, read_off=w.read_off,
+                   name_len=[len(n) for n in w.names])
+
+    def close(self):
+        if self._h:
+            lib().gp_job_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def polish(self, sync=True):
+        _check(lib().gp_job_polish(self._h, int(sync)))
+
+    def build_filters(self, sync=True):
+        _check(lib().gp_job_build_filters(self._h, int(sync)))
+
+    def ntedit_pass(self, ki, sync=True):
+        _check(lib().gp_job_ntedit_pass(self._h, ki, int(sync)))
+
+    def ntedit_guard(self, sync=True):
+        _check(lib().gp_job_ntedit_guard(self._h, int(sync)))
+
+    def mask(self, sync=True):
+        _check(lib().gp_job_mask(self._h, int(sync)))
+
+    def sealer(self, sync=True):
+        _check(lib().gp_job_sealer(self._h, int(sync)))
+
+    def upper(self, sync=True):
+        _check(lib().gp_job_upper(self._h, int(sync)))
+
+    def sync(self):
+        _check(lib().gp_job_sync(self._h))
+
+    def get_filter(self, batch, ki) -> np.ndarray:
+        out = np.zeros(self.params.bf_bytes, dtype=np.uint8)
+        _check(lib().gp_job_get_filter(self._h, batch, ki, out.ctypes.data_as(u8p)))
+        return out
+
+    def set_filters(self, filters: np.ndarray):
+        f = _arr(filters, np.uint8).reshape(-1)
+        assert f.size == self.n_batches * self.params.n_k * self.params.bf_bytes
+        _check(lib().gp_job_set_filters(self._h, f.ctypes.data_as(u8p)))
+
+    def sequences(self):
+        """list of bytes (None for contigs ntEdit dropped), in contig order"""
+        lens = np.zeros(self.n_contigs, dtype=np.uint64)
+        dropped = np.zeros(self.n_contigs, dtype=np.uint8)
+        total = C.c_uint64(0)
+        _check(lib().gp_job_get_lengths(self._h, lens.ctypes.data_as(u64p),
+                                        dropped.ctypes.data_as(u8p), C.byref(total)))
+        buf = np.zeros(max(int(total.value), 1), dtype=np.uint8)
+        _check(lib().gp_job_get_sequences(self._h, buf.ctypes.data_as(u8p), buf.size))
+        out, at = [], 0
+        for i in range(self.n_contigs):
+            n = int(lens[i])
+            out.append(None if dropped[i] else buf[at:at + n].tobytes())
+            at += n
+        return out
+
+    def counters(self) -> dict:
+        c = Counters()
+        _check(lib().gp_job_get_counters(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def kernel_time(self, name: str):
+        ms, n, u = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().gp_job_kernel_time(self._h, name.encode(), C.byref(ms), C.byref(n),
+                                        C.byref(u)))
+        return ms.value, n.value, u.value

@@ -1,0 +1,532 @@
+// api.hip -- the C ABI of libgpcore (include/gpcore.h): contexts, jobs, uploads,
+// stage sequencing and result copies.  Host C++; the kernels live in stage_*.hip.
+#include "gp_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace gp {
+
+static thread_local std::string g_err;
+
+void set_error(const std::string& msg) { g_err = msg; }
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line)
+{
+    g_err = std::string(what) + " failed at " + file + ":" + std::to_string(line) + ": " +
+            hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? GP_ERR_OOM : GP_ERR_HIP;
+}
+
+} // namespace gp
+
+using namespace gp;
+
+extern "C" {
+
+const char* gp_last_error(void) { return g_err.c_str(); }
+
+int gp_version(void) { return 100; }
+
+void gp_default_params(gp_params* p)
+{
+    if (!p)
+        return;
+    std::memset(p, 0, sizeof *p);
+    p->n_k = 4;
+    p->k[0] = 32;
+    p->k[1] = 28;
+    p->k[2] = 24;
+    p->k[3] = 20;
+    p->hash_num = 4;
+    p->cbf_bytes = 10ull * 1024 * 1024;
+    p->bf_bytes = 512ull * 1024;
+    p->max_insertions = 5;
+    p->max_deletions = 5;
+    p->mode = 1;
+    p->missing_ratio = 0.5f;
+    p->edit_ratio = 0.5f;
+    p->jump = 3;
+    p->min_contig_len = 100;
+    p->soft_mask = 1;
+    p->sealer_max_gap = 800;
+    p->sealer_max_paths = 10;
+    p->sealer_max_branches = 1000;
+    p->sealer_max_cost = 100000;
+    p->run_sealer = 1;
+}
+
+int gp_ctx_create(int device, gp_ctx** out)
+{
+    if (!out) {
+        set_error("gp_ctx_create: out is NULL");
+        return GP_ERR_INVALID_ARG;
+    }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("gp_ctx_create: no HIP device available (libgpcore has no CPU fallback)");
+        return GP_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("gp_ctx_create: device index out of range");
+        return GP_ERR_INVALID_ARG;
+    }
+    gp_ctx* c = new (std::nothrow) gp_ctx();
+    if (!c)
+        return GP_ERR_OOM;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&c->prop, device) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("gp_ctx_create: could not initialise the device");
+        delete c;
+        return GP_ERR_HIP;
+    }
+    *out = c;
+    return GP_OK;
+}
+
+void gp_ctx_destroy(gp_ctx* ctx)
+{
+    if (!ctx)
+        return;
+    if (ctx->stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+void* gp_ctx_stream(gp_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+/* src/goldpolish_targeted_bfs.cpp:45-53 */
+int gp_kmer_threshold(uint64_t mapped_bases)
+{
+    const double a = 4.66943, b = 2.11391e-07;
+    int t = (int)std::round(a + (double)mapped_bases * b);
+    return std::min(t, 13);
+}
+
+/* src/goldpolish_targeted_bfs.cpp:96-123 */
+size_t gp_rank_reads(size_t n, const char* const* ids, const double* phred_avg,
+                     const uint64_t* lens, uint64_t target_len, double max_reads_per_10kbp,
+                     uint32_t* order, uint64_t* bases)
+{
+    if (bases)
+        *bases = 0;
+    if (n == 0 || !ids || !phred_avg || !lens || !order)
+        return 0;
+    struct Item {
+        uint32_t idx;
+        size_t phred;
+    };
+    std::vector<Item> v(n);
+    for (size_t i = 0; i < n; i++)
+        v[i] = { (uint32_t)i, (size_t)phred_avg[i] };
+    std::sort(v.begin(), v.end(), [&](const Item& x, const Item& y) {
+        if (x.phred != y.phred)
+            return x.phred > y.phred;
+        return std::strcmp(ids[x.idx], ids[y.idx]) < 0;
+    });
+    size_t cap = (size_t)((double)target_len * max_reads_per_10kbp / 10000.0);
+    size_t use = std::min(n, cap);
+    uint64_t sum = 0;
+    for (size_t i = 0; i < use; i++) {
+        order[i] = v[i].idx;
+        sum += lens[v[i].idx];
+    }
+    if (bases)
+        *bases = sum;
+    return use;
+}
+
+static int check_params(const gp_params& p)
+{
+    if (p.n_k == 0 || p.n_k > GP_MAX_K_VALUES) {
+        set_error("params: n_k must be 1..8");
+        return GP_ERR_INVALID_ARG;
+    }
+    for (uint32_t i = 0; i < p.n_k; i++)
+        if (p.k[i] < 4 || p.k[i] > 64) {
+            set_error("params: every k must be 4..64");
+            return GP_ERR_UNSUPPORTED;
+        }
+    if (p.hash_num == 0 || p.hash_num > (uint32_t)kMaxHash) {
+        set_error("params: hash_num must be 1..8");
+        return GP_ERR_UNSUPPORTED;
+    }
+    if (p.cbf_bytes == 0 || p.cbf_bytes >= (1ull << 32) || p.bf_bytes == 0 || p.bf_bytes % 4 ||
+        p.bf_bytes >= (1ull << 29)) {
+        set_error("params: cbf_bytes must be < 4 GiB, bf_bytes a multiple of 4 below 512 MiB");
+        return GP_ERR_UNSUPPORTED;
+    }
+    if (p.mode != 1) {
+        set_error("params: only ntEdit mode 1 (GoldPolish's) is implemented");
+        return GP_ERR_UNSUPPORTED;
+    }
+    if (p.max_insertions > 5 || p.max_deletions > 10 || p.jump == 0) {
+        set_error("params: max_insertions <= 5, max_deletions <= 10, jump >= 1");
+        return GP_ERR_INVALID_ARG;
+    }
+    return GP_OK;
+}
+
+int gp_job_create(gp_ctx* ctx, const gp_params* params, const gp_batch_set* set, gp_job** out)
+{
+    if (!ctx || !params || !set || !out) {
+        set_error("gp_job_create: NULL argument");
+        return GP_ERR_INVALID_ARG;
+    }
+    *out = nullptr;
+    int rc = check_params(*params);
+    if (rc != GP_OK)
+        return rc;
+    if (set->n_contigs && (!set->contig_off || !set->contig_read_begin ||
+                           !set->contig_kmer_threshold || !set->batch_contig_begin)) {
+        set_error("gp_job_create: batch set has NULL arrays");
+        return GP_ERR_INVALID_ARG;
+    }
+    if (set->n_batches == 0 || set->batch_contig_begin[set->n_batches] != set->n_contigs) {
+        set_error("gp_job_create: batch_contig_begin does not cover the contigs");
+        return GP_ERR_INVALID_ARG;
+    }
+    if (set->n_contigs >= (1u << 28)) {
+        set_error("gp_job_create: too many contigs in one job");
+        return GP_ERR_UNSUPPORTED;
+    }
+    for (uint32_t c = 0; c < set->n_contigs; c++) {
+        if (set->contig_read_begin[c + 1] < set->contig_read_begin[c] ||
+            set->contig_off[c + 1] < set->contig_off[c]) {
+            set_error("gp_job_create: offsets must be non-decreasing");
+            return GP_ERR_INVALID_ARG;
+        }
+        // fill_bfs refuses thresholds below 4 (src/utils.cpp:105-107) when it is reached
+        if (set->contig_read_begin[c + 1] > set->contig_read_begin[c] &&
+            set->contig_kmer_threshold[c] < 4) {
+            set_error("kmer_threshold must be greater than or equal to 4");
+            return GP_ERR_THRESHOLD;
+        }
+        if (set->contig_kmer_threshold[c] + params->n_k > 250) {
+            set_error("kmer_threshold too large for 8-bit counters");
+            return GP_ERR_INVALID_ARG;
+        }
+    }
+    if (set->n_contigs && set->contig_read_begin[set->n_contigs] > set->n_reads) {
+        set_error("gp_job_create: contig_read_begin exceeds n_reads");
+        return GP_ERR_INVALID_ARG;
+    }
+    GP_HIP(hipSetDevice(ctx->device));
+
+    gp_job* j = new (std::nothrow) gp_job();
+    if (!j)
+        return GP_ERR_OOM;
+    j->ctx = ctx;
+    j->prm = *params;
+    j->n_batches = set->n_batches;
+    j->n_contigs = set->n_contigs;
+    j->n_reads = set->n_reads;
+    auto fail = [&](int code) {
+        gp_job_destroy(j);
+        return code;
+    };
+
+    // ---- host-side tables
+    j->h_batch_contig_begin.assign(set->batch_contig_begin,
+                                   set->batch_contig_begin + set->n_batches + 1);
+    j->h_contig_batch.resize(set->n_contigs);
+    for (uint32_t b = 0; b < set->n_batches; b++)
+        for (uint32_t c = set->batch_contig_begin[b]; c < set->batch_contig_begin[b + 1]; c++)
+            j->h_contig_batch[c] = b;
+    j->h_contig_thr.assign(set->contig_kmer_threshold, set->contig_kmer_threshold + set->n_contigs);
+    j->h_contig_name_len.resize(set->n_contigs);
+    for (uint32_t c = 0; c < set->n_contigs; c++)
+        j->h_contig_name_len[c] = set->contig_name_len ? set->contig_name_len[c] : 0;
+    j->h_contig_off.assign(set->contig_off, set->contig_off + set->n_contigs + 1);
+
+    // ---- reads: concatenate with one separator after each read
+    j->h_seg_start.resize((size_t)set->n_contigs + 1);
+    uint64_t total = 0;
+    for (uint32_t c = 0; c < set->n_contigs; c++) {
+        j->h_seg_start[c] = total;
+        for (uint32_t r = set->contig_read_begin[c]; r < set->contig_read_begin[c + 1]; r++)
+            total += set->read_off[r + 1] - set->read_off[r] + 1;
+    }
+    j->h_seg_start[set->n_contigs] = total;
+    j->read_positions = total;
+    {
+        uint8_t* stage = nullptr;
+        if (total) {
+            if (hipHostMalloc((void**)&stage, total) != hipSuccess) {
+                set_error("gp_job_create: pinned staging allocation failed");
+                return fail(GP_ERR_OOM);
+            }
+            uint64_t at = 0;
+            for (uint32_t c = 0; c < set->n_contigs; c++)
+                for (uint32_t r = set->contig_read_begin[c]; r < set->contig_read_begin[c + 1];
+                     r++) {
+                    uint64_t len = set->read_off[r + 1] - set->read_off[r];
+                    std::memcpy(stage + at, set->read_buf + set->read_off[r], len);
+                    at += len;
+                    stage[at++] = '\n';
+                }
+        }
+        if ((rc = j->d_reads.alloc(total + 64)) != GP_OK) {
+            if (stage)
+                (void)hipHostFree(stage);
+            return fail(rc);
+        }
+        hipError_t e = hipMemset(j->d_reads.p, '\n', total + 64);
+        if (e == hipSuccess && total)
+            e = hipMemcpy(j->d_reads.p, stage, total, hipMemcpyHostToDevice);
+        if (stage)
+            (void)hipHostFree(stage);
+        if (e != hipSuccess)
+            return fail(hip_fail(e, "upload reads", __FILE__, __LINE__));
+    }
+    if ((rc = j->d_seg_start.alloc((size_t)set->n_contigs + 1)) != GP_OK ||
+        (rc = j->d_seg_batch.alloc(set->n_contigs)) != GP_OK ||
+        (rc = j->d_seg_thr.alloc(set->n_contigs)) != GP_OK)
+        return fail(rc);
+    {
+        hipError_t e = hipMemcpy(j->d_seg_start.p, j->h_seg_start.data(),
+                                 j->h_seg_start.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess && set->n_contigs)
+            e = hipMemcpy(j->d_seg_batch.p, j->h_contig_batch.data(),
+                          set->n_contigs * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess && set->n_contigs)
+            e = hipMemcpy(j->d_seg_thr.p, j->h_contig_thr.data(), set->n_contigs * sizeof(uint32_t),
+                          hipMemcpyHostToDevice);
+        if (e != hipSuccess)
+            return fail(hip_fail(e, "upload segment tables", __FILE__, __LINE__));
+    }
+
+    // ---- contigs
+    {
+        uint64_t cb = j->h_contig_off[set->n_contigs];
+        if ((rc = j->d_contigs_in.alloc(cb + 64)) != GP_OK)
+            return fail(rc);
+        if (cb) {
+            hipError_t e = hipMemcpy(j->d_contigs_in.p, set->contig_buf + set->contig_off[0],
+                                     cb - set->contig_off[0], hipMemcpyHostToDevice);
+            if (e != hipSuccess)
+                return fail(hip_fail(e, "upload contigs", __FILE__, __LINE__));
+        }
+        if (set->contig_off[0] != 0) {
+            uint64_t base = set->contig_off[0];
+            for (auto& o : j->h_contig_off)
+                o -= base;
+        }
+    }
+
+    // ---- filters
+    const uint64_t streams = (uint64_t)set->n_batches * params->n_k;
+    if ((rc = j->d_cbf.alloc(streams * params->cbf_bytes)) != GP_OK ||
+        (rc = j->d_bf.alloc(streams * (params->bf_bytes / 4))) != GP_OK)
+        return fail(rc);
+    if ((rc = stage_a_prepare(j)) != GP_OK)
+        return fail(rc);
+    if ((rc = stage_bc_prepare(j)) != GP_OK)
+        return fail(rc);
+    *out = j;
+    return GP_OK;
+}
+
+void gp_job_destroy(gp_job* job)
+{
+    if (!job)
+        return;
+    if (job->ctx) {
+        (void)hipSetDevice(job->ctx->device);
+        (void)hipStreamSynchronize(job->ctx->stream);
+    }
+    stage_a_release(job);
+    stage_bc_release(job);
+    job->t_first_pass.destroy();
+    job->t_round.destroy();
+    job->t_scan.destroy();
+    job->t_walk.destroy();
+    job->t_bfs.destroy();
+    delete job;
+}
+
+int gp_job_sync(gp_job* job)
+{
+    if (!job)
+        return GP_ERR_INVALID_ARG;
+    GP_HIP(hipStreamSynchronize(job->ctx->stream));
+    return GP_OK;
+}
+
+static int finish(gp_job* job, int rc, int sync)
+{
+    if (rc != GP_OK)
+        return rc;
+    if (sync)
+        return gp_job_sync(job);
+    return GP_OK;
+}
+
+int gp_job_build_filters(gp_job* job, int sync)
+{
+    if (!job)
+        return GP_ERR_INVALID_ARG;
+    GP_HIP(hipSetDevice(job->ctx->device));
+    return finish(job, stage_a_run(job), sync);
+}
+
+int gp_job_ntedit_pass(gp_job* job, uint32_t k_index, int sync)
+{
+    if (!job || k_index >= job->prm.n_k)
+        return GP_ERR_INVALID_ARG;
+    if (!job->filters_ready) {
+        set_error("gp_job_ntedit_pass: filters have not been built or set");
+        return GP_ERR_STATE;
+    }
+    GP_HIP(hipSetDevice(job->ctx->device));
+    int rc = GP_OK;
+    if (k_index == 0)
+        rc = stage_b_reset(job);
+    if (rc == GP_OK)
+        rc = stage_b_pass(job, k_index);
+    return finish(job, rc, sync);
+}
+
+int gp_job_ntedit_guard(gp_job* job, int sync)
+{
+    if (!job)
+        return GP_ERR_INVALID_ARG;
+    return finish(job, stage_b_guard(job), sync);
+}
+
+int gp_job_mask(gp_job* job, int sync)
+{
+    if (!job)
+        return GP_ERR_INVALID_ARG;
+    return finish(job, stage_mask(job), sync);
+}
+
+int gp_job_sealer(gp_job* job, int sync)
+{
+    if (!job)
+        return GP_ERR_INVALID_ARG;
+    if (!job->filters_ready) {
+        set_error("gp_job_sealer: filters have not been built or set");
+        return GP_ERR_STATE;
+    }
+    return finish(job, stage_c_run(job), sync);
+}
+
+int gp_job_upper(gp_job* job, int sync)
+{
+    if (!job)
+        return GP_ERR_INVALID_ARG;
+    return finish(job, stage_upper(job), sync);
+}
+
+int gp_job_polish(gp_job* job, int sync)
+{
+    if (!job)
+        return GP_ERR_INVALID_ARG;
+    GP_HIP(hipSetDevice(job->ctx->device));
+    int rc = stage_a_run(job);
+    for (uint32_t ki = 0; rc == GP_OK && ki < job->prm.n_k; ki++) {
+        if (ki == 0)
+            rc = stage_b_reset(job);
+        if (rc == GP_OK)
+            rc = stage_b_pass(job, ki);
+    }
+    if (rc == GP_OK)
+        rc = stage_b_guard(job);
+    if (rc == GP_OK)
+        rc = stage_mask(job);
+    if (rc == GP_OK && job->prm.run_sealer)
+        rc = stage_c_run(job);
+    if (rc == GP_OK)
+        rc = stage_upper(job);
+    return finish(job, rc, sync);
+}
+
+int gp_job_get_filter(gp_job* job, uint32_t batch, uint32_t k_index, uint8_t* out)
+{
+    if (!job || !out || batch >= job->n_batches || k_index >= job->prm.n_k) {
+        set_error("gp_job_get_filter: bad argument");
+        return GP_ERR_INVALID_ARG;
+    }
+    GP_HIP(hipSetDevice(job->ctx->device));
+    GP_HIP(hipStreamSynchronize(job->ctx->stream));
+    const uint64_t words = job->prm.bf_bytes / 4;
+    GP_HIP(hipMemcpy(out, job->d_bf.p + ((uint64_t)batch * job->prm.n_k + k_index) * words,
+                     job->prm.bf_bytes, hipMemcpyDeviceToHost));
+    return GP_OK;
+}
+
+int gp_job_set_filters(gp_job* job, const uint8_t* filters)
+{
+    if (!job || !filters)
+        return GP_ERR_INVALID_ARG;
+    GP_HIP(hipSetDevice(job->ctx->device));
+    GP_HIP(hipStreamSynchronize(job->ctx->stream));
+    GP_HIP(hipMemcpy(job->d_bf.p, filters,
+                     (uint64_t)job->n_batches * job->prm.n_k * job->prm.bf_bytes,
+                     hipMemcpyHostToDevice));
+    job->filters_ready = true;
+    return GP_OK;
+}
+
+int gp_job_get_lengths(gp_job* job, uint64_t* lengths, uint8_t* dropped, uint64_t* total)
+{
+    if (!job)
+        return GP_ERR_INVALID_ARG;
+    GP_HIP(hipSetDevice(job->ctx->device));
+    return stage_lengths(job, lengths, dropped, total);
+}
+
+int gp_job_get_sequences(gp_job* job, uint8_t* buf, uint64_t buf_bytes)
+{
+    if (!job || !buf)
+        return GP_ERR_INVALID_ARG;
+    GP_HIP(hipSetDevice(job->ctx->device));
+    return stage_sequences(job, buf, buf_bytes);
+}
+
+int gp_job_get_counters(gp_job* job, gp_counters* out)
+{
+    if (!job || !out)
+        return GP_ERR_INVALID_ARG;
+    *out = job->counters;
+    return GP_OK;
+}
+
+int gp_job_kernel_time(gp_job* job, const char* kernel, double* total_ms, uint64_t* launches,
+                       uint64_t* units)
+{
+    if (!job || !kernel)
+        return GP_ERR_INVALID_ARG;
+    const KernelTimer* t = nullptr;
+    if (!std::strcmp(kernel, "cbf_first_pass"))
+        t = &job->t_first_pass;
+    else if (!std::strcmp(kernel, "cbf_round"))
+        t = &job->t_round;
+    else if (!std::strcmp(kernel, "ntedit_scan"))
+        t = &job->t_scan;
+    else if (!std::strcmp(kernel, "ntedit_walk"))
+        t = &job->t_walk;
+    else if (!std::strcmp(kernel, "sealer_bfs"))
+        t = &job->t_bfs;
+    if (!t) {
+        set_error("gp_job_kernel_time: unknown kernel name");
+        return GP_ERR_INVALID_ARG;
+    }
+    if (total_ms)
+        *total_ms = t->total_ms;
+    if (launches)
+        *launches = t->launches;
+    if (units)
+        *units = t->total_units;
+    return GP_OK;
+}
+
+} // extern "C"

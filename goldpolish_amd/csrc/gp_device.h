@@ -1,0 +1,157 @@
+// gp_device.h -- device-side primitives shared by the stage kernels (gfx950).
+//
+// ntHash (the hash the reference pipeline agrees on end to end; arithmetic
+// documented in /root/reference/subprojects/ntedit/lib/nthash.hpp:24-28,66-91,
+// 100-152,180-191,305-314): 64-bit words whose low 33 and high 31 bits rotate
+// independently, canonical value = forward + reverse, extra hashes by a
+// multiply / xor-shift of the canonical value.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gp {
+
+constexpr uint64_t kSeedA = 0x3c8bfbb395c60474ULL;
+constexpr uint64_t kSeedC = 0x3193c18562a02b4cULL;
+constexpr uint64_t kSeedG = 0x20323ed082572324ULL;
+constexpr uint64_t kSeedT = 0x295549f54be24456ULL;
+constexpr uint64_t kMultiSeed = 0x90b45d39fb6da1faULL;
+constexpr int kMultiShift = 27;
+constexpr int kMaxHash = 8;
+constexpr uint32_t kNoResv = 0xFFFFFFFFu;
+
+// 2-bit code used inside kernels: A0 C1 T2 G3 (= (c >> 1) & 3 for ACGTacgt), so
+// the complement is code ^ 2.  kBadCode marks every other byte.
+constexpr uint8_t kBadCode = 4;
+
+__host__ __device__ inline uint8_t base_code(uint8_t c)
+{
+    uint8_t u = c & 0xDF;
+    bool ok = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
+    return ok ? (uint8_t)((c >> 1) & 3) : kBadCode;
+}
+
+__host__ __device__ inline uint64_t seed_of_code(uint32_t code)
+{
+    // branch-free select chain; code in 0..3
+    uint64_t lo = (code & 1) ? kSeedC : kSeedA;
+    uint64_t hi = (code & 1) ? kSeedG : kSeedT;
+    return (code & 2) ? hi : lo;
+}
+
+// forward seed of a raw byte (0 for anything but ACGTacgt)
+__host__ __device__ inline uint64_t seed_fwd(uint8_t c)
+{
+    uint8_t code = base_code(c);
+    return code == kBadCode ? 0ULL : seed_of_code(code);
+}
+
+// reverse-strand seed of a raw byte: the reference indexes its table with the
+// low three bits of the byte (nthash.hpp:14,115), which gives the complement
+// for ACGTacgt and a few non-zero values for IUPAC letters; reproduced as is.
+__host__ __device__ inline uint64_t seed_rc(uint8_t c)
+{
+    switch (c & 7) {
+    case 1: return kSeedT;
+    case 3: return kSeedG;
+    case 4: return kSeedA;
+    case 7: return kSeedC;
+    default: return 0ULL;
+    }
+}
+
+__host__ __device__ inline uint64_t srol1(uint64_t x)
+{
+    uint64_t carry = ((x & 0x8000000000000000ULL) >> 30) | ((x & 0x100000000ULL) >> 32);
+    return ((x << 1) & 0xFFFFFFFDFFFFFFFFULL) | carry;
+}
+
+__host__ __device__ inline uint64_t sror1(uint64_t x)
+{
+    uint64_t carry = ((x & 1ULL) << 32) | ((x & 0x200000000ULL) << 30);
+    return ((x >> 1) & 0xFFFFFFFEFFFFFFFFULL) | carry;
+}
+
+__host__ __device__ inline uint64_t sroln(uint64_t x, uint32_t n)
+{
+    uint64_t hi = x >> 33, lo = x & 0x1FFFFFFFFULL;
+    uint32_t a = n % 31u, b = n % 33u;
+    hi = ((hi << a) | (hi >> (31u - a))) & 0x7FFFFFFFULL;
+    lo = ((lo << b) | (lo >> (33u - b))) & 0x1FFFFFFFFULL;
+    return (hi << 33) | lo;
+}
+
+// i-th extension hash of canonical value `base` for k-mer size k (i >= 1)
+__host__ __device__ inline uint64_t ext_hash(uint64_t base, uint32_t k, uint32_t i)
+{
+    uint64_t t = base * ((uint64_t)i ^ ((uint64_t)k * kMultiSeed));
+    return t ^ (t >> kMultiShift);
+}
+
+// x % d for a divisor fixed per launch.  d = c * 2^s with c odd: the low s bits
+// pass through and the rest is reduced modulo c with 32-bit Lemire reductions
+// (exact for c < 65536); other divisors fall back to the 64-bit remainder.
+struct FastMod {
+    uint64_t d;
+    uint64_t magic;   // floor((2^64-1)/c) + 1
+    uint32_t c;       // odd part
+    uint32_t s;       // power-of-two part
+    uint32_t two32;   // 2^32 mod c
+    uint32_t fast;    // 1: use the split path
+};
+
+inline FastMod make_fastmod(uint64_t d)
+{
+    FastMod m{};
+    m.d = d;
+    uint64_t c = d;
+    uint32_t s = 0;
+    while (c && (c & 1) == 0) {
+        c >>= 1;
+        s++;
+    }
+    m.s = s;
+    m.c = (uint32_t)c;
+    m.fast = (c >= 1 && c < 65536) ? 1u : 0u;
+    if (m.fast) {
+        m.magic = c == 1 ? 0 : (0xFFFFFFFFFFFFFFFFULL / c + 1);
+        m.two32 = (uint32_t)((1ULL << 32) % c);
+    }
+    return m;
+}
+
+__device__ inline uint32_t mod32(uint32_t a, const FastMod& m)
+{
+    uint64_t low = m.magic * (uint64_t)a;
+    return (uint32_t)__umul64hi(low, (uint64_t)m.c);
+}
+
+__device__ inline uint64_t fastmod(uint64_t x, const FastMod& m)
+{
+    if (!m.fast)
+        return x % m.d;
+    uint64_t low = x & ((1ULL << m.s) - 1);
+    if (m.c == 1)
+        return low;
+    uint64_t q = x >> m.s;
+    uint32_t r = mod32((uint32_t)(q >> 32), m) * m.two32 + mod32((uint32_t)q, m);
+    r = mod32(r, m);
+    return ((uint64_t)r << m.s) | low;
+}
+
+// first lane of the active set appends `n_active` items with one atomic
+__device__ inline uint32_t wave_append(uint32_t* counter)
+{
+    uint64_t mask = __ballot(1);
+    int lane = (int)(threadIdx.x & 63);
+    uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((uint32_t)lane == leader)
+        base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    uint32_t rank = (uint32_t)__popcll(mask & ((1ULL << lane) - 1));
+    return base + rank;
+}
+
+} // namespace gp

@@ -1,0 +1,141 @@
+// gp_internal.h -- host-side state behind the C ABI (include/gpcore.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/gpcore.h"
+#include "gp_device.h"
+
+namespace gp {
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define GP_HIP(call)                                                    \
+    do {                                                                \
+        hipError_t e__ = (call);                                        \
+        if (e__ != hipSuccess)                                          \
+            return gp::hip_fail(e__, #call, __FILE__, __LINE__);        \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count)
+    {
+        release();
+        if (count == 0)
+            count = 1;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error(std::string("hipMalloc of ") + std::to_string(count * sizeof(T)) +
+                      " bytes failed: " + hipGetErrorString(e));
+            return GP_ERR_OOM;
+        }
+        n = count;
+        return GP_OK;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+struct KernelTimer {
+    // pairs of events recorded around launches of one kernel family
+    std::vector<hipEvent_t> start, stop;
+    std::vector<uint64_t> units;
+    size_t used = 0;
+    double total_ms = 0;
+    uint64_t launches = 0, total_units = 0;
+    void reset() { used = 0; total_ms = 0; launches = 0; total_units = 0; }
+    int begin(hipStream_t s, uint64_t n_units);
+    int end(hipStream_t s);
+    int collect(); // after a stream sync
+    void destroy();
+};
+
+} // namespace gp
+
+struct gp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop{};
+};
+
+// Per-k constants of the rolling hash, prepared on the host.
+struct KConsts {
+    uint32_t k;
+    uint64_t out_fwd[4]; // sroln(seed(code), k): what leaves the forward hash
+    uint64_t in_rev[4];  // sroln(seed(code ^ 2), k): what enters the reverse hash
+};
+
+struct gp_job {
+    gp_ctx* ctx = nullptr;
+    gp_params prm{};
+    uint32_t n_batches = 0, n_contigs = 0, n_reads = 0;
+
+    // ---- inputs resident in HBM
+    // reads: every read followed by one '\n' separator, in (batch, contig, rank)
+    // order, so that a k-mer never spans two reads and "position in this buffer"
+    // is the serial order the reference feeds its counting filter in.
+    gp::DevBuf<uint8_t> d_reads;
+    uint64_t read_positions = 0;          // bytes in d_reads
+    gp::DevBuf<uint64_t> d_seg_start;     // [n_contigs+1] first position of each contig's reads
+    gp::DevBuf<uint32_t> d_seg_batch;     // [n_contigs]
+    gp::DevBuf<uint32_t> d_seg_thr;       // [n_contigs] kmer_threshold of the contig
+    std::vector<uint64_t> h_seg_start;
+    std::vector<uint32_t> h_batch_contig_begin, h_contig_batch, h_contig_thr, h_contig_name_len;
+
+    gp::DevBuf<uint8_t> d_contigs_in;     // original contigs, concatenated
+    std::vector<uint64_t> h_contig_off;
+
+    // ---- filters
+    gp::DevBuf<uint8_t> d_cbf;            // [n_batches][n_k][cbf_bytes]
+    gp::DevBuf<uint32_t> d_bf;            // [n_batches][n_k][bf_bytes/4]
+
+    // ---- stage A work buffers
+    gp::DevBuf<uint32_t> d_resv[2];       // reservation tables (hashed slots)
+    uint32_t resv_bits = 0;
+    gp::DevBuf<uint4> d_pending[2];       // {hash lo, hash hi, pos, meta}
+    gp::DevBuf<uint32_t> d_counts;        // [kMaxRounds+2] pending count per round
+    gp::DevBuf<unsigned long long> d_stats; // device-side gp_counters
+    uint64_t window = 0;
+    uint32_t* h_count_pinned = nullptr;
+
+    // ---- stage B/C state (see stage_b.hip / stage_c.hip)
+    struct StageBC* bc = nullptr;
+
+    gp::KernelTimer t_first_pass, t_round, t_scan, t_walk, t_bfs;
+    gp_counters counters{};
+    bool filters_ready = false;
+};
+
+namespace gp {
+int stage_a_prepare(gp_job* job);            // allocate work buffers
+int stage_a_run(gp_job* job);                // enqueue + drive the filter build
+void stage_a_release(gp_job* job);
+int stage_bc_prepare(gp_job* job);
+void stage_bc_release(gp_job* job);
+int stage_b_reset(gp_job* job);              // current sequences := inputs
+int stage_b_pass(gp_job* job, uint32_t ki);
+int stage_b_guard(gp_job* job);
+int stage_mask(gp_job* job);
+int stage_c_run(gp_job* job);
+int stage_upper(gp_job* job);
+int stage_lengths(gp_job* job, uint64_t* lengths, uint8_t* dropped, uint64_t* total);
+int stage_sequences(gp_job* job, uint8_t* buf, uint64_t buf_bytes);
+} // namespace gp

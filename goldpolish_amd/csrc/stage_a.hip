@@ -1,0 +1,497 @@
+// stage_a.hip -- stage A of the path on MI355X: ntHash every k-mer of every
+// mapped read and build the per-batch Bloom filters through the counting
+// filter threshold.
+//
+// What it replaces: fill_bfs (/root/reference/src/utils.cpp:96-123) as driven
+// by serve_batch (/root/reference/src/goldpolish_targeted_bfs.cpp:55-146).
+// The reference feeds one counting filter per (batch, k) *serially*: reads in
+// rank order, k-mers left to right, each doing
+//     c = min of its 4 counters; if (c < thr) { counters == c become c+1; c++ }
+//     if (c >= thr) insert the k-mer into the batch's Bloom filter
+// which makes the result depend on that order.  The same result is produced
+// here in parallel:
+//
+//   * "position in the concatenated read buffer" IS the serial order, so an
+//     operation's identity is (k index, position).
+//   * Counters never exceed thr and never decrease.  An operation that sees
+//     all of its counters >= thr-1 -- at ANY time, even ahead of its turn --
+//     must end with those counters == thr and with its k-mer inserted, whatever
+//     happens before it; it completes immediately (first_pass / round kernels,
+//     "settled" path).
+//   * Every other operation takes a deterministic reservation: it writes its
+//     position with atomicMin into a hashed slot for each of its counters; in
+//     the next launch the operations that hold all their slots are exactly
+//     those with no earlier unfinished operation on any of their counters, so
+//     they apply the serial update; the rest retry.  Two tables alternate so
+//     commit(r) and reserve(r+1) share one launch.
+//
+// Memory behaviour: the sequence is streamed once per k through LDS (coalesced
+// 1 B/base); the counter / bit accesses are 1-byte random accesses into 10 MiB
+// (counters) and 512 KiB (bits) per (batch, k) -- HBM/Infinity-Cache
+// transaction-bound, no reuse to tile for.  Integer / bitwise work only.
+#include "gp_internal.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace gp {
+
+constexpr int kTile = 1024;        // positions per workgroup
+constexpr int kPerThread = 4;      // consecutive positions per lane
+constexpr int kBlock = kTile / kPerThread;
+constexpr int kHalo = 64;          // k <= 64
+constexpr uint32_t kMaxRounds = 4094;
+constexpr int kRoundBlocks = 2048;
+
+struct AArgs {
+    const uint8_t* reads;
+    uint64_t n_pos;
+    const uint64_t* seg_start;
+    const uint32_t* seg_batch;
+    const uint32_t* seg_thr;
+    uint32_t n_seg;
+    uint8_t* cbf;
+    uint32_t* bf;
+    uint32_t n_k, hash_num;
+    uint64_t cbf_bytes;
+    uint32_t bf_words;
+    FastMod cbf_mod, bf_mod;
+    KConsts kc[GP_MAX_K_VALUES];
+    uint32_t* resv_cur;  // table the incoming list reserved in
+    uint32_t* resv_next; // table losers reserve in for the next round
+    uint32_t resv_bits;
+    uint4* list_in;
+    uint4* list_out;
+    uint32_t* counts;    // counts[r] = length of the list round r consumes
+    uint32_t round;
+    uint64_t win_start, win_end;
+    unsigned long long* stats; // [0] positions [1] ops [2] ordered ops
+};
+
+__device__ inline uint32_t resv_slot(const AArgs& a, uint32_t stream, uint32_t idx)
+{
+    uint64_t key = (uint64_t)stream * a.cbf_bytes + idx;
+    return (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> (64 - a.resv_bits));
+}
+
+__device__ inline void bf_insert(const AArgs& a, uint32_t stream, const uint64_t* hv)
+{
+    uint32_t* w = a.bf + (uint64_t)stream * a.bf_words;
+    for (uint32_t i = 0; i < a.hash_num; i++) {
+        uint64_t n = fastmod(hv[i], a.bf_mod);
+        uint32_t bit = 1u << (uint32_t)(n & 31);
+        uint32_t* p = w + (n >> 5);
+        // a stale read only costs a redundant atomic: bits are never cleared
+        if (!(*p & bit))
+            atomicOr(p, bit);
+    }
+}
+
+// One operation whose hash is known.  Returns true when it is finished, false
+// when it has to wait for its turn (then idx[] holds its counter indices).
+__device__ inline bool try_settle(const AArgs& a, uint32_t stream, uint32_t thr, uint32_t k,
+                                  uint64_t base, uint32_t* idx)
+{
+    uint64_t hv[kMaxHash];
+    hv[0] = base;
+    for (uint32_t i = 1; i < a.hash_num; i++)
+        hv[i] = ext_hash(base, k, i);
+    uint8_t* cb = a.cbf + (uint64_t)stream * a.cbf_bytes;
+    uint32_t c[kMaxHash];
+    uint32_t m = 255;
+    for (uint32_t i = 0; i < a.hash_num; i++) {
+        idx[i] = (uint32_t)fastmod(hv[i], a.cbf_mod);
+        c[i] = cb[idx[i]];
+        m = min(m, c[i]);
+    }
+    if (m + 1 < thr)
+        return false;
+    // every counter is already >= thr-1: order cannot matter any more
+    for (uint32_t i = 0; i < a.hash_num; i++)
+        if (c[i] < thr)
+            cb[idx[i]] = (uint8_t)thr;
+    bf_insert(a, stream, hv);
+    return true;
+}
+
+__device__ inline void reserve(const AArgs& a, uint32_t* table, uint32_t stream,
+                               const uint32_t* idx, uint32_t pos)
+{
+    for (uint32_t i = 0; i < a.hash_num; i++)
+        atomicMin(&table[resv_slot(a, stream, idx[i])], pos);
+}
+
+// ---- first pass over a window: hash, settle what can be settled, reserve the rest
+__global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
+{
+    __shared__ uint8_t codes[kTile + kHalo];
+    __shared__ unsigned long long s_stats[3];
+    const uint32_t ki = blockIdx.y;
+    const KConsts& kc = a.kc[ki];
+    const uint32_t k = kc.k;
+    const uint64_t tile0 = a.win_start + (uint64_t)blockIdx.x * kTile;
+
+    if (threadIdx.x < 3)
+        s_stats[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < kTile + kHalo; i += kBlock) {
+        uint64_t p = tile0 + i;
+        uint8_t c = p < a.n_pos ? a.reads[p] : (uint8_t)'\n';
+        codes[i] = base_code(c);
+    }
+    __syncthreads();
+
+    const int t0 = threadIdx.x * kPerThread;
+    const uint64_t pos0 = tile0 + t0;
+    uint32_t n_ops = 0, n_ordered = 0, n_positions = 0;
+    if (pos0 < a.win_end) {
+        // segment (= contig's read block) that holds pos0
+        uint32_t lo = 0, hi = a.n_seg;
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (a.seg_start[mid] <= pos0)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        uint32_t seg = lo;
+        uint64_t seg_end = a.seg_start[seg + 1];
+
+        // hash of the first window; bad bytes contribute 0 so rolling stays exact
+        uint64_t fh = 0, rh = 0;
+        int last_bad = -1;
+        for (uint32_t i = 0; i < k; i++) {
+            uint32_t cf = codes[t0 + i];
+            uint32_t cr = codes[t0 + k - 1 - i];
+            fh = srol1(fh) ^ (cf < 4 ? seed_of_code(cf) : 0ULL);
+            rh = srol1(rh) ^ (cr < 4 ? seed_of_code(cr ^ 2) : 0ULL);
+            if (cf >= 4)
+                last_bad = (int)i;
+        }
+        for (int j = 0; j < kPerThread; j++) {
+            const uint64_t pos = pos0 + j;
+            if (pos >= a.win_end)
+                break;
+            if (j > 0) {
+                uint32_t out = codes[t0 + j - 1], in = codes[t0 + j + k - 1];
+                uint64_t s_in = in < 4 ? seed_of_code(in) : 0ULL;
+                uint64_t s_outk = out < 4 ? kc.out_fwd[out] : 0ULL;
+                uint64_t r_ink = in < 4 ? kc.in_rev[in] : 0ULL;
+                uint64_t r_out = out < 4 ? seed_of_code(out ^ 2) : 0ULL;
+                fh = srol1(fh) ^ s_in ^ s_outk;
+                rh = sror1(rh ^ r_ink ^ r_out);
+                if (in >= 4)
+                    last_bad = j + (int)k - 1;
+            }
+            n_positions++;
+            if (last_bad >= j || pos + k > a.n_pos)
+                continue;
+            while (pos >= seg_end) {
+                seg++;
+                seg_end = a.seg_start[seg + 1];
+            }
+            const uint32_t stream = a.seg_batch[seg] * a.n_k + ki;
+            const uint32_t thr = a.seg_thr[seg] - 2 + ki;
+            const uint64_t base = fh + rh;
+            uint32_t idx[kMaxHash];
+            n_ops++;
+            if (try_settle(a, stream, thr, k, base, idx))
+                continue;
+            n_ordered++;
+            const uint32_t rel = (uint32_t)(pos - a.win_start);
+            reserve(a, a.resv_cur, stream, idx, rel);
+            uint32_t at = wave_append(&a.counts[0]);
+            a.list_out[at] = make_uint4((uint32_t)base, (uint32_t)(base >> 32), rel,
+                                        (seg << 3) | ki);
+        }
+    }
+    atomicAdd(&s_stats[0], (unsigned long long)n_positions);
+    atomicAdd(&s_stats[1], (unsigned long long)n_ops);
+    atomicAdd(&s_stats[2], (unsigned long long)n_ordered);
+    __syncthreads();
+    if (threadIdx.x < 3 && s_stats[threadIdx.x])
+        atomicAdd(&a.stats[threadIdx.x], s_stats[threadIdx.x]);
+}
+
+// ---- one reservation round: commit the holders, let the others retry
+__global__ __launch_bounds__(256) void cbf_round(AArgs a)
+{
+    const uint32_t n_in = a.counts[a.round];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in;
+         i += gridDim.x * blockDim.x) {
+        const uint4 rec = a.list_in[i];
+        const uint64_t base = ((uint64_t)rec.y << 32) | rec.x;
+        const uint32_t pos = rec.z;
+        const uint32_t ki = rec.w & 7, seg = rec.w >> 3;
+        const uint32_t k = a.kc[ki].k;
+        const uint32_t stream = a.seg_batch[seg] * a.n_k + ki;
+        const uint32_t thr = a.seg_thr[seg] - 2 + ki;
+
+        uint64_t hv[kMaxHash];
+        uint32_t idx[kMaxHash], slot[kMaxHash];
+        hv[0] = base;
+        bool mine = true;
+        for (uint32_t h = 0; h < a.hash_num; h++) {
+            if (h)
+                hv[h] = ext_hash(base, k, h);
+            idx[h] = (uint32_t)fastmod(hv[h], a.cbf_mod);
+            slot[h] = resv_slot(a, stream, idx[h]);
+            mine &= (a.resv_cur[slot[h]] == pos);
+        }
+        // hand back whatever this operation holds, winner or not, so the table
+        // is all-free again when it is reused two rounds later
+        for (uint32_t h = 0; h < a.hash_num; h++)
+            if (a.resv_cur[slot[h]] == pos)
+                a.resv_cur[slot[h]] = kNoResv;
+
+        uint8_t* cb = a.cbf + (uint64_t)stream * a.cbf_bytes;
+        if (mine) {
+            // no earlier unfinished operation touches these counters: serial update
+            uint32_t c[kMaxHash], m = 255;
+            for (uint32_t h = 0; h < a.hash_num; h++) {
+                c[h] = cb[idx[h]];
+                m = min(m, c[h]);
+            }
+            if (m < thr) {
+                for (uint32_t h = 0; h < a.hash_num; h++)
+                    if (c[h] == m)
+                        cb[idx[h]] = (uint8_t)(m + 1);
+                m++;
+            }
+            if (m >= thr)
+                bf_insert(a, stream, hv);
+            continue;
+        }
+        uint32_t idx2[kMaxHash];
+        if (try_settle(a, stream, thr, k, base, idx2))
+            continue;
+        reserve(a, a.resv_next, stream, idx, pos);
+        uint32_t at = wave_append(&a.counts[a.round + 1]);
+        a.list_out[at] = rec;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+int KernelTimer::begin(hipStream_t s, uint64_t n_units)
+{
+    if (used == start.size()) {
+        hipEvent_t a, b;
+        GP_HIP(hipEventCreate(&a));
+        GP_HIP(hipEventCreate(&b));
+        start.push_back(a);
+        stop.push_back(b);
+        units.push_back(0);
+    }
+    units[used] = n_units;
+    GP_HIP(hipEventRecord(start[used], s));
+    return GP_OK;
+}
+
+int KernelTimer::end(hipStream_t s)
+{
+    GP_HIP(hipEventRecord(stop[used], s));
+    used++;
+    return GP_OK;
+}
+
+int KernelTimer::collect()
+{
+    for (size_t i = 0; i < used; i++) {
+        float ms = 0;
+        GP_HIP(hipEventElapsedTime(&ms, start[i], stop[i]));
+        total_ms += ms;
+        launches++;
+        total_units += units[i];
+    }
+    used = 0;
+    return GP_OK;
+}
+
+void KernelTimer::destroy()
+{
+    for (auto e : start)
+        (void)hipEventDestroy(e);
+    for (auto e : stop)
+        (void)hipEventDestroy(e);
+    start.clear();
+    stop.clear();
+    units.clear();
+    used = 0;
+}
+
+static uint64_t env_u64(const char* name, uint64_t dflt)
+{
+    const char* v = getenv(name);
+    if (!v || !*v)
+        return dflt;
+    return strtoull(v, nullptr, 10);
+}
+
+int stage_a_prepare(gp_job* job)
+{
+    const gp_params& p = job->prm;
+    // window: how many read positions are hashed per launch.  The pending lists
+    // are sized for the worst case (every k-mer of every k must wait).
+    uint64_t w = env_u64("GP_STAGE_A_WINDOW", 8ull << 20);
+    w = std::max<uint64_t>(w, kTile);
+    w = std::min<uint64_t>(w, std::max<uint64_t>(job->read_positions, kTile));
+    w = (w + kTile - 1) / kTile * kTile;
+    job->window = w;
+    const uint64_t max_pending = w * p.n_k;
+    if (max_pending >= (1ull << 31)) {
+        set_error("stage A window too large");
+        return GP_ERR_INVALID_ARG;
+    }
+    int rc;
+    for (int i = 0; i < 2; i++)
+        if ((rc = job->d_pending[i].alloc(max_pending)) != GP_OK)
+            return rc;
+    // reservation slots: >= 8 per possible pending counter touch, power of two
+    uint32_t bits = 16;
+    while ((1ull << bits) < max_pending * p.hash_num * 2 && bits < 28)
+        bits++;
+    job->resv_bits = bits;
+    for (int i = 0; i < 2; i++)
+        if ((rc = job->d_resv[i].alloc(1ull << bits)) != GP_OK)
+            return rc;
+    if ((rc = job->d_counts.alloc(kMaxRounds + 2)) != GP_OK)
+        return rc;
+    if ((rc = job->d_stats.alloc(16)) != GP_OK)
+        return rc;
+    GP_HIP(hipHostMalloc((void**)&job->h_count_pinned, 64));
+    return GP_OK;
+}
+
+void stage_a_release(gp_job* job)
+{
+    if (job->h_count_pinned)
+        (void)hipHostFree(job->h_count_pinned);
+    job->h_count_pinned = nullptr;
+}
+
+int stage_a_run(gp_job* job)
+{
+    const gp_params& p = job->prm;
+    hipStream_t s = job->ctx->stream;
+    AArgs a{};
+    a.reads = job->d_reads.p;
+    a.n_pos = job->read_positions;
+    a.seg_start = job->d_seg_start.p;
+    a.seg_batch = job->d_seg_batch.p;
+    a.seg_thr = job->d_seg_thr.p;
+    a.n_seg = job->n_contigs;
+    a.cbf = job->d_cbf.p;
+    a.bf = job->d_bf.p;
+    a.n_k = p.n_k;
+    a.hash_num = p.hash_num;
+    a.cbf_bytes = p.cbf_bytes;
+    a.bf_words = (uint32_t)(p.bf_bytes / 4);
+    a.cbf_mod = make_fastmod(p.cbf_bytes);
+    a.bf_mod = make_fastmod(p.bf_bytes * 8);
+    for (uint32_t i = 0; i < p.n_k; i++) {
+        a.kc[i].k = p.k[i];
+        for (uint32_t c = 0; c < 4; c++) {
+            a.kc[i].out_fwd[c] = sroln(seed_of_code(c), p.k[i]);
+            a.kc[i].in_rev[c] = sroln(seed_of_code(c ^ 2), p.k[i]);
+        }
+    }
+    a.resv_bits = job->resv_bits;
+    a.stats = job->d_stats.p;
+
+    job->t_first_pass.reset();
+    job->t_round.reset();
+    job->counters.a_rounds = 0;
+
+    // fresh filters + free reservation tables
+    GP_HIP(hipMemsetAsync(job->d_cbf.p, 0, job->d_cbf.n, s));
+    GP_HIP(hipMemsetAsync(job->d_bf.p, 0, job->d_bf.n * sizeof(uint32_t), s));
+    GP_HIP(hipMemsetAsync(job->d_stats.p, 0, 16 * sizeof(unsigned long long), s));
+    for (int i = 0; i < 2; i++)
+        GP_HIP(hipMemsetAsync(job->d_resv[i].p, 0xFF, job->d_resv[i].n * sizeof(uint32_t), s));
+
+    if (job->read_positions == 0 || job->n_contigs == 0) {
+        job->filters_ready = true;
+        return GP_OK;
+    }
+
+    for (uint64_t w0 = 0; w0 < job->read_positions; w0 += job->window) {
+        const uint64_t w1 = std::min(job->read_positions, w0 + job->window);
+        GP_HIP(hipMemsetAsync(job->d_counts.p, 0, (kMaxRounds + 2) * sizeof(uint32_t), s));
+        a.win_start = w0;
+        a.win_end = w1;
+        a.counts = job->d_counts.p;
+        a.resv_cur = job->d_resv[0].p;
+        a.resv_next = job->d_resv[1].p;
+        a.list_in = nullptr;
+        a.list_out = job->d_pending[0].p;
+        a.round = 0;
+        dim3 grid((unsigned)((w1 - w0 + kTile - 1) / kTile), p.n_k);
+        int rc = job->t_first_pass.begin(s, (w1 - w0) * p.n_k);
+        if (rc != GP_OK)
+            return rc;
+        hipLaunchKernelGGL(cbf_first_pass, grid, dim3(kBlock), 0, s, a);
+        GP_HIP(hipGetLastError());
+        if ((rc = job->t_first_pass.end(s)) != GP_OK)
+            return rc;
+
+        // rounds: launched in growing chunks, the pending count is read back
+        // after each chunk (a launch on an empty list costs a few microseconds)
+        uint32_t round = 0, chunk = 2;
+        uint64_t rounds_here = 0;
+        for (;;) {
+            // every round finishes at least the earliest waiting operation, so this
+            // is a bug trap, not a limit anyone should meet
+            if (rounds_here > (1u << 22)) {
+                set_error("stage A: reservation rounds did not converge");
+                return GP_ERR_STATE;
+            }
+            rounds_here += chunk;
+            if ((rc = job->t_round.begin(s, chunk)) != GP_OK)
+                return rc;
+            for (uint32_t c = 0; c < chunk && round < kMaxRounds; c++, round++) {
+                a.round = round;
+                a.resv_cur = job->d_resv[round & 1].p;
+                a.resv_next = job->d_resv[(round + 1) & 1].p;
+                a.list_in = job->d_pending[round & 1].p;
+                a.list_out = job->d_pending[(round + 1) & 1].p;
+                hipLaunchKernelGGL(cbf_round, dim3(kRoundBlocks), dim3(256), 0, s, a);
+            }
+            GP_HIP(hipGetLastError());
+            if ((rc = job->t_round.end(s)) != GP_OK)
+                return rc;
+            GP_HIP(hipMemcpyAsync(job->h_count_pinned, job->d_counts.p + round, sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, s));
+            GP_HIP(hipStreamSynchronize(s));
+            job->counters.a_rounds += chunk;
+            if (*job->h_count_pinned == 0)
+                break;
+            if (round >= kMaxRounds) {
+                // carry the survivors over into a fresh counter array
+                uint32_t left = *job->h_count_pinned;
+                GP_HIP(hipMemsetAsync(job->d_counts.p, 0, (kMaxRounds + 2) * sizeof(uint32_t), s));
+                GP_HIP(hipMemcpyAsync(job->d_counts.p, job->h_count_pinned, sizeof(uint32_t),
+                                      hipMemcpyHostToDevice, s));
+                (void)left;
+                // parity of `round` (even: kMaxRounds is even) keeps list/table roles
+                round = 0;
+            }
+            chunk = std::min<uint32_t>(chunk * 2, 64);
+        }
+    }
+    unsigned long long st[3];
+    GP_HIP(hipMemcpyAsync(st, job->d_stats.p, sizeof st, hipMemcpyDeviceToHost, s));
+    GP_HIP(hipStreamSynchronize(s));
+    job->counters.a_positions = st[0];
+    job->counters.a_ops = st[1];
+    job->counters.a_ordered_ops = st[2];
+    int rc = job->t_first_pass.collect();
+    if (rc != GP_OK)
+        return rc;
+    if ((rc = job->t_round.collect()) != GP_OK)
+        return rc;
+    job->filters_ready = true;
+    return GP_OK;
+}
+
+} // namespace gp

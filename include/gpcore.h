@@ -1,0 +1,174 @@
+/*
+ * gpcore.h -- C ABI of libgpcore, the MI355X-native GoldPolish polishing core.
+ *
+ * Drop-in boundary for the reference's per-batch k-mer correction path
+ * (SURVEY.md section 8b): everything `goldpolish-targeted-bfs` (filter build),
+ * `ntedit-gr` (substitution / indel sweep), `goldpolish-mask`, `sealer-gr`
+ * (gap-fill BFS) and `goldpolish-to-upper` do for a batch, as one in-process
+ * call on device-resident data.  Plain pointers and sizes only; no C++ or
+ * torch types cross this boundary.  Every function returns 0 (GP_OK) or a
+ * negative gp_status and never throws; the message for the calling thread's
+ * last failure is gp_last_error().  A gp_ctx may be used by one thread at a
+ * time; different contexts are independent.
+ *
+ * There is no CPU fallback: gp_ctx_create fails with GP_ERR_NO_DEVICE when no
+ * gfx950 device is usable.
+ */
+#ifndef GPCORE_H
+#define GPCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GP_MAX_K_VALUES 8
+
+typedef enum gp_status {
+    GP_OK = 0,
+    GP_ERR_INVALID_ARG = -1,   /* bad pointer / size / parameter combination */
+    GP_ERR_NO_DEVICE = -2,     /* no usable HIP device (no CPU fallback exists) */
+    GP_ERR_HIP = -3,           /* a HIP runtime call failed; see gp_last_error() */
+    GP_ERR_OOM = -4,           /* device or host allocation failed */
+    GP_ERR_THRESHOLD = -5,     /* kmer_threshold < 4 (reference: src/utils.cpp:105-107) */
+    GP_ERR_STATE = -6,         /* stage called out of order */
+    GP_ERR_UNSUPPORTED = -7    /* parameter outside what the kernels implement */
+} gp_status;
+
+typedef struct gp_ctx gp_ctx; /* one per device */
+typedef struct gp_job gp_job; /* a set of batches resident on the device */
+
+/* Parameters of the path.  Defaults = what GoldPolish passes:
+ *   k list 32,28,24,20                       scripts/goldpolish:189-190
+ *   hash_num 4, cbf 10 MiB, bf 512 KiB       src/goldpolish_targeted_bfs.cpp:270-272
+ *   ntEdit -d5 -i5 -m1 -X0.5 -Y0.5 -a1 -j3 -z100   scripts/goldpolish-ntedit:27,
+ *                                            subprojects/ntedit/ntedit.cpp:85-115
+ *   mask -s -k<first k>                      scripts/goldpolish-make:65-66
+ *   Sealer -L<first k> -P10 -B1000 --lower, -G800 -C100000
+ *                                            scripts/goldpolish-make:68-72,
+ *                                            subprojects/sealer/sealer.cpp:131-165 */
+typedef struct gp_params {
+    uint32_t n_k;
+    uint32_t k[GP_MAX_K_VALUES]; /* descending, each 4..64 */
+    uint32_t hash_num;           /* 1..8 */
+    uint64_t cbf_bytes;          /* counting filter: one u8 counter per byte */
+    uint64_t bf_bytes;           /* Bloom filter bytes (bits = 8x) */
+    /* ntEdit */
+    uint32_t max_insertions;     /* -i 0..5 */
+    uint32_t max_deletions;      /* -d 0..10 */
+    int32_t mode;                /* -m; only 1 (GoldPolish's) is implemented on device */
+    float missing_ratio;         /* -X */
+    float edit_ratio;            /* -Y */
+    uint32_t jump;               /* -j */
+    uint32_t min_contig_len;     /* -z */
+    int32_t soft_mask;           /* -a */
+    /* Sealer */
+    uint32_t sealer_max_gap;     /* -G */
+    uint32_t sealer_max_paths;   /* -P */
+    uint32_t sealer_max_branches;/* -B */
+    uint32_t sealer_max_cost;    /* -C */
+    int32_t run_sealer;          /* 0 skips stage C (mask and upper still run) */
+} gp_params;
+
+/* A set of batches in flat arrays (host memory, caller-owned, read during
+ * gp_job_create only).  Batch b holds contigs [batch_contig_begin[b],
+ * batch_contig_begin[b+1]); contig c holds bytes contig_buf[contig_off[c] ..
+ * contig_off[c+1]) and uses reads [contig_read_begin[c], contig_read_begin[c+1])
+ * -- ALREADY ranked and truncated as serve_batch does
+ * (src/goldpolish_targeted_bfs.cpp:96-123; gp_rank_reads implements it) -- with
+ * counting threshold contig_kmer_threshold[c] (gp_kmer_threshold).
+ * contig_name_len[c] = strlen("id[ comment]") feeds the 0.75 byte-ratio guard of
+ * scripts/goldpolish-ntedit:31-40. */
+typedef struct gp_batch_set {
+    uint32_t n_batches;
+    const uint32_t* batch_contig_begin; /* [n_batches+1] */
+    uint32_t n_contigs;
+    const uint8_t* contig_buf;
+    const uint64_t* contig_off;         /* [n_contigs+1] */
+    const uint32_t* contig_name_len;    /* [n_contigs] */
+    const uint32_t* contig_read_begin;  /* [n_contigs+1] */
+    const uint32_t* contig_kmer_threshold; /* [n_contigs] */
+    uint32_t n_reads;
+    const uint8_t* read_buf;
+    const uint64_t* read_off;           /* [n_reads+1] */
+} gp_batch_set;
+
+/* Work counters, filled by the kernels themselves (the
+ * data-dependent terms of the algorithmic-bytes formula). */
+typedef struct gp_counters {
+    uint64_t a_positions;    /* read bases streamed by the filter build, summed over k */
+    uint64_t a_ops;          /* valid k-mers = insert_thresh_contains calls */
+    uint64_t a_ordered_ops;  /* ops that needed the ordered (reservation) path */
+    uint64_t a_rounds;       /* reservation rounds launched */
+    uint64_t b_scan_kmers;   /* k-mers tested by the membership scan */
+    uint64_t b_sites;        /* positions where an absent k-mer was confirmed */
+    uint64_t b_probes;       /* Bloom filter look-ups in the trial sweep */
+    uint64_t b_edits;        /* accepted substitutions + indels */
+    uint64_t c_gaps;         /* gaps found */
+    uint64_t c_closed;       /* gaps closed */
+    uint64_t c_vertex_tests; /* k-mer membership tests during BFS */
+} gp_counters;
+
+/* ---- library / context ------------------------------------------------- */
+const char* gp_last_error(void);
+int gp_version(void);
+void gp_default_params(gp_params* p);
+int gp_ctx_create(int device, gp_ctx** out);
+void gp_ctx_destroy(gp_ctx* ctx);
+/* HIP stream (hipStream_t) every kernel of this context is launched on, so a
+ * caller can bracket gp_job_* calls with its own HIP events. */
+void* gp_ctx_stream(gp_ctx* ctx);
+
+/* ---- host-side helpers that belong to the path -------------------------- */
+/* mappings_bases_to_kmer_threshold (src/goldpolish_targeted_bfs.cpp:45-53) */
+int gp_kmer_threshold(uint64_t mapped_bases);
+/* read ranking + cap of serve_batch (src/goldpolish_targeted_bfs.cpp:96-123):
+ * order[] receives the indices of the reads to use, best first; returns how
+ * many; *bases = sum of their lengths.  phred is truncated to an integer first,
+ * as the reference does. */
+size_t gp_rank_reads(size_t n, const char* const* ids, const double* phred_avg,
+                     const uint64_t* lens, uint64_t target_len, double max_reads_per_10kbp,
+                     uint32_t* order, uint64_t* bases);
+
+/* ---- jobs --------------------------------------------------------------- */
+/* Copies the batch set to the device (host->HBM over PCIe; NOT part of the
+ * polishing time) and allocates filters and work buffers. */
+int gp_job_create(gp_ctx* ctx, const gp_params* params, const gp_batch_set* set, gp_job** out);
+void gp_job_destroy(gp_job* job);
+/* The whole path for every batch of the job: filters -> ntEdit cascade (+guard)
+ * -> mask -> Sealer -> upper.  Asynchronous on gp_ctx_stream unless sync != 0.
+ * May be called again: it restarts from the uploaded inputs. */
+int gp_job_polish(gp_job* job, int sync);
+/* Individual stages, in order, for tests and profiling. */
+int gp_job_build_filters(gp_job* job, int sync);          /* stage A */
+int gp_job_ntedit_pass(gp_job* job, uint32_t k_index, int sync); /* stage B, one k */
+int gp_job_ntedit_guard(gp_job* job, int sync);           /* 0.75 byte-ratio guard */
+int gp_job_mask(gp_job* job, int sync);
+int gp_job_sealer(gp_job* job, int sync);                 /* stage C */
+int gp_job_upper(gp_job* job, int sync);
+int gp_job_sync(gp_job* job);
+
+/* ---- results (device -> host copies) ------------------------------------ */
+/* Bloom filter of batch b for k[k_index]: bf_bytes bytes into out. */
+int gp_job_get_filter(gp_job* job, uint32_t batch, uint32_t k_index, uint8_t* out);
+/* Replace the device filters with caller-supplied bytes (n_batches*n_k*bf_bytes,
+ * batch-major): lets stage B/C run against a known filter. */
+int gp_job_set_filters(gp_job* job, const uint8_t* filters);
+/* Current sequence of every contig: lengths[c] == 0 and dropped[c] == 1 for
+ * contigs ntEdit dropped (shorter than min_contig_len).  Sequences are returned
+ * concatenated in contig order; call with buf == NULL to get total bytes. */
+int gp_job_get_lengths(gp_job* job, uint64_t* lengths, uint8_t* dropped, uint64_t* total);
+int gp_job_get_sequences(gp_job* job, uint8_t* buf, uint64_t buf_bytes);
+int gp_job_get_counters(gp_job* job, gp_counters* out);
+/* Average device time (ms) of the dominant stage-A kernel's launches since the
+ * last gp_job_build_filters, measured with HIP events on the context stream,
+ * and the number of launches and streamed positions it covered. */
+int gp_job_kernel_time(gp_job* job, const char* kernel, double* total_ms, uint64_t* launches,
+                       uint64_t* units);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPCORE_H */

@@ -1,0 +1,141 @@
+"""Stage A parity on a real MI355X: the Bloom filters built by the HIP path
+(through the C ABI) must equal, bit for bit, the filters the oracle builds by
+replaying the reads serially (reference: src/utils.cpp:96-123)."""
+import os
+
+import numpy as np
+import pytest
+
+from goldpolish_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gp():
+    from goldpolish_amd import core
+    ctx = core.Context(0)
+    yield core, ctx
+    ctx.close()
+
+
+def oracle_filters(oracle, w, params, batch_contig_begin=None):
+    """filters[batch][ki] as numpy arrays, from the serial oracle"""
+    ks = list(params.k[:params.n_k])
+    n = w.n_contigs
+    bcb = list(batch_contig_begin) if batch_contig_begin is not None else list(range(n + 1))
+    out = []
+    for b in range(len(bcb) - 1):
+        cbfs = [np.zeros(params.cbf_bytes, dtype=np.uint8) for _ in ks]
+        bfs = [np.zeros(params.bf_bytes, dtype=np.uint8) for _ in ks]
+        for c in range(bcb[b], bcb[b + 1]):
+            reads = w.reads_of(c)
+            if reads:
+                oracle.fill_bfs(reads, ks, int(w.kmer_threshold[c]), params.cbf_bytes,
+                                params.bf_bytes, params.hash_num, cbfs, bfs)
+        out.append(bfs)
+    return out
+
+
+def run_and_compare(core, ctx, oracle, w, params, batch_contig_begin=None):
+    job = core.Job(ctx, params, contig_buf=w.contig_buf, contig_off=w.contig_off,
+                   contig_read_begin=w.contig_read_begin, kmer_threshold=w.kmer_threshold,
+                   read_buf=w.read_buf, read_off=w.read_off,
+                   batch_contig_begin=batch_contig_begin)
+    try:
+        job.build_filters()
+        want = oracle_filters(oracle, w, params, batch_contig_begin)
+        for b in range(job.n_batches):
+            for ki in range(params.n_k):
+                got = job.get_filter(b, ki)
+                assert np.array_equal(got, want[b][ki]), (b, ki, int((got != want[b][ki]).sum()))
+        return job.counters()
+    finally:
+        job.close()
+
+
+def test_filters_match_oracle_default_sizes(gp, oracle):
+    core, ctx = gp
+    w = synth.make_workload([25000, 9000, 14000], 30, seed=11)
+    c = run_and_compare(core, ctx, oracle, w, core.default_params())
+    assert c["a_ops"] > 0 and c["a_ordered_ops"] > 0
+
+
+def test_small_filters_heavy_collisions_and_saturation(gp, oracle):
+    """tiny counting filter: long dependency chains, saturation, settled shortcut"""
+    core, ctx = gp
+    w = synth.make_workload([20000, 20000], 25, seed=12)
+    for cbf, bf in [(4096, 2048), (65536 + 4, 4096), (10 * 1024, 1024 * 12)]:
+        p = core.default_params(k_values=[32, 20], cbf_bytes=cbf, bf_bytes=bf)
+        run_and_compare(core, ctx, oracle, w, p)
+
+
+def test_many_windows(gp, oracle, monkeypatch):
+    core, ctx = gp
+    monkeypatch.setenv("GP_STAGE_A_WINDOW", "4096")
+    w = synth.make_workload([15000, 8000], 12, seed=13)
+    run_and_compare(core, ctx, oracle, w, core.default_params(k_values=[28, 24]))
+
+
+def _custom_workload(contigs, reads_per_contig, thresholds):
+    names = [f"c{i}" for i in range(len(contigs))]
+    coff = np.zeros(len(contigs) + 1, dtype=np.uint64)
+    coff[1:] = np.cumsum([len(c) for c in contigs])
+    flat = [r for rs in reads_per_contig for r in rs]
+    roff = np.zeros(len(flat) + 1, dtype=np.uint64)
+    if flat:
+        roff[1:] = np.cumsum([len(r) for r in flat])
+    crb = np.zeros(len(contigs) + 1, dtype=np.uint32)
+    crb[1:] = np.cumsum([len(rs) for rs in reads_per_contig])
+    return synth.Workload(
+        names=names, contig_buf=np.frombuffer(b"".join(contigs), dtype=np.uint8),
+        contig_off=coff, read_buf=np.frombuffer(b"".join(flat) or b"", dtype=np.uint8),
+        read_off=roff, contig_read_begin=crb,
+        kmer_threshold=np.asarray(thresholds, dtype=np.uint32))
+
+
+def test_edge_cases_ragged_N_lowercase_repeats_and_shared_batches(gp, oracle):
+    core, ctx = gp
+    rng = np.random.default_rng(5)
+    g = synth.random_genome(6000, rng).tobytes()
+    low = g[:3000].lower()
+    with_n = bytearray(g[1000:4000])
+    for i in (10, 500, 501, 502, 1700, 2999):
+        with_n[i] = ord("N")
+    with_n[40] = ord("R")
+    homopolymer = b"A" * 700 + g[:100] + b"ACAC" * 300 + b"T" * 400
+    short = g[:19]          # shorter than every k
+    exactly_k = g[100:120]  # one 20-mer only
+    reads0 = [g, g[::1], low, bytes(with_n), homopolymer, homopolymer, short, exactly_k, b""]
+    reads1 = [g[2000:5000]] * 9 + [homopolymer] * 3
+    reads3 = [synth.revcomp(np.frombuffer(g, dtype=np.uint8)).tobytes()] * 7
+    contigs = [g, g[:500], b"ACGT" * 50, g[:4000]]
+    # contig 2 has no reads at all; contigs 0+1 share a batch with different thresholds
+    w = _custom_workload(contigs, [reads0, reads1, [], reads3], [5, 7, 5, 13])
+    p = core.default_params()
+    run_and_compare(core, ctx, oracle, w, p, batch_contig_begin=[0, 2, 3, 4])
+    # same data, one contig per batch, tiny filters
+    p2 = core.default_params(k_values=[32, 28, 24, 20], cbf_bytes=5000, bf_bytes=4096)
+    run_and_compare(core, ctx, oracle, w, p2)
+
+
+def test_threshold_below_4_is_refused(gp):
+    core, ctx = gp
+    w = _custom_workload([b"ACGT" * 100], [[b"ACGT" * 100]], [3])
+    with pytest.raises(core.GpError) as e:
+        core.Job(ctx, core.default_params(), contig_buf=w.contig_buf, contig_off=w.contig_off,
+                 contig_read_begin=w.contig_read_begin, kmer_threshold=w.kmer_threshold,
+                 read_buf=w.read_buf, read_off=w.read_off)
+    assert e.value.code == -5
+
+
+def test_idempotent_rebuild(gp, oracle):
+    """building twice gives the same filters (buffers are reset, no stale reservations)"""
+    core, ctx = gp
+    w = synth.make_workload([12000], 20, seed=14)
+    p = core.default_params(k_values=[32])
+    with core.Job.from_workload(ctx, p, w) as job:
+        job.build_filters()
+        a = job.get_filter(0, 0).copy()
+        job.build_filters()
+        assert np.array_equal(a, job.get_filter(0, 0))
