@@ -150,8 +150,8 @@ static int check_params(const gp_params& p)
         return GP_ERR_INVALID_ARG;
     }
     for (uint32_t i = 0; i < p.n_k; i++)
-        if (p.k[i] < 4 || p.k[i] > 64) {
-            set_error("params: every k must be 4..64");
+        if (p.k[i] < 4 || p.k[i] > 63) {
+            set_error("params: every k must be 4..63");
             return GP_ERR_UNSUPPORTED;
         }
     if (p.hash_num == 0 || p.hash_num > (uint32_t)kMaxHash) {

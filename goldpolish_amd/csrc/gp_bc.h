@@ -1,0 +1,40 @@
+// gp_bc.h -- device-resident state shared by stage B (stage_b.hip) and stage C
+// (stage_c.hip): the per-contig sequence slots and the ntEdit node lists.
+#pragma once
+
+#include "gp_internal.h"
+
+namespace gp {
+
+struct Node {
+    int32_t type; // -1 unset, 0 = contig[s..e], 1 = inserted char c
+    uint32_t s, e;
+    uint32_t c;
+};
+
+struct StageBC {
+    // two sequence buffers with identical per-contig slots; cur flips per pass
+    DevBuf<uint8_t> seq[2];
+    DevBuf<uint32_t> len[2];
+    DevBuf<uint64_t> off;     // [n_contigs+1] slot offsets (bytes)
+    DevBuf<uint8_t> dropped;  // [n_contigs]
+    DevBuf<Node> nodes;
+    DevBuf<uint64_t> node_off; // [n_contigs+1]
+    DevBuf<uint32_t> contig_batch, name_len, in_len;
+    DevBuf<uint64_t> in_off;
+    DevBuf<uint32_t> batch_begin; // [n_batches+1]
+    DevBuf<uint32_t> err;     // device-side error word
+    DevBuf<unsigned long long> stats; // b_scan_kmers, b_sites, b_probes, b_edits, c_*
+    DevBuf<uint8_t> batch_skip;
+    std::vector<uint64_t> h_off, h_node_off;
+    int cur = 0;
+    uint64_t total_slots = 0;
+    // stage C buffers live in stage_c.hip
+    void* c_state = nullptr;
+};
+
+
+int stage_c_prepare(gp_job* job);
+void stage_c_release(gp_job* job);
+
+} // namespace gp

@@ -70,6 +70,10 @@ struct KernelTimer {
 
 } // namespace gp
 
+namespace gp {
+struct StageBC;
+}
+
 struct gp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -117,7 +121,7 @@ struct gp_job {
     uint32_t* h_count_pinned = nullptr;
 
     // ---- stage B/C state (see stage_b.hip / stage_c.hip)
-    struct StageBC* bc = nullptr;
+    gp::StageBC* bc = nullptr;
 
     gp::KernelTimer t_first_pass, t_round, t_scan, t_walk, t_bfs;
     gp_counters counters{};

@@ -1,0 +1,1674 @@
+// stage_b.hip -- stage B of the path on MI355X: the ntEdit substitution / indel
+// trial sweep for every contig of a job against the batch's Bloom filter for
+// one k, plus the cascade guard and the two string transforms around stage C
+// (soft mask, upper-case).
+//
+// What it replaces: kmerizeAndCorrect and its helpers
+// (/root/reference/subprojects/ntedit/ntedit.cpp:393-1771) as invoked by
+// scripts/goldpolish-ntedit:20-40 (-d5 -i5 -m1 -X -Y -a1), then
+// scripts/goldpolish-mask:44-72 and scripts/goldpolish-to-upper:17-21.
+//
+// ntEdit is a strictly left-to-right state machine: an accepted edit changes
+// what every later position sees.  The device version keeps that order exact
+// and finds its parallelism inside each step instead:
+//   * one 256-thread workgroup per contig; thread 0 owns the edit state (the
+//     reference's node list of position runs and inserted characters, kept in
+//     HBM; cursors and hashes in LDS),
+//   * "scan": when everything right of the tail is untouched contig, the next
+//     256 k-mers are hashed and probed at once, one per lane, and the first
+//     absent one (ballot + ffs) is the next site -- nothing between is
+//     observable, so the walker jumps there,
+//   * "site": the confirm count, the 3 substitution trials and, when needed,
+//     the 341 insertion strings + deletions run one candidate per lane, each
+//     lane rolling its own hash over a shared LDS window and counting filter
+//     hits; the winner is picked with the reference's tie rule (later wins),
+//   * thresholds are evaluated on the host with the reference's float
+//     expressions and handed over as integers.
+// Filter probes are 4-byte random reads into 512 KiB (L2-resident); sequence
+// traffic is one byte per base per pass.  Integer / bitwise work only.
+#include "gp_internal.h"
+#include "gp_bc.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace gp {
+
+constexpr int kWalkThreads = 256;
+constexpr int kMaxK = 64;
+constexpr int kZMax = 2 * kMaxK + 16 + kWalkThreads; // window chars in LDS
+constexpr int kMaxCand = 341 + 16;
+
+struct WalkArgs {
+    uint8_t* seq;            // current sequences (mutated in place)
+    uint8_t* out;            // next sequences
+    const uint64_t* off;
+    const uint32_t* len_cur;
+    uint32_t* len_next;
+    uint8_t* dropped;
+    Node* nodes;
+    const uint64_t* node_off;
+    const uint32_t* bf;      // all filters
+    const uint32_t* contig_batch;
+    uint32_t n_k, ki, k, hash_num, bf_words;
+    FastMod bf_mod;
+    uint32_t max_ins_tries;  // num_tries[max_insertions]
+    uint32_t max_del, jump, min_contig_len, soft_mask;
+    uint32_t need_missing, need_edit, need_del; // integer forms of the float tests
+    uint32_t insertion_cap;
+    uint32_t* err;
+    unsigned long long* stats;
+};
+
+// ---------------------------------------------------------------- hashing
+struct HashTab {
+    uint64_t f[5], fk[5], r[5], rk[5]; // seeds (index 4 = 0) plain and rotated by k
+};
+
+__device__ inline uint32_t fcode(uint8_t c)
+{
+    uint8_t b = base_code(c);
+    return b == kBadCode ? 4u : b;
+}
+
+__device__ inline uint32_t rcode(uint8_t c)
+{
+    // reverse-strand seed class of a raw byte (reference: table[c & 7]); returns the
+    // code of the base whose FORWARD seed it is, or 4 for zero
+    switch (c & 7) {
+    case 1: return 2; // T
+    case 3: return 3; // G
+    case 4: return 0; // A
+    case 7: return 1; // C
+    default: return 4;
+    }
+}
+
+struct Ctx {
+    // per-workgroup constants
+    const WalkArgs* a;
+    uint8_t* seq;       // this contig (mutable)
+    Node* nd;
+    uint32_t node_cap;
+    const uint32_t* bf;
+    uint32_t len, k;
+};
+
+struct Shared {
+    HashTab ht;
+    // walker state (thread 0 writes)
+    uint32_t hi, ti, hn, tn, nn;
+    uint64_t fh, rh;
+    uint32_t char_in;
+    int32_t cur_tested;
+    uint32_t min_tested_ti;   // k-mers whose tail is left of this are still being skipped
+    int32_t request;
+    uint32_t nz;              // chars available in Z
+    uint32_t scan_j0, scan_n; // first k-mer index / number of k-mers of the scan
+    uint32_t scan_found;
+    uint32_t draft;
+    uint32_t n_sub;
+    uint8_t subs[4];
+    uint32_t sub_in_bf[4], sub_present[4];
+    uint32_t confirm_missing, confirm_bad;
+    uint32_t num_del;
+    uint32_t sweep_index_char, sweep_del_from;
+    uint32_t best_key;        // (support << 16) | order, reduced with atomicMax
+    unsigned long long st_scan, st_sites, st_probes, st_edits;
+    uint8_t Z[kZMax];
+    uint64_t scan_fh[kWalkThreads], scan_rh[kWalkThreads];
+    uint32_t wave_min[kWalkThreads / 64];
+    uint8_t cand_sup[kMaxCand];
+};
+
+enum { REQ_DONE = 0, REQ_SCAN, REQ_SITE, REQ_NEXT };
+
+__device__ inline uint64_t roll_f(const HashTab& t, uint64_t fh, uint8_t out, uint8_t in)
+{
+    return srol1(fh) ^ t.f[fcode(in)] ^ t.fk[fcode(out)];
+}
+
+__device__ inline uint64_t roll_r(const HashTab& t, uint64_t rh, uint8_t out, uint8_t in)
+{
+    return sror1(rh ^ t.rk[rcode(in)] ^ t.r[rcode(out)]);
+}
+
+__device__ inline void changelast(const HashTab& t, uint64_t& fh, uint64_t& rh, uint8_t out,
+                                  uint8_t in)
+{
+    fh ^= t.f[fcode(out)] ^ t.f[fcode(in)];
+    rh = sror1(srol1(rh) ^ t.rk[rcode(out)] ^ t.rk[rcode(in)]);
+}
+
+__device__ inline void hash_kmer(const HashTab& t, const uint8_t* z, uint32_t k, uint64_t& fh,
+                                 uint64_t& rh)
+{
+    uint64_t f = 0, r = 0;
+    for (uint32_t i = 0; i < k; i++) {
+        f = srol1(f) ^ t.f[fcode(z[i])];
+        r = srol1(r) ^ t.r[rcode(z[k - 1 - i])];
+    }
+    fh = f;
+    rh = r;
+}
+
+__device__ inline bool bf_contains(const WalkArgs& a, const uint32_t* bf, uint64_t base)
+{
+    bool all = true;
+    for (uint32_t i = 0; i < a.hash_num; i++) {
+        uint64_t h = i ? ext_hash(base, a.k, i) : base;
+        uint64_t n = fastmod(h, a.bf_mod);
+        all &= ((bf[n >> 5] >> (uint32_t)(n & 31)) & 1u) != 0;
+    }
+    return all;
+}
+
+__device__ inline bool is_accepted_u(uint8_t c)
+{
+    uint8_t u = (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c;
+    switch (u) {
+    case 'A': case 'T': case 'G': case 'C': case 'R': case 'Y': case 'S':
+    case 'W': case 'K': case 'M': case 'B': case 'D': case 'H': case 'V':
+        return true;
+    default:
+        return false;
+    }
+}
+
+__device__ inline uint8_t to_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
+__device__ inline uint8_t to_lower(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; }
+
+// ------------------------------------------------ node list (thread 0 only)
+__device__ inline Node nd_get(const Ctx& c, const Shared& S, uint32_t i)
+{
+    if (i < S.nn)
+        return c.nd[i];
+    Node u;
+    u.type = -1;
+    u.s = u.e = u.c = 0;
+    return u;
+}
+
+__device__ inline void nd_put(const Ctx& c, Shared& S, uint32_t i, Node n)
+{
+    if (i < S.nn) {
+        c.nd[i] = n;
+    } else if (S.nn < c.node_cap) {
+        c.nd[S.nn++] = n;
+    } else {
+        atomicOr(c.a->err, 1u); // node list overflow
+    }
+}
+
+__device__ inline uint8_t get_char(const Ctx& c, uint32_t pos, const Node& n)
+{
+    if (n.type == 0)
+        return pos < c.len ? c.seq[pos] : 0;
+    if (n.type == 1)
+        return (uint8_t)n.c;
+    return 0;
+}
+
+__device__ inline void increment(const Ctx& c, const Shared& S, uint32_t& pos, uint32_t& ni)
+{
+    Node n = nd_get(c, S, ni);
+    if (n.type == 0) {
+        pos++;
+        if (pos > n.e) {
+            ni++;
+            if (ni < S.nn && c.nd[ni].type == 0)
+                pos = c.nd[ni].s;
+        }
+    } else if (n.type == 1) {
+        ni++;
+        if (ni < S.nn && c.nd[ni].type == 0)
+            pos = c.nd[ni].s;
+    }
+}
+
+__device__ inline bool roll_cursor(const Ctx& c, const Shared& S, uint32_t& hi, uint32_t& ti,
+                                   uint32_t& hn, uint32_t& tn, uint8_t& out, uint8_t& in)
+{
+    if (hi >= c.len || hn >= S.nn)
+        return false;
+    out = get_char(c, hi, nd_get(c, S, hn));
+    increment(c, S, hi, hn);
+    if (ti >= c.len || tn >= S.nn)
+        return false;
+    increment(c, S, ti, tn);
+    if (ti >= c.len || tn >= S.nn)
+        return false;
+    in = get_char(c, ti, nd_get(c, S, tn));
+    return true;
+}
+
+__device__ void make_insertion(const Ctx& c, Shared& S, uint32_t& tn, int insert_pos,
+                               const uint8_t* ins, uint32_t nins)
+{
+    Node orig = c.nd[tn];
+    if (orig.type == 0 && !(insert_pos <= (int)orig.s)) {
+        Node after;
+        after.type = 0;
+        after.s = (uint32_t)insert_pos;
+        after.e = orig.e;
+        after.c = 0;
+        c.nd[tn].e = (uint32_t)insert_pos - 1;
+        for (uint32_t i = 0; i < nins; i++) {
+            Node x;
+            x.type = 1;
+            x.s = x.e = 0;
+            x.c = ins[i];
+            nd_put(c, S, tn + i + 1, x);
+        }
+        nd_put(c, S, tn + nins + 1, after);
+        tn++;
+        return;
+    }
+    if (orig.type == 0 || orig.type == 1) {
+        // the live tail (a handful of nodes: edits happen at the right edge) moves right
+        uint32_t nre = 0;
+        while (tn + nre < S.nn && c.nd[tn + nre].type != -1)
+            nre++;
+        const uint32_t need = tn + nins + nre;
+        if (need > c.node_cap) {
+            atomicOr(c.a->err, 1u);
+            return;
+        }
+        while (S.nn < need)
+            c.nd[S.nn++].type = -1;
+        for (uint32_t q = nre; q-- > 0;)
+            c.nd[tn + nins + q] = c.nd[tn + q];
+        for (uint32_t q = 0; q < nins; q++) {
+            Node x;
+            x.type = 1;
+            x.s = x.e = 0;
+            x.c = ins[q];
+            c.nd[tn + q] = x;
+        }
+    }
+}
+
+__device__ void make_deletion(const Ctx& c, Shared& S, uint32_t& tn, uint32_t& pos,
+                              uint32_t num_del)
+{
+    for (int depth = 0; depth < 64; depth++) { // the reference recurses; bounded here
+        Node orig = nd_get(c, S, tn);
+        uint32_t leftover = 0;
+        if (orig.type == 0) {
+            if (pos <= orig.s) {
+                if ((uint32_t)(pos + num_del) <= orig.e) {
+                    c.nd[tn].s = pos + num_del;
+                    pos = c.nd[tn].s;
+                    return;
+                }
+                leftover = (uint32_t)((uint64_t)(uint32_t)(pos + num_del) - (uint64_t)orig.e);
+                pos = orig.e + 1;
+                uint32_t i = tn + 1;
+                while (i < S.nn && c.nd[i].type != -1) {
+                    c.nd[i - 1] = c.nd[i];
+                    c.nd[i].type = -1;
+                    i++;
+                }
+            } else {
+                if ((uint32_t)(pos + num_del) <= orig.e) {
+                    Node split;
+                    split.type = 0;
+                    split.s = pos + num_del;
+                    split.e = orig.e;
+                    split.c = 0;
+                    c.nd[tn].e = pos - 1;
+                    pos = split.s;
+                    tn++;
+                    nd_put(c, S, tn, split);
+                    return;
+                }
+                leftover = (uint32_t)((uint64_t)(uint32_t)(pos + num_del) - (uint64_t)orig.e);
+                c.nd[tn].e = pos - 1;
+                pos = orig.e + 1;
+                tn++;
+            }
+        } else if (orig.type == 1) {
+            uint32_t i = tn;
+            leftover = num_del;
+            while (i < S.nn && c.nd[i].type == 1 && leftover > 0) {
+                c.nd[i].type = -1;
+                leftover--;
+                i++;
+            }
+            uint32_t j = tn;
+            while (i < S.nn && c.nd[i].type != -1) {
+                c.nd[j] = c.nd[i];
+                c.nd[i].type = -1;
+                i++;
+                j++;
+            }
+        } else {
+            return;
+        }
+        if (leftover > 0 && tn < S.nn && c.nd[tn].type != -1) {
+            if (c.nd[tn].type == 0)
+                pos = c.nd[tn].s;
+            num_del = leftover;
+            continue;
+        }
+        return;
+    }
+}
+
+__device__ bool find_accepted_kmer(const Ctx& c, Shared& S, uint32_t& hi, uint32_t& ti,
+                                   uint32_t& hn, uint32_t& tn, uint8_t* kmer)
+{
+    const uint32_t k = c.k;
+    Node cur = nd_get(c, S, tn);
+    uint32_t ttn = tn, thn = 0;
+    uint32_t i = ti;
+    while (i < c.len && ttn < S.nn && c.nd[ttn].type != -1) {
+        uint8_t ch = get_char(c, i, cur);
+        if (is_accepted_u(ch)) {
+            uint32_t n = 0;
+            kmer[n++] = ch;
+            thn = ttn;
+            uint32_t j = i;
+            increment(c, S, j, ttn);
+            while (j < c.len && ttn < S.nn && c.nd[ttn].type != -1) {
+                cur = c.nd[ttn];
+                ch = get_char(c, j, cur);
+                if (!is_accepted_u(ch)) {
+                    i = j;
+                    break;
+                }
+                kmer[n++] = ch;
+                if (n == k)
+                    break;
+                increment(c, S, j, ttn);
+            }
+            if (n == k) {
+                hi = i;
+                ti = j;
+                hn = thn;
+                tn = ttn;
+                return true;
+            }
+        }
+        increment(c, S, i, ttn);
+    }
+    hi = c.len;
+    ti = c.len;
+    return false;
+}
+
+__device__ inline uint8_t rc_char(uint8_t ch)
+{
+    switch (ch) {
+    case 'A': case 'a': return 'T';
+    case 'T': case 't': return 'A';
+    case 'G': case 'g': return 'C';
+    case 'C': case 'c': return 'G';
+    default: return 'N';
+    }
+}
+
+__device__ bool is_repeat_insertion(const uint8_t* s, int n, int* lps)
+{
+    if (n <= 0)
+        return false;
+    int len = 0, i = 1;
+    lps[0] = 0;
+    while (i < n) {
+        if (s[i] == s[len]) {
+            lps[i++] = ++len;
+        } else if (len != 0) {
+            len = lps[len - 1];
+        } else {
+            lps[i++] = 0;
+        }
+    }
+    len = lps[n - 1];
+    return len > 0 && n % (n - len) == 0;
+}
+
+__device__ void drop_repeat_nodes(const Ctx& c, Shared& S, uint32_t tn, uint32_t ti,
+                                  uint32_t count)
+{
+    uint32_t j = 1;
+    if (c.nd[tn].type == 0 && ti == c.nd[tn].s)
+        j = 0;
+    for (uint32_t i = count; i > 0; i--) {
+        if (i > tn)
+            continue;
+        if (tn + j < S.nn && c.nd[tn + j].type != -1) {
+            c.nd[tn - i] = c.nd[tn + j];
+            c.nd[tn + j].type = -1;
+            j++;
+        } else {
+            c.nd[tn - i].type = -1;
+        }
+    }
+}
+
+struct Best {
+    uint32_t type; // 0 none, 1 sub, 2 ins, 3 del
+    uint8_t sub_base;
+    uint8_t indel[8];
+    uint32_t indel_len;
+    uint32_t sup;
+};
+
+// multi_possible_bases[first][i]: shortest first, then A<C<G<T
+__device__ inline uint32_t indel_string(uint8_t first, uint32_t i, uint8_t* out)
+{
+    uint32_t L = 1, start = 0, next = 1; // counts 1,5,21,85,341
+    while (i >= next) {
+        L++;
+        start = next;
+        next = next * 4 + 1;
+    }
+    uint32_t j = i - start;
+    out[0] = first;
+    for (uint32_t q = L - 1; q >= 1; q--) {
+        out[q] = (uint8_t)("ACGT"[j & 3]);
+        j >>= 2;
+    }
+    return L;
+}
+
+__device__ void make_edit(const Ctx& c, Shared& S, uint8_t draft, Best& b)
+{
+    const HashTab& ht = S.ht;
+    const uint32_t k = c.k;
+    Node tnode = nd_get(c, S, S.tn);
+    switch (b.type) {
+    case 1:
+        if (tnode.type == 0)
+            c.seq[S.ti] = b.sub_base;
+        else if (tnode.type == 1)
+            c.nd[S.tn].c = b.sub_base;
+        changelast(ht, S.fh, S.rh, draft, b.sub_base);
+        S.st_edits++;
+        break;
+    case 2: {
+        bool skipped = false;
+        // run of inserted chars just left of the tail, nearest first, complemented
+        uint8_t prev[224];
+        int lps[224];
+        uint32_t np = 0;
+        {
+            uint32_t tn = S.tn;
+            if ((tn < S.nn && c.nd[tn].type == 0 && S.ti == c.nd[tn].s) || c.nd[tn].type == 1)
+                tn--;
+            while (tn < S.nn && c.nd[tn].type == 1) {
+                if (np < 200)
+                    prev[np] = rc_char((uint8_t)c.nd[tn].c);
+                np++;
+                tn--;
+            }
+            if (np > 200) {
+                atomicOr(c.a->err, 2u);
+                np = 200;
+            }
+        }
+        if (np + b.indel_len >= k) {
+            uint8_t kmer[kMaxK];
+            if (is_repeat_insertion(prev, (int)np, lps) ||
+                np + b.indel_len >= c.a->insertion_cap) {
+                drop_repeat_nodes(c, S, S.tn, S.ti, np);
+                if (find_accepted_kmer(c, S, S.hi, S.ti, S.hn, S.tn, kmer))
+                    hash_kmer(ht, kmer, k, S.fh, S.rh);
+                skipped = true;
+            } else {
+                for (uint32_t w = 0; w < b.indel_len; w++) {
+                    for (uint32_t q = np; q > 0; q--)
+                        prev[q] = prev[q - 1];
+                    prev[0] = rc_char(b.indel[w]);
+                    np++;
+                    if (is_repeat_insertion(prev, (int)np, lps)) {
+                        drop_repeat_nodes(c, S, S.tn, S.ti, np - w);
+                        if (find_accepted_kmer(c, S, S.hi, S.ti, S.hn, S.tn, kmer))
+                            hash_kmer(ht, kmer, k, S.fh, S.rh);
+                        skipped = true;
+                    }
+                }
+            }
+        }
+        if (!skipped) {
+            make_insertion(c, S, S.tn, (int)S.ti, b.indel, b.indel_len);
+            changelast(ht, S.fh, S.rh, draft, b.indel[0]);
+            S.st_edits++;
+        }
+        break;
+    }
+    case 3:
+        make_deletion(c, S, S.tn, S.ti, b.indel_len);
+        changelast(ht, S.fh, S.rh, draft, get_char(c, S.ti, nd_get(c, S, S.tn)));
+        S.st_edits++;
+        break;
+    default:
+        if (c.a->soft_mask) {
+            uint8_t lo = to_lower(draft);
+            if (tnode.type == 0)
+                c.seq[S.ti] = lo;
+            else if (tnode.type == 1)
+                c.nd[S.tn].c = lo;
+            changelast(ht, S.fh, S.rh, draft, lo);
+        }
+        break;
+    }
+}
+
+// gather up to `want` chars of the edited sequence starting at the head cursor
+__device__ uint32_t gather(const Ctx& c, const Shared& S, uint8_t* z, uint32_t want)
+{
+    uint32_t pos = S.hi, ni = S.hn, n = 0;
+    while (n < want) {
+        if (pos >= c.len || ni >= S.nn)
+            break;
+        Node nd = c.nd[ni];
+        if (nd.type == -1) {
+            // the reference keeps reading a 0 byte from an unset node without advancing
+            while (n < want)
+                z[n++] = 0;
+            break;
+        }
+        z[n++] = get_char(c, pos, nd);
+        increment(c, S, pos, ni);
+    }
+    return n;
+}
+
+// ------------------------------------------------------------- the kernel
+__device__ inline uint32_t block_min(Shared& S, uint32_t v)
+{
+    // v != ~0u marks a hit at index v; returns the smallest, ~0u if none
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t m = __ballot(v != 0xFFFFFFFFu);
+    uint32_t first = m ? (uint32_t)__shfl((int)v, __ffsll((long long)m) - 1) : 0xFFFFFFFFu;
+    // hits are index-ordered by lane, so the first set lane of a wave is its minimum
+    if (lane == 0)
+        S.wave_min[wave] = first;
+    __syncthreads();
+    uint32_t r = 0xFFFFFFFFu;
+    for (int w = 0; w < kWalkThreads / 64; w++)
+        r = min(r, S.wave_min[w]);
+    __syncthreads();
+    return r;
+}
+
+__device__ inline uint32_t block_sum(Shared& S, uint32_t v)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_down((int)v, o);
+    if (lane == 0)
+        S.wave_min[wave] = v;
+    __syncthreads();
+    uint32_t r = 0;
+    for (int w = 0; w < kWalkThreads / 64; w++)
+        r += S.wave_min[w];
+    __syncthreads();
+    return r;
+}
+
+// insertion / deletion sweep for one index char; every thread takes candidates
+// t, t+256, ...; result: S.best_key (0 = nothing passed)
+__device__ void indel_sweep(const Ctx& c, Shared& S, uint8_t index_char, uint32_t del_from)
+{
+    const WalkArgs& a = *c.a;
+    const HashTab& ht = S.ht;
+    const uint32_t k = c.k, jump = a.jump;
+    const uint8_t draft = (uint8_t)S.draft;
+    const uint32_t n_ins = a.max_ins_tries;
+    // deletions num_del = del_from .. max_del are tried at iterations 0.. of the loop
+    const uint32_t n_del = (n_ins > 0 && del_from <= a.max_del)
+                               ? min(a.max_del - del_from + 1, n_ins)
+                               : 0u;
+    uint32_t probes = 0;
+    uint32_t my_best = 0;
+    for (uint32_t cand = threadIdx.x; cand < n_ins + n_del; cand += kWalkThreads) {
+        uint64_t fh = S.fh, rh = S.rh;
+        uint32_t present = 0, order;
+        bool pass;
+        if (cand < n_ins) {
+            uint8_t ins[8];
+            const uint32_t L = indel_string(index_char, cand, ins);
+            ins[L] = draft;
+            changelast(ht, fh, rh, draft, index_char);
+            // X = Z[0..k-1) ++ ins[0..L] ; then Z[k..): k-mer q ends at X[q+k]
+            for (uint32_t q = 0; q + 1 < k; q++) {
+                uint8_t in;
+                if (q < L) {
+                    in = ins[q + 1];
+                } else {
+                    uint32_t zi = k + (q - L);
+                    if (zi >= S.nz)
+                        break;
+                    in = S.Z[zi];
+                }
+                fh = roll_f(ht, fh, S.Z[q], in);
+                rh = roll_r(ht, rh, S.Z[q], in);
+                if (q % jump == 0) {
+                    probes++;
+                    present += bf_contains(a, c.bf, fh + rh) ? 1u : 0u;
+                }
+            }
+            pass = present >= a.need_edit;
+            order = 2 * cand;
+        } else {
+            const uint32_t it = cand - n_ins;
+            const uint32_t n = del_from + it;
+            // X' = Z[0..k-1) ++ Z[k-1+n ..)
+            uint8_t last = (k - 1 + n) < S.nz ? S.Z[k - 1 + n] : 0;
+            changelast(ht, fh, rh, draft, last);
+            probes++;
+            present += bf_contains(a, c.bf, fh + rh) ? 1u : 0u;
+            for (uint32_t q = 1; q + 2 <= k; q++) {
+                uint32_t zi = k - 1 + n + q;
+                if (zi >= S.nz)
+                    break;
+                // chars leaving: Z[q-1]; but once q-1 reaches k-1 the window has no
+                // original prefix left (q <= k-2, so it never does)
+                fh = roll_f(ht, fh, S.Z[q - 1], S.Z[zi]);
+                rh = roll_r(ht, rh, S.Z[q - 1], S.Z[zi]);
+                if (q % jump == 0) {
+                    probes++;
+                    present += bf_contains(a, c.bf, fh + rh) ? 1u : 0u;
+                }
+            }
+            pass = present >= a.need_del;
+            order = 2 * it + 1;
+        }
+        if (pass) {
+            uint32_t key = (present << 16) | order;
+            my_best = max(my_best, key);
+        }
+    }
+    if (my_best)
+        atomicMax(&S.best_key, my_best);
+    atomicAdd(&S.st_probes, (unsigned long long)probes);
+}
+
+__global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
+{
+    __shared__ Shared S;
+    const uint32_t cid = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    if (a.dropped[cid])
+        return;
+    const uint32_t len = a.len_cur[cid];
+    if (len < a.min_contig_len) {
+        // ntEdit silently leaves out contigs shorter than -z (ntedit.cpp:1850-1853)
+        if (tid == 0) {
+            a.dropped[cid] = 1;
+            a.len_next[cid] = 0;
+        }
+        return;
+    }
+    Ctx c;
+    c.a = &a;
+    c.seq = a.seq + a.off[cid];
+    c.nd = a.nodes + a.node_off[cid];
+    c.node_cap = (uint32_t)(a.node_off[cid + 1] - a.node_off[cid]);
+    c.bf = a.bf + ((uint64_t)a.contig_batch[cid] * a.n_k + a.ki) * a.bf_words;
+    c.len = len;
+    c.k = a.k;
+    const uint32_t k = a.k, jump = a.jump;
+
+    if (tid == 0) {
+        for (uint32_t code = 0; code < 5; code++) {
+            uint64_t s = code < 4 ? seed_of_code(code) : 0ULL;
+            S.ht.f[code] = s;
+            S.ht.r[code] = s;
+            S.ht.fk[code] = sroln(s, k);
+            S.ht.rk[code] = sroln(s, k);
+        }
+        S.st_scan = S.st_sites = S.st_probes = S.st_edits = 0;
+        // findFirstAcceptedKmer(0)
+        uint32_t hi = len - 1;
+        for (uint32_t i = 0; i + k < len;) {
+            if (is_accepted_u(c.seq[i])) {
+                bool good = true;
+                for (uint32_t j = i + 1; j < i + k; j++)
+                    if (!is_accepted_u(c.seq[j])) {
+                        good = false;
+                        i = j + 1;
+                        break;
+                    }
+                if (good) {
+                    hi = i;
+                    break;
+                }
+            } else {
+                i++;
+            }
+        }
+        S.hi = hi;
+        S.ti = hi + k - 1;
+        S.hn = S.tn = 0;
+        S.nn = 1;
+        Node root;
+        root.type = 0;
+        root.s = 0;
+        root.e = len - 1;
+        root.c = 0;
+        c.nd[0] = root;
+        S.fh = S.rh = 0;
+        S.char_in = 0;
+        S.cur_tested = 0;
+        S.min_tested_ti = 0;
+        if (hi + k - 1 < len) {
+            hash_kmer(S.ht, c.seq + hi, k, S.fh, S.rh);
+            S.char_in = c.seq[S.ti];
+            S.request = REQ_NEXT;
+        } else {
+            S.request = REQ_DONE;
+        }
+    }
+    __syncthreads();
+
+    // Each pass of this loop is one "request" decided by thread 0.  Every request
+    // moves the walker forward, so 4*len+4096 passes is a bug trap, never a limit.
+    for (uint32_t trip = 0;; trip++) {
+        if (trip > 4u * len + 4096u) {
+            if (tid == 0)
+                atomicOr(a.err, 4u);
+            break;
+        }
+        // ---------------- thread 0: decide how to reach the next untested k-mer
+        if (tid == 0 && S.request == REQ_NEXT) {
+            Node tnode = nd_get(c, S, S.tn);
+            const bool plain = tnode.type == 0 && tnode.e == len - 1 && S.ti <= tnode.e;
+            if (plain) {
+                // scan: current k-mer chars via the cursor, lookahead straight from the contig
+                uint32_t got = gather(c, S, S.Z, k);
+                if (got < k) {
+                    S.request = REQ_DONE; // cannot happen while the tail is in range
+                } else {
+                    uint32_t ahead = len - 1 - S.ti;
+                    uint32_t j0 = S.cur_tested ? 1u : 0u;
+                    uint32_t n = min((uint32_t)kWalkThreads, ahead + 1 - j0);
+                    if (n == 0) {
+                        S.request = REQ_DONE; // the next roll would fail: end of contig
+                    } else {
+                        S.scan_j0 = j0;
+                        S.scan_n = n;
+                        S.nz = k + min(ahead, j0 + n - 1);
+                        S.request = REQ_SCAN;
+                    }
+                }
+            } else {
+                // literal: one trip through the bottom of the reference loop, then its top
+                bool go = true;
+                if (S.cur_tested) {
+                    int target = -1;
+                    do {
+                        uint8_t out = 0, in = 0;
+                        if (roll_cursor(c, S, S.hi, S.ti, S.hn, S.tn, out, in)) {
+                            if (!is_accepted_u(in))
+                                target = (int)S.ti + (int)k;
+                            S.fh = roll_f(S.ht, S.fh, out, in);
+                            S.rh = roll_r(S.ht, S.rh, out, in);
+                            S.char_in = in;
+                        } else {
+                            go = false;
+                            break;
+                        }
+                    } while (target >= 0 && (int)S.ti != target);
+                    S.min_tested_ti = 0;
+                }
+                if (!go || S.hi + k - 1 >= len) {
+                    S.request = REQ_DONE;
+                } else {
+                    S.cur_tested = 1;
+                    S.st_probes++;
+                    if (!bf_contains(a, c.bf, S.fh + S.rh))
+                        S.request = REQ_SITE;
+                    else
+                        S.request = REQ_NEXT;
+                }
+            }
+        }
+        __syncthreads();
+        const int req = S.request;
+        if (req == REQ_DONE)
+            break;
+
+        if (req == REQ_SCAN) {
+            // lookahead chars Z[k..nz) come straight from the (untouched) contig
+            const uint32_t j0 = S.scan_j0, n = S.scan_n, ti0 = S.ti;
+            for (uint32_t i = k + tid; i < S.nz; i += kWalkThreads)
+                S.Z[i] = c.seq[ti0 + 1 + (i - k)];
+            __syncthreads();
+            uint32_t hit = 0xFFFFFFFFu;
+            if (tid < n) {
+                const uint32_t jj = j0 + tid;
+                uint64_t fh, rh;
+                hash_kmer(S.ht, S.Z + jj, k, fh, rh);
+                S.scan_fh[tid] = fh;
+                S.scan_rh[tid] = rh;
+                bool tested = (ti0 + jj) >= S.min_tested_ti;
+                for (uint32_t i = max(jj, k); i < jj + k; i++)
+                    tested &= is_accepted_u(S.Z[i]);
+                if (jj == 0)
+                    tested = true;
+                if (tested && !bf_contains(a, c.bf, fh + rh))
+                    hit = jj;
+            }
+            uint32_t first = block_min(S, hit);
+            if (tid == 0) {
+                S.st_scan += n;
+                const uint32_t dest = first != 0xFFFFFFFFu ? first : j0 + n - 1;
+                // a non-accepted base that came in on the way keeps blocking k-mers that hold it
+                for (uint32_t i = k; i < k + dest && i < S.nz; i++)
+                    if (!is_accepted_u(S.Z[i]))
+                        S.min_tested_ti = max(S.min_tested_ti, ti0 + 1 + (i - k) + k);
+                for (uint32_t s = 0; s < dest; s++)
+                    increment(c, S, S.hi, S.hn);
+                S.ti = ti0 + dest;
+                // tn stays: the tail never leaves the final node
+                S.fh = S.scan_fh[dest - j0];
+                S.rh = S.scan_rh[dest - j0];
+                S.char_in = S.Z[dest + k - 1];
+                S.cur_tested = 1;
+                S.request = first != 0xFFFFFFFFu ? REQ_SITE : REQ_NEXT;
+            }
+            __syncthreads();
+            continue;
+        }
+
+        if (req == REQ_NEXT)
+            continue;
+
+        // ------------------------------------------------------------ REQ_SITE
+        if (tid == 0) {
+            S.nz = gather(c, S, S.Z, 2 * k + 12);
+            S.draft = to_upper((uint8_t)S.char_in);
+            S.best_key = 0;
+        }
+        __syncthreads();
+        {
+            // confirm: k more k-mers, every jump-th one probed
+            uint32_t miss = 0, bad = 0;
+            if (tid < k) {
+                const uint32_t q = tid;
+                if (k + q >= S.nz)
+                    bad = 1;
+                else if (!is_accepted_u(S.Z[k + q]))
+                    bad = 1;
+            }
+            bad = block_sum(S, bad);
+            if (!bad && tid < k && tid % jump == 0) {
+                uint64_t fh, rh;
+                hash_kmer(S.ht, S.Z + tid + 1, k, fh, rh);
+                miss = bf_contains(a, c.bf, fh + rh) ? 0u : 1u;
+            }
+            miss = block_sum(S, miss);
+            if (tid == 0) {
+                S.confirm_bad = bad;
+                S.confirm_missing = miss;
+                S.st_probes += bad ? 0 : (k + jump - 1) / jump;
+            }
+            __syncthreads();
+        }
+        if (S.confirm_bad || S.confirm_missing < a.need_missing) {
+            if (tid == 0)
+                S.request = REQ_NEXT;
+            __syncthreads();
+            continue;
+        }
+
+        // substitution trials: one wave-sized slice of work per candidate base
+        if (tid == 0) {
+            S.st_sites++;
+            const char* s;
+            switch ((uint8_t)S.draft) {
+            case 'A': s = "TCG"; break;
+            case 'T': s = "ACG"; break;
+            case 'C': s = "ATG"; break;
+            case 'G': s = "ATC"; break;
+            case 'R': s = "TC"; break;
+            case 'Y': s = "AG"; break;
+            case 'S': s = "AT"; break;
+            case 'W': s = "CG"; break;
+            case 'K': s = "AC"; break;
+            case 'M': s = "TG"; break;
+            case 'B': s = "A"; break;
+            case 'D': s = "C"; break;
+            case 'H': s = "G"; break;
+            case 'V': s = "T"; break;
+            default: s = ""; break;
+            }
+            uint32_t n = 0;
+            for (; s[n]; n++)
+                S.subs[n] = (uint8_t)s[n];
+            S.n_sub = n;
+            for (uint32_t i = 0; i < 4; i++)
+                S.sub_in_bf[i] = S.sub_present[i] = 0;
+            S.num_del = 1;
+        }
+        __syncthreads();
+        {
+            // thread (si*64 + q): q == 63 probes the changed k-mer itself,
+            // q < k probes the k-mer after q+1 rolls when q % jump == 0
+            const uint32_t si = tid >> 6, q = tid & 63;
+            if (si < S.n_sub) {
+                const uint8_t sb = S.subs[si];
+                if (q == 63) {
+                    uint64_t fh = S.fh, rh = S.rh;
+                    changelast(S.ht, fh, rh, (uint8_t)S.draft, sb);
+                    if (bf_contains(a, c.bf, fh + rh))
+                        S.sub_in_bf[si] = 1;
+                } else if (q < k && q % jump == 0 && k + q < S.nz) {
+                    // k-mer = Z[q+1 .. q+1+k) with Z[k-1] replaced by sb
+                    uint64_t f = 0, r = 0;
+                    const uint8_t* z = S.Z + q + 1;
+                    const uint32_t at = k - 1 - (q + 1); // index of the site inside this k-mer
+                    for (uint32_t i = 0; i < k; i++) {
+                        uint8_t cf = (i == at) ? sb : z[i];
+                        uint32_t ir = k - 1 - i;
+                        uint8_t cr = (ir == at) ? sb : z[ir];
+                        f = srol1(f) ^ S.ht.f[fcode(cf)];
+                        r = srol1(r) ^ S.ht.r[rcode(cr)];
+                    }
+                    if (bf_contains(a, c.bf, f + r))
+                        atomicAdd(&S.sub_present[si], 1u);
+                }
+            }
+        }
+        __syncthreads();
+
+        // replay the reference's control flow over the trial results (uniform)
+        Best best;
+        best.type = 0;
+        best.sup = 0;
+        best.sub_base = 0;
+        best.indel_len = 0;
+        for (uint32_t si = 0; si < S.n_sub; si++) {
+            if (!S.sub_in_bf[si])
+                continue;
+            if (tid == 0) {
+                // trial + revert leaves the UPPER-case draft base behind (:1608-1615)
+                Node tnode = nd_get(c, S, S.tn);
+                if (tnode.type == 0)
+                    c.seq[S.ti] = (uint8_t)S.draft;
+                else if (tnode.type == 1)
+                    c.nd[S.tn].c = S.draft;
+                S.st_probes += 1 + (k + jump - 1) / jump;
+            }
+            const uint32_t present = S.sub_present[si];
+            if (present >= a.need_edit) {
+                if (present >= best.sup) {
+                    best.type = 1;
+                    best.sub_base = S.subs[si];
+                    best.sup = present;
+                }
+                continue; // modes 0/1: a good substitution ends this base's turn
+            }
+            if (best.type != 1) {
+                __syncthreads();
+                if (tid == 0)
+                    S.best_key = 0;
+                __syncthreads();
+                indel_sweep(c, S, S.subs[si], S.num_del);
+                __syncthreads();
+                const uint32_t key = S.best_key;
+                // deletions del_from.. were consumed by this call
+                uint32_t n_del = (a.max_ins_tries > 0 && S.num_del <= a.max_del)
+                                     ? min(a.max_del - S.num_del + 1, a.max_ins_tries)
+                                     : 0u;
+                const uint32_t del_from = S.num_del;
+                __syncthreads();
+                if (tid == 0)
+                    S.num_del = del_from + n_del;
+                if (key) {
+                    const uint32_t order = key & 0xFFFF;
+                    best.sup = key >> 16;
+                    if (order & 1) {
+                        best.type = 3;
+                        best.indel_len = del_from + (order >> 1);
+                    } else {
+                        best.type = 2;
+                        best.indel_len = indel_string(S.subs[si], order >> 1, best.indel);
+                    }
+                    break; // tryIndels returned true (modes 0/1)
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            make_edit(c, S, (uint8_t)S.draft, best);
+            S.request = REQ_NEXT;
+        }
+        __syncthreads();
+    }
+
+    // ---- write the edited contig: nodes in order, every thread copies a slice
+    __syncthreads();
+    uint8_t* out = a.out + a.off[cid];
+    uint32_t o = 0;
+    const uint32_t nn = S.nn;
+    for (uint32_t ni = 0; ni < nn; ni++) {
+        const Node n = c.nd[ni];
+        if (n.type == -1)
+            break;
+        if (n.type == 0) {
+            uint32_t s = n.s, cnt = n.e - n.s + 1;
+            if (s <= len) {
+                if (cnt > len - s)
+                    cnt = len - s;
+                for (uint32_t i = tid; i < cnt; i += kWalkThreads)
+                    out[o + i] = c.seq[s + i];
+                o += cnt;
+            }
+        } else {
+            if (tid == 0)
+                out[o] = (uint8_t)n.c;
+            o++;
+        }
+    }
+    if (tid == 0) {
+        a.len_next[cid] = o;
+        atomicAdd(&a.stats[0], S.st_scan);
+        atomicAdd(&a.stats[1], S.st_sites);
+        atomicAdd(&a.stats[2], S.st_probes);
+        atomicAdd(&a.stats[3], S.st_edits);
+    }
+}
+
+// ------------------------------------------------------------- small kernels
+__global__ void copy_contigs(const uint8_t* src, const uint64_t* src_off, const uint32_t* src_len,
+                             uint8_t* dst, const uint64_t* dst_off, uint32_t* dst_len,
+                             uint8_t* dropped, const uint8_t* only_if_batch_skip,
+                             const uint32_t* contig_batch)
+{
+    const uint32_t cid = blockIdx.x;
+    if (only_if_batch_skip && !only_if_batch_skip[contig_batch[cid]])
+        return;
+    const uint32_t n = src_len[cid];
+    const uint8_t* s = src + src_off[cid];
+    uint8_t* d = dst + dst_off[cid];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+        d[i] = s[i];
+    if (threadIdx.x == 0) {
+        dst_len[cid] = n;
+        dropped[cid] = 0;
+    }
+}
+
+// scripts/goldpolish-ntedit:31-40: bytes(out)/bytes(in) truncated to 4 decimals < 0.75
+__global__ void guard_kernel(const uint32_t* batch_begin, uint32_t n_batches,
+                             const uint32_t* name_len, const uint32_t* in_len,
+                             const uint32_t* cur_len, const uint8_t* dropped, uint8_t* batch_skip)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_batches)
+        return;
+    unsigned long long in_bytes = 0, out_bytes = 0;
+    for (uint32_t c = batch_begin[b]; c < batch_begin[b + 1]; c++) {
+        in_bytes += 1ull + name_len[c] + 1 + in_len[c] + 1;
+        if (!dropped[c])
+            out_bytes += 1ull + name_len[c] + 1 + cur_len[c] + 1;
+    }
+    batch_skip[b] = (in_bytes > 0 && (out_bytes * 10000ull) / in_bytes < 7500ull) ? 1 : 0;
+}
+
+// ---- soft mask (scripts/goldpolish-mask:44-72), one workgroup per contig.
+// The regex ([ACTG]+|[Nn]+|[actgUNMRWSYKVHDBunmrwsykvhdb]+) is a 4-state
+// machine over the bytes; each thread runs it over its own chunk for every
+// possible entry state, the chunk summaries are chained, and a second sweep
+// applies the run-length rule.  Run lengths are carried across chunks.
+__device__ inline int cls_acgt(uint8_t c) { return c == 'A' || c == 'C' || c == 'T' || c == 'G'; }
+__device__ inline int cls_n(uint8_t c) { return c == 'N' || c == 'n'; }
+__device__ inline int cls_other(uint8_t c)
+{
+    switch (c) {
+    case 'a': case 'c': case 't': case 'g': case 'U': case 'N': case 'M': case 'R': case 'W':
+    case 'S': case 'Y': case 'K': case 'V': case 'H': case 'D': case 'B': case 'u': case 'n':
+    case 'm': case 'r': case 'w': case 's': case 'y': case 'k': case 'v': case 'h': case 'd':
+    case 'b':
+        return 1;
+    default:
+        return 0;
+    }
+}
+// state: 0 = between runs, 1 = in [ACTG]+, 2 = in [Nn]+, 3 = in the third class
+__device__ inline int mask_next(int st, uint8_t c, bool& starts)
+{
+    starts = false;
+    if (st == 1 && cls_acgt(c))
+        return 1;
+    if (st == 2 && cls_n(c))
+        return 2;
+    if (st == 3 && cls_other(c))
+        return 3;
+    starts = true;
+    if (cls_acgt(c))
+        return 1;
+    if (cls_n(c))
+        return 2;
+    if (cls_other(c))
+        return 3;
+    starts = false;
+    return 0;
+}
+
+__device__ inline uint8_t mask_view(const uint8_t* s, uint32_t len, uint32_t k, uint32_t i)
+{
+    // the input with its first and last k bases upper-cased (all of it if len < 2k)
+    uint8_t ch = s[i];
+    if (len < 2 * k || i < k || i >= len - k)
+        ch = to_upper(ch);
+    return ch;
+}
+
+constexpr int kMaskThreads = 256;
+
+__global__ __launch_bounds__(kMaskThreads) void mask_kernel(const uint8_t* src,
+                                                            const uint64_t* off,
+                                                            const uint32_t* len_cur, uint8_t* dst,
+                                                            uint32_t* len_next,
+                                                            const uint8_t* dropped, uint32_t k)
+{
+    __shared__ uint8_t exit_state[kMaskThreads][4];
+    __shared__ uint32_t run_open_len[kMaskThreads][4]; // length of the run still open at chunk end
+    __shared__ uint8_t run_open_first[kMaskThreads][4];
+    __shared__ uint32_t kept[kMaskThreads];
+    __shared__ uint8_t entry_state[kMaskThreads + 1];
+    __shared__ uint32_t entry_len[kMaskThreads + 1];
+    __shared__ uint8_t entry_first[kMaskThreads + 1];
+    __shared__ uint32_t tail_len[kMaskThreads + 1]; // how far the run open at chunk start continues
+    __shared__ uint32_t out_base[kMaskThreads + 1];
+    __shared__ uint32_t first_keep, last_keep;
+    const uint32_t cid = blockIdx.x, tid = threadIdx.x;
+    if (dropped[cid])
+        return;
+    const uint32_t len = len_cur[cid];
+    const uint8_t* s = src + off[cid];
+    uint8_t* d = dst + off[cid];
+    const uint32_t chunk = (len + kMaskThreads - 1) / kMaskThreads;
+    const uint32_t b = min(len, tid * chunk), e = min(len, b + chunk);
+
+    // pass 1: chunk summary for each entry state
+    for (int st0 = 0; st0 < 4; st0++) {
+        int st = st0;
+        uint32_t open_len = 0; // chars of the currently open run inside this chunk
+        uint8_t open_first = 0;
+        bool from_entry = true; // open run began before the chunk
+        for (uint32_t i = b; i < e; i++) {
+            bool starts;
+            uint8_t ch = mask_view(s, len, k, i);
+            st = mask_next(st, ch, starts);
+            if (st == 0) {
+                open_len = 0;
+                from_entry = false;
+            } else if (starts) {
+                open_len = 1;
+                open_first = ch;
+                from_entry = false;
+            } else {
+                open_len++;
+            }
+        }
+        exit_state[tid][st0] = (uint8_t)st;
+        // if the run reaches back to the chunk start, mark with the high bit
+        run_open_len[tid][st0] = open_len | (from_entry && st != 0 ? 0x80000000u : 0u);
+        run_open_first[tid][st0] = open_first;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // chain: state / open run length / first char of the open run at each chunk start
+        uint8_t st = 0, first = 0;
+        uint32_t rl = 0;
+        for (int t = 0; t < kMaskThreads; t++) {
+            entry_state[t] = st;
+            entry_len[t] = rl;
+            entry_first[t] = first;
+            uint32_t ol = run_open_len[t][st];
+            uint8_t nst = exit_state[t][st];
+            if (ol & 0x80000000u) {
+                rl += ol & 0x7FFFFFFFu;
+            } else {
+                rl = ol;
+                first = run_open_first[t][st];
+            }
+            if (nst == 0)
+                rl = 0;
+            st = nst;
+        }
+        entry_state[kMaskThreads] = st;
+    }
+    __syncthreads();
+    // pass 2: how far does the run that is open at my chunk start extend to the right?
+    {
+        int st = entry_state[tid];
+        uint32_t ext = 0;
+        bool whole = true;
+        if (st != 0) {
+            for (uint32_t i = b; i < e; i++) {
+                bool starts;
+                uint8_t ch = mask_view(s, len, k, i);
+                int nst = mask_next(st, ch, starts);
+                if (nst == 0 || starts) {
+                    whole = false;
+                    break;
+                }
+                st = nst;
+                ext++;
+            }
+        } else {
+            whole = false;
+        }
+        kept[tid] = ext | (whole && e > b ? 0x80000000u : (e == b && st != 0 ? 0x80000000u : 0u));
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // tail_len[t] = length of the entry run's continuation from chunk t's start onwards
+        uint32_t acc = 0;
+        tail_len[kMaskThreads] = 0;
+        for (int t = kMaskThreads - 1; t >= 0; t--) {
+            uint32_t v = kept[t];
+            if (v & 0x80000000u)
+                acc = (v & 0x7FFFFFFFu) + acc;
+            else
+                acc = v;
+            tail_len[t] = acc;
+        }
+    }
+    __syncthreads();
+    // pass 3: count kept chars per chunk (chars outside every class vanish)
+    {
+        int st = entry_state[tid];
+        uint32_t n = 0;
+        for (uint32_t i = b; i < e; i++) {
+            bool starts;
+            st = mask_next(st, mask_view(s, len, k, i), starts);
+            n += st != 0;
+        }
+        kept[tid] = n;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int t = 0; t < kMaskThreads; t++) {
+            out_base[t] = acc;
+            acc += kept[t];
+        }
+        out_base[kMaskThreads] = acc;
+        first_keep = 0xFFFFFFFFu;
+        last_keep = 0;
+    }
+    __syncthreads();
+    // pass 4: emit.  A run is lower-cased when it is shorter than k and does not start
+    // with 'N'; its full length = part before the chunk + part inside + continuation.
+    {
+        int st = entry_state[tid];
+        uint32_t o = out_base[tid];
+        uint32_t i = b;
+        uint32_t lo_first = 0xFFFFFFFFu, hi_last = 0; // first / last+1 non-[Nn] output index
+        while (i < e) {
+            bool starts;
+            uint8_t ch = mask_view(s, len, k, i);
+            int nst = mask_next(st, ch, starts);
+            if (nst == 0) {
+                st = 0;
+                i++;
+                continue;
+            }
+            // [i, j) = the part of this run inside my chunk
+            uint32_t before = 0;
+            uint8_t first = ch;
+            if (!starts) { // continuing the entry run (only possible at i == b)
+                before = entry_len[tid];
+                first = entry_first[tid];
+            }
+            uint32_t j = i + 1;
+            int rs = nst;
+            while (j < e) {
+                bool st2;
+                int n2 = mask_next(rs, mask_view(s, len, k, j), st2);
+                if (n2 == 0 || st2)
+                    break;
+                rs = n2;
+                j++;
+            }
+            uint32_t after = (j == e) ? tail_len[tid + 1] : 0;
+            // does the run really continue into the next chunk?  tail_len[t+1] counts the
+            // continuation of whatever run is open at that chunk's start, which is this
+            // run exactly when we reached the chunk end inside it.
+            uint32_t total = before + (j - i) + after;
+            bool lower = (first != 'N') && total < k;
+            for (uint32_t q = i; q < j; q++) {
+                uint8_t c2 = mask_view(s, len, k, q);
+                if (lower)
+                    c2 = to_lower(c2);
+                d[o] = c2;
+                if (!cls_n(c2)) {
+                    lo_first = min(lo_first, o);
+                    hi_last = max(hi_last, o + 1);
+                }
+                o++;
+            }
+            st = rs;
+            i = j;
+        }
+        if (lo_first != 0xFFFFFFFFu) {
+            atomicMin(&first_keep, lo_first);
+            atomicMax(&last_keep, hi_last);
+        }
+    }
+    __syncthreads();
+    // strip("Nn") from both ends; empty -> "N"
+    const uint32_t fk = first_keep, lk = last_keep;
+    if (fk == 0xFFFFFFFFu) {
+        if (tid == 0) {
+            d[0] = 'N';
+            len_next[cid] = 1;
+        }
+        return;
+    }
+    // shift left in chunks so that no thread overwrites bytes another still has to read
+    if (fk > 0) {
+        const uint32_t n = lk - fk;
+        for (uint32_t base = 0; base < n; base += kMaskThreads) {
+            uint8_t v = 0;
+            if (base + tid < n)
+                v = d[fk + base + tid];
+            __syncthreads();
+            if (base + tid < n)
+                d[base + tid] = v;
+            __syncthreads();
+        }
+    }
+    if (tid == 0)
+        len_next[cid] = lk - fk;
+}
+
+__global__ void upper_kernel(uint8_t* seq, const uint64_t* off, const uint32_t* len,
+                             const uint8_t* dropped)
+{
+    const uint32_t cid = blockIdx.y;
+    if (dropped[cid])
+        return;
+    uint8_t* s = seq + off[cid];
+    const uint32_t n = len[cid];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        s[i] = to_upper(s[i]);
+}
+
+// ------------------------------------------------------------------ host side
+static uint32_t smallest_count_passing(float threshold)
+{
+    // smallest unsigned c with float(c) >= threshold, the reference's comparison
+    uint32_t c = 0;
+    while (!((float)c >= threshold) && c < 100000)
+        c++;
+    return c;
+}
+
+int stage_bc_prepare(gp_job* job)
+{
+    StageBC* b = new (std::nothrow) StageBC();
+    if (!b)
+        return GP_ERR_OOM;
+    job->bc = b;
+    const uint32_t n = job->n_contigs;
+    b->h_off.resize((size_t)n + 1);
+    b->h_node_off.resize((size_t)n + 1);
+    uint64_t off = 0, noff = 0;
+    std::vector<uint32_t> in_len(n);
+    for (uint32_t c = 0; c < n; c++) {
+        uint64_t len = job->h_contig_off[c + 1] - job->h_contig_off[c];
+        if (len >= (1ull << 31)) {
+            set_error("contig longer than 2^31 bases");
+            return GP_ERR_UNSUPPORTED;
+        }
+        in_len[c] = (uint32_t)len;
+        b->h_off[c] = off;
+        b->h_node_off[c] = noff;
+        // room for net insertions (ntEdit) and gap fills (Sealer)
+        uint64_t cap = len + len / 2 + 4096;
+        cap = (cap + 63) & ~63ull;
+        off += cap;
+        noff += len + 256;
+    }
+    b->h_off[n] = off;
+    b->h_node_off[n] = noff;
+    b->total_slots = off;
+    int rc;
+    for (int i = 0; i < 2; i++) {
+        if ((rc = b->seq[i].alloc(off + 64)) != GP_OK)
+            return rc;
+        if ((rc = b->len[i].alloc(n)) != GP_OK)
+            return rc;
+    }
+    if ((rc = b->off.alloc((size_t)n + 1)) != GP_OK || (rc = b->dropped.alloc(n)) != GP_OK ||
+        (rc = b->nodes.alloc(noff + 1)) != GP_OK ||
+        (rc = b->node_off.alloc((size_t)n + 1)) != GP_OK ||
+        (rc = b->contig_batch.alloc(n)) != GP_OK || (rc = b->name_len.alloc(n)) != GP_OK ||
+        (rc = b->in_len.alloc(n)) != GP_OK || (rc = b->in_off.alloc((size_t)n + 1)) != GP_OK ||
+        (rc = b->batch_begin.alloc((size_t)job->n_batches + 1)) != GP_OK ||
+        (rc = b->err.alloc(4)) != GP_OK || (rc = b->stats.alloc(16)) != GP_OK ||
+        (rc = b->batch_skip.alloc(job->n_batches)) != GP_OK)
+        return rc;
+    GP_HIP(hipMemcpy(b->off.p, b->h_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    GP_HIP(hipMemcpy(b->node_off.p, b->h_node_off.data(), (n + 1) * sizeof(uint64_t),
+                     hipMemcpyHostToDevice));
+    if (n) {
+        GP_HIP(hipMemcpy(b->contig_batch.p, job->h_contig_batch.data(), n * sizeof(uint32_t),
+                         hipMemcpyHostToDevice));
+        GP_HIP(hipMemcpy(b->name_len.p, job->h_contig_name_len.data(), n * sizeof(uint32_t),
+                         hipMemcpyHostToDevice));
+        GP_HIP(hipMemcpy(b->in_len.p, in_len.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    GP_HIP(hipMemcpy(b->in_off.p, job->h_contig_off.data(), (n + 1) * sizeof(uint64_t),
+                     hipMemcpyHostToDevice));
+    GP_HIP(hipMemcpy(b->batch_begin.p, job->h_batch_contig_begin.data(),
+                     (job->n_batches + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    GP_HIP(hipMemset(b->err.p, 0, 4 * sizeof(uint32_t)));
+    GP_HIP(hipMemset(b->stats.p, 0, 16 * sizeof(unsigned long long)));
+    return GP_OK;
+}
+
+void stage_bc_release(gp_job* job)
+{
+    if (!job->bc)
+        return;
+    stage_c_release(job);
+    delete job->bc;
+    job->bc = nullptr;
+}
+
+int stage_b_reset(gp_job* job)
+{
+    StageBC* b = job->bc;
+    hipStream_t s = job->ctx->stream;
+    b->cur = 0;
+    GP_HIP(hipMemsetAsync(b->dropped.p, 0, std::max<size_t>(job->n_contigs, 1), s));
+    GP_HIP(hipMemsetAsync(b->stats.p, 0, 16 * sizeof(unsigned long long), s));
+    GP_HIP(hipMemsetAsync(b->err.p, 0, 4 * sizeof(uint32_t), s));
+    if (job->n_contigs) {
+        hipLaunchKernelGGL(copy_contigs, dim3(job->n_contigs), dim3(256), 0, s,
+                           (const uint8_t*)job->d_contigs_in.p, (const uint64_t*)b->in_off.p,
+                           (const uint32_t*)b->in_len.p, b->seq[0].p, (const uint64_t*)b->off.p,
+                           b->len[0].p, b->dropped.p, (const uint8_t*)nullptr,
+                           (const uint32_t*)b->contig_batch.p);
+        GP_HIP(hipGetLastError());
+    }
+    job->counters.b_scan_kmers = job->counters.b_sites = job->counters.b_probes =
+        job->counters.b_edits = 0;
+    return GP_OK;
+}
+
+static int pull_stats(gp_job* job)
+{
+    StageBC* b = job->bc;
+    unsigned long long st[16];
+    uint32_t err = 0;
+    GP_HIP(hipMemcpyAsync(st, b->stats.p, sizeof st, hipMemcpyDeviceToHost, job->ctx->stream));
+    GP_HIP(hipMemcpyAsync(&err, b->err.p, sizeof err, hipMemcpyDeviceToHost, job->ctx->stream));
+    GP_HIP(hipStreamSynchronize(job->ctx->stream));
+    job->counters.b_scan_kmers = st[0];
+    job->counters.b_sites = st[1];
+    job->counters.b_probes = st[2];
+    job->counters.b_edits = st[3];
+    job->counters.c_gaps = st[4];
+    job->counters.c_closed = st[5];
+    job->counters.c_vertex_tests = st[6];
+    if (err) {
+        set_error("device work buffer overflow (code " + std::to_string(err) + ")");
+        return GP_ERR_STATE;
+    }
+    return GP_OK;
+}
+
+int stage_b_pass(gp_job* job, uint32_t ki)
+{
+    StageBC* b = job->bc;
+    const gp_params& p = job->prm;
+    if (job->n_contigs == 0)
+        return GP_OK;
+    WalkArgs a{};
+    a.seq = b->seq[b->cur].p;
+    a.out = b->seq[b->cur ^ 1].p;
+    a.off = b->off.p;
+    a.len_cur = b->len[b->cur].p;
+    a.len_next = b->len[b->cur ^ 1].p;
+    a.dropped = b->dropped.p;
+    a.nodes = b->nodes.p;
+    a.node_off = b->node_off.p;
+    a.bf = job->d_bf.p;
+    a.contig_batch = b->contig_batch.p;
+    a.n_k = p.n_k;
+    a.ki = ki;
+    a.k = p.k[ki];
+    a.hash_num = p.hash_num;
+    a.bf_words = (uint32_t)(p.bf_bytes / 4);
+    a.bf_mod = make_fastmod(p.bf_bytes * 8);
+    static const uint32_t tries[6] = { 0, 1, 5, 21, 85, 341 };
+    a.max_ins_tries = tries[p.max_insertions];
+    a.max_del = p.max_deletions;
+    a.jump = p.jump;
+    a.min_contig_len = p.min_contig_len;
+    a.soft_mask = p.soft_mask ? 1 : 0;
+    // the reference's float expressions (ntedit.cpp:1517-1523, 1333-1337, 1226-1230)
+    const float kf = (float)a.k;
+    a.need_missing = smallest_count_passing((kf / (float)p.jump) * p.missing_ratio);
+    a.need_edit = smallest_count_passing((kf / (float)p.jump) * p.edit_ratio);
+    a.need_del = smallest_count_passing((1 + (kf / (float)p.jump)) * p.edit_ratio);
+    a.insertion_cap = (uint32_t)(kf * 1.5f);
+    a.err = b->err.p;
+    a.stats = b->stats.p;
+    hipStream_t s = job->ctx->stream;
+    int rc = job->t_walk.begin(s, job->h_contig_off[job->n_contigs]);
+    if (rc != GP_OK)
+        return rc;
+    hipLaunchKernelGGL(ntedit_walk, dim3(job->n_contigs), dim3(kWalkThreads), 0, s, a);
+    GP_HIP(hipGetLastError());
+    if ((rc = job->t_walk.end(s)) != GP_OK)
+        return rc;
+    b->cur ^= 1;
+    return GP_OK;
+}
+
+int stage_b_guard(gp_job* job)
+{
+    StageBC* b = job->bc;
+    if (job->n_contigs == 0)
+        return GP_OK;
+    hipStream_t s = job->ctx->stream;
+    hipLaunchKernelGGL(guard_kernel, dim3((job->n_batches + 255) / 256), dim3(256), 0, s,
+                       (const uint32_t*)b->batch_begin.p, job->n_batches,
+                       (const uint32_t*)b->name_len.p, (const uint32_t*)b->in_len.p,
+                       (const uint32_t*)b->len[b->cur].p, (const uint8_t*)b->dropped.p,
+                       b->batch_skip.p);
+    hipLaunchKernelGGL(copy_contigs, dim3(job->n_contigs), dim3(256), 0, s,
+                       (const uint8_t*)job->d_contigs_in.p, (const uint64_t*)b->in_off.p,
+                       (const uint32_t*)b->in_len.p, b->seq[b->cur].p, (const uint64_t*)b->off.p,
+                       b->len[b->cur].p, b->dropped.p, (const uint8_t*)b->batch_skip.p,
+                       (const uint32_t*)b->contig_batch.p);
+    GP_HIP(hipGetLastError());
+    return GP_OK;
+}
+
+int stage_mask(gp_job* job)
+{
+    StageBC* b = job->bc;
+    if (job->n_contigs == 0)
+        return GP_OK;
+    hipStream_t s = job->ctx->stream;
+    hipLaunchKernelGGL(mask_kernel, dim3(job->n_contigs), dim3(kMaskThreads), 0, s,
+                       (const uint8_t*)b->seq[b->cur].p, (const uint64_t*)b->off.p,
+                       (const uint32_t*)b->len[b->cur].p, b->seq[b->cur ^ 1].p,
+                       b->len[b->cur ^ 1].p, (const uint8_t*)b->dropped.p, job->prm.k[0]);
+    GP_HIP(hipGetLastError());
+    b->cur ^= 1;
+    return GP_OK;
+}
+
+int stage_upper(gp_job* job)
+{
+    StageBC* b = job->bc;
+    if (job->n_contigs == 0)
+        return GP_OK;
+    hipStream_t s = job->ctx->stream;
+    hipLaunchKernelGGL(upper_kernel, dim3(64, job->n_contigs), dim3(256), 0, s, b->seq[b->cur].p,
+                       (const uint64_t*)b->off.p, (const uint32_t*)b->len[b->cur].p,
+                       (const uint8_t*)b->dropped.p);
+    GP_HIP(hipGetLastError());
+    return pull_stats(job);
+}
+
+int stage_lengths(gp_job* job, uint64_t* lengths, uint8_t* dropped, uint64_t* total)
+{
+    StageBC* b = job->bc;
+    const uint32_t n = job->n_contigs;
+    GP_HIP(hipStreamSynchronize(job->ctx->stream));
+    int rc = pull_stats(job);
+    if (rc != GP_OK)
+        return rc;
+    std::vector<uint32_t> len(n ? n : 1);
+    std::vector<uint8_t> dr(n ? n : 1);
+    if (n) {
+        GP_HIP(hipMemcpy(len.data(), b->len[b->cur].p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        GP_HIP(hipMemcpy(dr.data(), b->dropped.p, n, hipMemcpyDeviceToHost));
+    }
+    uint64_t t = 0;
+    for (uint32_t c = 0; c < n; c++) {
+        uint64_t l = dr[c] ? 0 : len[c];
+        if (lengths)
+            lengths[c] = l;
+        if (dropped)
+            dropped[c] = dr[c];
+        t += l;
+    }
+    if (total)
+        *total = t;
+    return GP_OK;
+}
+
+int stage_sequences(gp_job* job, uint8_t* buf, uint64_t buf_bytes)
+{
+    StageBC* b = job->bc;
+    const uint32_t n = job->n_contigs;
+    std::vector<uint64_t> lens(n ? n : 1);
+    std::vector<uint8_t> dr(n ? n : 1);
+    uint64_t total = 0;
+    int rc = stage_lengths(job, lens.data(), dr.data(), &total);
+    if (rc != GP_OK)
+        return rc;
+    if (total > buf_bytes) {
+        set_error("gp_job_get_sequences: buffer too small");
+        return GP_ERR_INVALID_ARG;
+    }
+    uint64_t at = 0;
+    for (uint32_t c = 0; c < n; c++) {
+        if (lens[c]) {
+            GP_HIP(hipMemcpy(buf + at, b->seq[b->cur].p + b->h_off[c], lens[c],
+                             hipMemcpyDeviceToHost));
+            at += lens[c];
+        }
+    }
+    return GP_OK;
+}
+
+} // namespace gp

@@ -51,7 +51,7 @@ typedef struct gp_job gp_job; /* a set of batches resident on the device */
  *                                            subprojects/sealer/sealer.cpp:131-165 */
 typedef struct gp_params {
     uint32_t n_k;
-    uint32_t k[GP_MAX_K_VALUES]; /* descending, each 4..64 */
+    uint32_t k[GP_MAX_K_VALUES]; /* descending, each 4..63 */
     uint32_t hash_num;           /* 1..8 */
     uint64_t cbf_bytes;          /* counting filter: one u8 counter per byte */
     uint64_t bf_bytes;           /* Bloom filter bytes (bits = 8x) */
