@@ -135,11 +135,12 @@ MASK_CASES = [
     (b"ACGTACGTACGT", 4, b"ACGTACGTACGT"),
     (b"ACGTacgtACGT", 4, b"ACGTacgtACGT"),             # lower run of 4 == k stays as is
     (b"ACGTAacgACGTA", 4, b"ACGTAacgACGTA"),
-    (b"ACGTAAaCGAAAAA", 4, b"ACGTaaacgAAAAA"),         # AA<k lowered, a kept, CG<k lowered
+    (b"ACGTAAaCGaAAAAA", 4, b"ACGTAAacgaAAAAA"),       # CG between two lower bases: run of 2 < k
     (b"NNNNACGTACGTNN", 4, b"ACGTACGT"),               # ends stripped
     (b"ACGTACGTNNNNNNACGTACGT", 4, b"ACGTACGTNNNNNNACGTACGT"),
     (b"ACGTACGTnnnACGTACGT", 4, b"ACGTACGTnnnACGTACGT"),   # 'n' run shorter than k: lower() no-op
-    (b"ACGTAXACGTA", 4, b"ACGTaACGTA"),                # X matches no class: dropped, splits runs
+    (b"ACGTAXACGTA", 4, b"ACGTAACGTA"),                # X matches no class: dropped, splits runs
+    (b"ACGTACGTAXAXACGTACGT", 4, b"ACGTACGTAaACGTACGT"),  # ... and a split-off run is short
     (b"acgt", 4, b"ACGT"),                             # len < 2k: all upper-cased first
     (b"nnnn", 4, b"N"),
     (b"", 4, b"N"),
