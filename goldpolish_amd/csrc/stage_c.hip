@@ -1,7 +1,1387 @@
-// stage_c.hip -- placeholder until the Sealer BFS kernels land (next commit).
+// stage_c.hip -- stage C of the path on MI355X: Sealer gap filling, i.e.
+// Konnector's constrained bidirectional BFS through the Bloom-filter de Bruijn
+// graph between the flanks of every soft-masked run, for each k in turn.
+//
+// What it replaces (see oracle/sealer.c for the line-by-line map):
+//   /root/reference/subprojects/sealer/sealer.cpp findFlanks :695-733,
+//       makePseudoReads :560-577, kRun :579-685, merge :425-517,
+//       insertIntoScaffold :525-558
+//   Konnector/konnector.h connectPairs :234-438
+//   Konnector/DBGBloomAlgorithms.h getStartKmerPos :51-108
+//   Graph/BidirectionalBFS.h, Graph/ConstrainedBidiBFSVisitor.h,
+//   Graph/AllPathsSearch.h, Graph/HashGraph.h, Align/alignGlobal.cc
+//
+// Shape of the work: a search is a pointer-chasing, latency-bound walk (hash
+// table of visited k-mers, 4 membership tests per vertex), searches are
+// independent of each other, and there are tens of thousands of them.  So:
+//   * find_gaps / prep_gaps: one workgroup per contig finds the gap runs and
+//     their flanks in parallel, and an exact hash set (keys compared by the
+//     flank bytes themselves) reproduces the reference's map semantics:
+//     identical flank pairs collapse to the last gap, and a left flank whose
+//     gap closed leaves the pool for the smaller k.
+//   * connect: persistent workers (one wave each, every wave drains a shared
+//     queue and exits when it is empty) run one search at a time in a private
+//     HBM arena; neighbour k-mers are hashed incrementally in O(1) from the
+//     parent's forward/reverse ntHash instead of re-hashing k bases.
+//   * consensus: the rare multi-path gaps are folded with the affine-gap
+//     aligner in a second queue.
+//   * apply_fills: per contig, fills are spliced right to left exactly as
+//     std::string::replace would, using a right-aligned gap buffer.
 #include "gp_bc.h"
+
+#include <algorithm>
+#include <cstring>
+
 namespace gp {
-int stage_c_prepare(gp_job*) { return GP_OK; }
-void stage_c_release(gp_job*) {}
-int stage_c_run(gp_job*) { return GP_OK; }
+
+constexpr uint32_t kNoLimit = 0xFFFFFFFFu;
+constexpr uint32_t kNoMatch = 0xFFFFFFFFu;
+constexpr int kSlotBits = 18;
+constexpr uint32_t kSlots = 1u << kSlotBits;
+constexpr uint32_t kVertCap = 1u << 17;     // <= max_cost + 2 vertices per search
+constexpr uint32_t kEdgeCap = 2u * kVertCap + 64;
+constexpr uint32_t kMaxPathsDev = 16;
+constexpr uint32_t kPathCap = 1024;          // vertices per stored path
+constexpr uint32_t kNwMax = 1800;            // longest sequence the consensus aligner takes
+constexpr int kWorkers = 1024;
+constexpr int kNwWorkers = 16;
+
+enum { FWD = 0, REV = 1 };
+enum { R_FOUND = 0, R_TOO_MANY_PATHS, R_TOO_MANY_BRANCHES, R_CYCLE, R_MAX_COST, R_MEM, R_NO_PATH };
+enum { V_SUCCESS = 0, V_SKIP, V_ABORT };
+
+struct Gap {
+    uint32_t s, e;      // gap run [s, e)
+    uint32_t contig;
+    uint32_t pair_rep;  // global index of the first gap with the same (left, right) flanks
+    uint32_t left_rep;  // ... with the same left flank
+};
+
+struct Vert {
+    uint64_t km[2];     // 2-bit packed k-mer, last base in the low bits (A0 C1 G2 T3)
+    uint64_t fh, rh;
+    uint32_t head[2], tail[2]; // successor lists of the two traversal-history graphs
+    uint16_t depth[2];
+    uint8_t color[2];
+    uint8_t pad[2];
+    uint32_t stamp_visit, stamp_cyc;
+};
+
+struct Edge {
+    uint32_t to, next;
+};
+
+struct MultiHdr {
+    uint32_t gap, sp, gp, n_paths;
+    uint32_t len[kMaxPathsDev];
+    uint64_t off[kMaxPathsDev]; // into the pool
+};
+
+struct CState {
+    DevBuf<Gap> gaps;
+    DevBuf<uint32_t> gap_off;      // [n_contigs+1] slice of `gaps` per contig
+    DevBuf<uint32_t> n_gaps;       // [n_contigs]
+    DevBuf<uint32_t> pair_last;    // [G] per pair representative: last gap + 1
+    DevBuf<uint32_t> closed_at;    // [G] per left representative: first k index that closed it
+    DevBuf<uint64_t> fill_off;     // [G]
+    DevBuf<uint32_t> fill_len;     // [G] 0 = not closed
+    DevBuf<uint32_t> table_left, table_pair; // exact hash sets, value = gap index + 1
+    DevBuf<uint32_t> work;         // valid gaps
+    DevBuf<uint32_t> queue;        // [0] work count [1] head [2] multi count [3] multi head
+    DevBuf<uint8_t> pool;          // fills and connecting sequences
+    DevBuf<unsigned long long> pool_head;
+    DevBuf<MultiHdr> multi;
+    // worker arenas
+    DevBuf<uint32_t> slots;
+    DevBuf<Vert> verts;
+    DevBuf<Edge> edges;
+    DevBuf<uint32_t> scratch;      // queues, stacks, paths
+    DevBuf<int32_t> nw;
+    DevBuf<uint32_t> epoch;        // per worker
+    std::vector<uint32_t> h_gap_off;
+    uint32_t gap_cap = 0, table_bits = 0, multi_cap = 0;
+    uint64_t pool_cap = 0;
+};
+
+constexpr uint32_t kScratchWords = 2 * kVertCap            // two BFS queues
+                                   + 4 * kPathCap          // DFS path + iterator stacks
+                                   + 3 * kMaxPathsDev * kPathCap; // left, right, found paths
+
+struct CArgs {
+    const uint8_t* seq;      // masked sequences (stage input)
+    uint8_t* out;            // spliced sequences
+    const uint64_t* off;
+    const uint32_t* len_cur;
+    uint32_t* len_next;
+    const uint8_t* dropped;
+    const uint32_t* contig_batch;
+    const uint32_t* bf;
+    uint32_t n_contigs, n_k, ki, k, hash_num, bf_words;
+    FastMod bf_mod;
+    uint32_t flank_len, max_gap, max_paths, max_branches, max_cost;
+    Gap* gaps;
+    const uint32_t* gap_off;
+    uint32_t* n_gaps;
+    uint32_t* pair_last;
+    uint32_t* closed_at;
+    uint64_t* fill_off;
+    uint32_t* fill_len;
+    uint32_t* table_left;
+    uint32_t* table_pair;
+    uint32_t table_bits;
+    uint32_t* work;
+    uint32_t* queue;
+    uint8_t* pool;
+    unsigned long long* pool_head;
+    uint64_t pool_cap;
+    MultiHdr* multi;
+    uint32_t multi_cap;
+    uint32_t* slots;
+    Vert* verts;
+    Edge* edges;
+    uint32_t* scratch;
+    int32_t* nw;
+    uint32_t* epoch;
+    uint32_t* err;
+    unsigned long long* stats; // [4] gaps [5] closed [6] vertex tests
+    uint64_t cap_of_slot;      // unused
+};
+
+__device__ inline bool is_gap_char(uint8_t c)
+{
+    switch (c) {
+    case 'N': case 'n': case 'a': case 't': case 'c': case 'g': case 'u': case 'r': case 'y':
+    case 'k': case 'm': case 's': case 'w': case 'b': case 'd': case 'h': case 'v': case 'x':
+        return true;
+    default:
+        return false;
+    }
 }
+
+__device__ inline uint8_t up(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
+
+__device__ inline uint8_t comp_base(uint8_t c)
+{
+    uint8_t r;
+    switch (up(c)) {
+    case 'A': r = 'T'; break;
+    case 'C': r = 'G'; break;
+    case 'G': r = 'C'; break;
+    case 'T': r = 'A'; break;
+    case 'M': r = 'K'; break;
+    case 'R': r = 'Y'; break;
+    case 'W': r = 'W'; break;
+    case 'S': r = 'S'; break;
+    case 'Y': r = 'R'; break;
+    case 'K': r = 'M'; break;
+    case 'V': r = 'B'; break;
+    case 'H': r = 'D'; break;
+    case 'D': r = 'H'; break;
+    case 'B': r = 'V'; break;
+    default: r = 'N'; break;
+    }
+    return (c >= 'a' && c <= 'z') ? (uint8_t)(r + 32) : r;
+}
+
+// ------------------------------------------------------------ gap discovery
+constexpr int kGapThreads = 256;
+
+__global__ __launch_bounds__(kGapThreads) void find_gaps(CArgs a)
+{
+    __shared__ uint32_t cnt[kGapThreads + 1];
+    const uint32_t cid = blockIdx.x, tid = threadIdx.x;
+    if (a.dropped[cid]) {
+        if (tid == 0)
+            a.n_gaps[cid] = 0;
+        return;
+    }
+    const uint32_t len = a.len_cur[cid];
+    const uint8_t* s = a.seq + a.off[cid];
+    const uint32_t chunk = (len + kGapThreads - 1) / kGapThreads;
+    const uint32_t b = min(len, tid * chunk), e = min(len, b + chunk);
+    uint32_t n = 0;
+    for (uint32_t i = b; i < e; i++)
+        if (is_gap_char(s[i]) && (i == 0 || !is_gap_char(s[i - 1])))
+            n++;
+    cnt[tid] = n;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int t = 0; t < kGapThreads; t++) {
+            uint32_t v = cnt[t];
+            cnt[t] = acc;
+            acc += v;
+        }
+        cnt[kGapThreads] = acc;
+        const uint32_t cap = a.gap_off[cid + 1] - a.gap_off[cid];
+        if (acc > cap) {
+            atomicOr(a.err, 8u);
+            acc = cap;
+        }
+        a.n_gaps[cid] = acc;
+        atomicAdd(&a.stats[4], (unsigned long long)cnt[kGapThreads]);
+    }
+    __syncthreads();
+    const uint32_t cap = a.gap_off[cid + 1] - a.gap_off[cid];
+    Gap* g = a.gaps + a.gap_off[cid];
+    uint32_t at = cnt[tid];
+    for (uint32_t i = b; i < e; i++)
+        if (is_gap_char(s[i]) && (i == 0 || !is_gap_char(s[i - 1]))) {
+            uint32_t j = i + 1;
+            while (j < len && is_gap_char(s[j]))
+                j++;
+            if (at < cap) {
+                g[at].s = i;
+                g[at].e = j;
+                g[at].contig = cid;
+            }
+            at++;
+        }
+}
+
+struct Flank {
+    uint32_t ls, le, rs, re;
+    bool valid;
+};
+
+__device__ inline Flank flank_of(const CArgs& a, uint32_t gi)
+{
+    const Gap g = a.gaps[gi];
+    const uint32_t base = a.gap_off[g.contig], n = a.n_gaps[g.contig];
+    const uint32_t local = gi - base;
+    const uint32_t len = a.len_cur[g.contig];
+    Flank f;
+    f.valid = g.e < len; // a sequence that ends in a gap leaves it alone (:711-714)
+    const uint32_t prev_e = local > 0 ? a.gaps[gi - 1].e : 0u;
+    const uint32_t next_s = local + 1 < n ? a.gaps[gi + 1].s : len;
+    const long ls = (long)g.s - (long)a.flank_len;
+    f.ls = (uint32_t)max((long)prev_e, ls);
+    f.le = g.s;
+    f.rs = g.e;
+    f.re = min(next_s, g.e + a.flank_len);
+    return f;
+}
+
+__device__ inline uint64_t fnv_upper(const uint8_t* s, uint32_t n, uint64_t h)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        h ^= up(s[i]);
+        h *= 1099511628211ULL;
+    }
+    return h;
+}
+
+__device__ inline bool same_upper(const uint8_t* a, uint32_t la, const uint8_t* b, uint32_t lb)
+{
+    if (la != lb)
+        return false;
+    for (uint32_t i = 0; i < la; i++)
+        if (up(a[i]) != up(b[i]))
+            return false;
+    return true;
+}
+
+// exact set: returns the representative (first claimant) of my key
+__device__ uint32_t find_or_insert(const CArgs& a, uint32_t* table, uint64_t h, uint32_t me,
+                                   bool pair)
+{
+    const uint32_t mask = (1u << a.table_bits) - 1;
+    uint32_t slot = (uint32_t)(h >> 20) & mask;
+    const Gap gm = a.gaps[me];
+    const Flank fm = flank_of(a, me);
+    const uint8_t* sm = a.seq + a.off[gm.contig];
+    for (uint32_t probe = 0; probe <= mask; probe++, slot = (slot + 1) & mask) {
+        uint32_t v = atomicCAS(&table[slot], 0u, me + 1);
+        if (v == 0)
+            return me;
+        const uint32_t other = v - 1;
+        if (other == me)
+            return me;
+        const Gap go = a.gaps[other];
+        if (go.contig != gm.contig)
+            continue;
+        const Flank fo = flank_of(a, other);
+        if (!same_upper(sm + fm.ls, fm.le - fm.ls, sm + fo.ls, fo.le - fo.ls))
+            continue;
+        if (pair && !same_upper(sm + fm.rs, fm.re - fm.rs, sm + fo.rs, fo.re - fo.rs))
+            continue;
+        return other;
+    }
+    atomicOr(a.err, 16u);
+    return me;
+}
+
+__global__ void prep_gaps(CArgs a)
+{
+    const uint32_t cid = blockIdx.x;
+    if (a.dropped[cid])
+        return;
+    const uint32_t n = a.n_gaps[cid], base = a.gap_off[cid];
+    const uint8_t* s = a.seq + a.off[cid];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t gi = base + i;
+        const Flank f = flank_of(a, gi);
+        a.fill_len[gi] = 0;
+        a.closed_at[gi] = 0xFFu;
+        if (!f.valid) {
+            a.gaps[gi].pair_rep = a.gaps[gi].left_rep = gi;
+            continue;
+        }
+        uint64_t hl = fnv_upper(s + f.ls, f.le - f.ls, 1469598103934665603ULL ^ ((uint64_t)cid << 32));
+        uint64_t hp = fnv_upper(s + f.rs, f.re - f.rs, hl ^ 0x9E3779B97F4A7C15ULL);
+        const uint32_t lr = find_or_insert(a, a.table_left, hl, gi, false);
+        const uint32_t pr = find_or_insert(a, a.table_pair, hp, gi, true);
+        a.gaps[gi].left_rep = lr;
+        a.gaps[gi].pair_rep = pr;
+        atomicMax(&a.pair_last[pr], gi + 1);
+        a.work[atomicAdd(&a.queue[0], 1u)] = gi;
+    }
+}
+
+// ------------------------------------------------------------------ search
+struct SeedTab {
+    uint64_t s[4], sk[4], sk1[4]; // seed, rotated by k, rotated by k-1; index A0 C1 G2 T3
+};
+
+struct Search {
+    const CArgs* a;
+    const uint32_t* bf;
+    uint32_t k;
+    SeedTab st;
+    uint32_t* slots;
+    uint32_t epoch;
+    Vert* v;
+    Edge* e;
+    uint32_t nv, ne;
+    uint32_t* q[2];
+    uint32_t qh[2], qt[2];
+    uint32_t* dfs_path;
+    uint32_t* dfs_it;
+    uint32_t* left;  // kMaxPathsDev x kPathCap
+    uint32_t* right;
+    uint32_t* found;
+    uint32_t left_n, right_n, found_n;
+    uint32_t left_len[kMaxPathsDev], right_len[kMaxPathsDev], found_len[kMaxPathsDev];
+    uint32_t start, goal;
+    uint32_t max_paths, max_branches, max_cost, cost;
+    uint32_t min_len, max_len, max_depth[2];
+    bool too_many_branches, max_cost_exceeded, too_many_paths, overflow;
+    uint32_t ce_u[kMaxPathsDev + 2], ce_v[kMaxPathsDev + 2], n_ce;
+    uint32_t stamp;
+    unsigned long long tests;
+};
+
+typedef unsigned __int128 u128;
+
+__device__ inline u128 km_load(const uint64_t km[2]) { return ((u128)km[1] << 64) | km[0]; }
+
+__device__ inline void km_store(u128 x, uint64_t km[2])
+{
+    km[0] = (uint64_t)x;
+    km[1] = (uint64_t)(x >> 64);
+}
+
+__device__ inline uint32_t code_acgt(uint8_t c)
+{
+    switch (c) {
+    case 'A': return 0;
+    case 'C': return 1;
+    case 'G': return 2;
+    case 'T': return 3;
+    default: return 4;
+    }
+}
+
+__device__ inline bool bf_has(Search& S, uint64_t base)
+{
+    const CArgs& a = *S.a;
+    S.tests++;
+    bool all = true;
+    for (uint32_t i = 0; i < a.hash_num; i++) {
+        uint64_t h = i ? ext_hash(base, S.k, i) : base;
+        uint64_t n = fastmod(h, a.bf_mod);
+        all &= ((S.bf[n >> 5] >> (uint32_t)(n & 31)) & 1u) != 0;
+    }
+    return all;
+}
+
+// hash + pack an upper-case ACGT k-mer; false if it holds another byte
+__device__ bool kmer_of(const Search& S, const uint8_t* s, uint64_t km[2], uint64_t& fh,
+                        uint64_t& rh)
+{
+    const uint32_t k = S.k;
+    uint64_t f = 0, r = 0;
+    u128 x = 0;
+    for (uint32_t i = 0; i < k; i++) {
+        uint32_t c = code_acgt(s[i]);
+        uint32_t cr = code_acgt(s[k - 1 - i]);
+        if (c > 3 || cr > 3)
+            return false;
+        f = srol1(f) ^ S.st.s[c];
+        r = srol1(r) ^ S.st.s[3 - cr];
+        x = (x << 2) | c;
+    }
+    km_store(x, km);
+    fh = f;
+    rh = r;
+    return true;
+}
+
+// getStartKmerPos, FORWARD direction (both call sites), rolling from the flank end backwards
+__device__ uint32_t start_kmer_pos(Search& S, const uint8_t* seq, uint32_t len, uint32_t need)
+{
+    const uint32_t k = S.k;
+    if (len < k)
+        return kNoMatch;
+    uint32_t run = 0, best_len = 0, best_pos = 0;
+    for (int pos = (int)(len - k); pos >= 0; pos--) {
+        uint64_t km[2], fh, rh;
+        bool ok = kmer_of(S, seq + pos, km, fh, rh);
+        if (ok)
+            ok = bf_has(S, fh + rh);
+        else
+            S.tests++;
+        if (!ok) {
+            if (run > best_len) {
+                best_pos = (uint32_t)pos + 1;
+                best_len = run;
+            }
+            run = 0;
+        } else {
+            run++;
+            if (run >= need)
+                return (uint32_t)pos;
+        }
+    }
+    if (run > best_len) {
+        best_pos = 0;
+        best_len = run;
+    }
+    return best_len == 0 ? kNoMatch : best_pos;
+}
+
+__device__ inline uint64_t mix_km(uint64_t a, uint64_t b)
+{
+    uint64_t h = a * 0x9E3779B97F4A7C15ULL ^ (b + 0x7F4A7C15ULL) * 0xC2B2AE3D27D4EB4FULL;
+    h ^= h >> 29;
+    return h * 0x165667B19E3779F9ULL;
+}
+
+__device__ uint32_t vert_get(Search& S, const uint64_t km[2], uint64_t fh, uint64_t rh)
+{
+    uint32_t slot = (uint32_t)(mix_km(km[0], km[1]) >> 40) & (kSlots - 1);
+    const uint32_t tag = S.epoch << kSlotBits;
+    for (;;) {
+        uint32_t sv = S.slots[slot];
+        if ((sv & ~(kSlots - 1)) != tag || sv == 0) {
+            // empty for this search
+            if (S.nv >= kVertCap - 1) {
+                S.overflow = true;
+                return 0;
+            }
+            uint32_t id = S.nv++;
+            Vert& x = S.v[id];
+            x.km[0] = km[0];
+            x.km[1] = km[1];
+            x.fh = fh;
+            x.rh = rh;
+            x.head[0] = x.head[1] = x.tail[0] = x.tail[1] = 0xFFFFFFFFu;
+            x.depth[0] = x.depth[1] = 0;
+            x.color[0] = x.color[1] = 0;
+            x.stamp_visit = x.stamp_cyc = 0;
+            S.slots[slot] = tag | (id + 1);
+            return id;
+        }
+        uint32_t id = (sv & (kSlots - 1)) - 1;
+        if (S.v[id].km[0] == km[0] && S.v[id].km[1] == km[1])
+            return id;
+        slot = (slot + 1) & (kSlots - 1);
+    }
+}
+
+// HashGraph::add_edge on history graph gi: append unless already there
+__device__ void hist_add_edge(Search& S, int gi, uint32_t u, uint32_t v)
+{
+    Vert& U = S.v[u];
+    for (uint32_t e = U.head[gi]; e != 0xFFFFFFFFu; e = S.e[e].next)
+        if (S.e[e].to == v)
+            return;
+    if (S.ne >= kEdgeCap) {
+        S.overflow = true;
+        return;
+    }
+    uint32_t id = S.ne++;
+    S.e[id].to = v;
+    S.e[id].next = 0xFFFFFFFFu;
+    if (U.tail[gi] == 0xFFFFFFFFu)
+        U.head[gi] = id;
+    else
+        S.e[U.tail[gi]].next = id;
+    U.tail[gi] = id;
+}
+
+__device__ inline void record_edge(Search& S, uint32_t src, uint32_t dst, int dir)
+{
+    if (dir == FWD)
+        hist_add_edge(S, FWD, dst, src);
+    else
+        hist_add_edge(S, REV, src, dst);
+}
+
+__device__ inline int bump_cost(Search& S)
+{
+    if (S.cost >= S.max_cost) {
+        S.max_cost_exceeded = true;
+        return V_ABORT;
+    }
+    S.cost++;
+    return V_SUCCESS;
+}
+
+__device__ int visit_edge(Search& S, uint32_t src, uint32_t dst, int dir)
+{
+    const uint32_t v = dir == FWD ? dst : src;
+    const uint32_t parent = dir == FWD ? src : dst;
+    if (S.v[v].color[!dir] != 0) {
+        if (bump_cost(S) == V_ABORT)
+            return V_ABORT;
+        if (S.v[parent].depth[dir] >= S.max_depth[dir])
+            return V_SKIP;
+        bool dup = false;
+        for (uint32_t i = 0; i < S.n_ce; i++)
+            dup |= (S.ce_u[i] == src && S.ce_v[i] == dst);
+        if (!dup && S.n_ce < kMaxPathsDev + 2) {
+            S.ce_u[S.n_ce] = src;
+            S.ce_v[S.n_ce] = dst;
+            S.n_ce++;
+        }
+        if (S.max_paths != kNoLimit && S.n_ce > S.max_paths) {
+            S.too_many_paths = true;
+            return V_ABORT;
+        }
+        record_edge(S, src, dst, FWD);
+        record_edge(S, src, dst, REV);
+        return V_SUCCESS;
+    }
+    if (S.v[v].color[dir] == 0) {
+        const uint32_t active = S.qt[dir] - S.qh[dir];
+        if (S.max_branches != kNoLimit && active >= S.max_branches) {
+            S.too_many_branches = true;
+            return V_ABORT;
+        }
+        if (bump_cost(S) == V_ABORT)
+            return V_ABORT;
+        const uint16_t pd = S.v[parent].depth[dir];
+        if (pd == S.max_depth[dir])
+            return V_SKIP;
+        S.v[v].depth[dir] = (uint16_t)(pd + 1);
+        record_edge(S, src, dst, dir);
+        S.v[v].color[dir] = 1;
+        S.q[dir][S.qt[dir]++] = v;
+        return V_SUCCESS;
+    }
+    if (bump_cost(S) == V_ABORT)
+        return V_ABORT;
+    record_edge(S, src, dst, dir);
+    return V_SUCCESS;
+}
+
+// Graph/AllPathsSearch.h:28-104 over history graph gi; paths into out (kPathCap each)
+__device__ int all_paths(Search& S, int gi, uint32_t from, uint32_t to, uint32_t max_paths,
+                         uint32_t max_depth, uint32_t max_cost, uint32_t* out, uint32_t* out_len,
+                         uint32_t& out_n, uint32_t& cost_out)
+{
+    uint32_t* path = S.dfs_path;
+    uint32_t* it = S.dfs_it;
+    const uint32_t stamp = ++S.stamp;
+    uint32_t n_cyc = 0, n = 0, cost = 0;
+    int rc = -1;
+    out_n = 0;
+    path[0] = from;
+    it[0] = S.v[from].head[gi];
+    n = 1;
+    S.v[from].stamp_visit = stamp;
+    while (n > 0 && cost <= max_cost) {
+        if (path[n - 1] == to) {
+            if (max_paths != kNoLimit && out_n >= max_paths) {
+                rc = R_TOO_MANY_PATHS;
+                break;
+            }
+            if (n_cyc) {
+                rc = R_CYCLE;
+                break;
+            }
+            if (out_n >= kMaxPathsDev || n > kPathCap) {
+                S.overflow = true;
+                rc = R_TOO_MANY_PATHS;
+                break;
+            }
+            for (uint32_t i = 0; i < n; i++)
+                out[out_n * kPathCap + i] = path[i];
+            out_len[out_n++] = n;
+        }
+        while (n > 0) {
+            const uint32_t cur = path[n - 1];
+            if ((max_depth != kNoLimit && (n - 1) >= max_depth) || it[n - 1] == 0xFFFFFFFFu) {
+                S.v[cur].stamp_visit = 0;
+                if (S.v[cur].stamp_cyc == stamp) {
+                    S.v[cur].stamp_cyc = 0;
+                    n_cyc--;
+                }
+                n--;
+                if (n > 0)
+                    it[n - 1] = S.e[it[n - 1]].next;
+            } else {
+                const uint32_t v = S.e[it[n - 1]].to;
+                if (S.v[v].stamp_visit == stamp) {
+                    if (S.v[v].stamp_cyc != stamp) {
+                        S.v[v].stamp_cyc = stamp;
+                        n_cyc++;
+                    }
+                    it[n - 1] = S.e[it[n - 1]].next;
+                } else {
+                    if (n >= kPathCap) {
+                        S.overflow = true;
+                        rc = R_TOO_MANY_PATHS;
+                        n = 0;
+                        break;
+                    }
+                    path[n] = v;
+                    it[n] = S.v[v].head[gi];
+                    n++;
+                    S.v[v].stamp_visit = stamp;
+                    cost++;
+                    break;
+                }
+            }
+        }
+        if (rc >= 0)
+            break;
+    }
+    if (rc < 0) {
+        if (cost > max_cost)
+            rc = R_MAX_COST;
+        else if (out_n == 0)
+            rc = R_NO_PATH;
+        else
+            rc = R_FOUND;
+    }
+    cost_out = cost;
+    return rc;
+}
+
+__device__ int build_paths_edge(Search& S, uint32_t u, uint32_t v)
+{
+    if (S.cost > S.max_cost) {
+        S.max_cost_exceeded = true;
+        return R_MAX_COST;
+    }
+    uint32_t c = 0;
+    const uint32_t max_to_start = S.max_paths - S.found_n;
+    int rc = all_paths(S, FWD, u, S.start, max_to_start, S.max_depth[FWD], S.max_cost - S.cost,
+                       S.left, S.left_len, S.left_n, c);
+    S.cost += c;
+    if (rc == R_FOUND) {
+        const uint32_t max_to_goal = (S.max_paths - S.found_n) / S.left_n;
+        rc = all_paths(S, REV, v, S.goal, max_to_goal, S.max_depth[REV], S.max_cost - S.cost,
+                       S.right, S.right_len, S.right_n, c);
+        S.cost += c;
+        if (rc == R_FOUND) {
+            bool added = false;
+            for (uint32_t x = 0; x < S.left_n; x++)
+                for (uint32_t y = 0; y < S.right_n; y++) {
+                    const uint32_t tot = S.left_len[x] + S.right_len[y];
+                    if (tot < S.min_len || tot > S.max_len)
+                        continue;
+                    if (S.found_n >= kMaxPathsDev || tot > kPathCap) {
+                        S.overflow = true;
+                        continue;
+                    }
+                    uint32_t* m = S.found + S.found_n * kPathCap;
+                    for (uint32_t i = 0; i < S.left_len[x]; i++)
+                        m[i] = S.left[x * kPathCap + S.left_len[x] - 1 - i];
+                    for (uint32_t i = 0; i < S.right_len[y]; i++)
+                        m[S.left_len[x] + i] = S.right[y * kPathCap + i];
+                    S.found_len[S.found_n++] = tot;
+                    added = true;
+                }
+            rc = added ? R_FOUND : R_NO_PATH;
+        }
+    }
+    if (rc == R_MAX_COST)
+        S.max_cost_exceeded = true;
+    else if (rc == R_TOO_MANY_PATHS)
+        S.too_many_paths = true;
+    return rc;
+}
+
+__device__ int bidi_search(Search& S)
+{
+    const uint32_t k = S.k;
+    const u128 all = (k == 64) ? ~(u128)0 : (((u128)1 << (2 * k)) - 1);
+    S.v[S.start].color[FWD] = 1;
+    S.v[S.goal].color[REV] = 1;
+    S.q[FWD][S.qt[FWD]++] = S.start;
+    S.q[REV][S.qt[REV]++] = S.goal;
+    int dir = FWD;
+    bool aborted = false;
+    while (!aborted && (S.qh[FWD] < S.qt[FWD] || S.qh[REV] < S.qt[REV])) {
+        const uint32_t u = S.q[dir][S.qh[dir]++];
+        const Vert pu = S.v[u];
+        const u128 pk = km_load(pu.km);
+        // base leaving the k-mer: first (forward extension) or last (backward extension)
+        const uint32_t first = (uint32_t)(pk >> (2 * (k - 1))) & 3;
+        const uint32_t last = (uint32_t)pk & 3;
+        for (uint32_t b = 0; b < 4 && !aborted; b++) {
+            uint64_t km[2], fh, rh;
+            if (dir == FWD) {
+                km_store(((pk << 2) | b) & all, km);
+                fh = srol1(pu.fh) ^ S.st.s[b] ^ S.st.sk[first];
+                rh = sror1(pu.rh ^ S.st.sk[3 - b] ^ S.st.s[3 - first]);
+            } else {
+                km_store((pk >> 2) | ((u128)b << (2 * (k - 1))), km);
+                fh = sror1(pu.fh ^ S.st.s[last]) ^ S.st.sk1[b];
+                rh = srol1(pu.rh ^ S.st.sk1[3 - last]) ^ S.st.s[3 - b];
+            }
+            if (!bf_has(S, fh + rh))
+                continue;
+            const uint32_t w = vert_get(S, km, fh, rh);
+            if (S.overflow) {
+                aborted = true;
+                break;
+            }
+            const int r = dir == FWD ? visit_edge(S, u, w, FWD) : visit_edge(S, w, u, REV);
+            if (r == V_ABORT || S.overflow)
+                aborted = true;
+        }
+        if (aborted)
+            break;
+        S.v[u].color[dir] = 2;
+        if (dir == REV && S.qh[FWD] < S.qt[FWD])
+            dir = FWD;
+        else if (dir == FWD && S.qh[REV] < S.qt[REV])
+            dir = REV;
+    }
+    if (S.too_many_paths)
+        return R_TOO_MANY_PATHS;
+    if (S.too_many_branches)
+        return R_TOO_MANY_BRANCHES;
+    if (S.max_cost_exceeded)
+        return R_MAX_COST;
+    if (S.overflow)
+        return R_MEM;
+    int overall = S.found_n ? R_FOUND : R_NO_PATH;
+    for (uint32_t i = 0; i < S.n_ce; i++) {
+        int rc = build_paths_edge(S, S.ce_u[i], S.ce_v[i]);
+        if (rc == R_FOUND)
+            overall = R_FOUND;
+        else if (rc != R_NO_PATH) {
+            overall = rc;
+            break;
+        }
+    }
+    return overall;
+}
+
+__device__ inline uint64_t pool_alloc(const CArgs& a, uint32_t bytes)
+{
+    unsigned long long at = atomicAdd(a.pool_head, (unsigned long long)((bytes + 15) & ~15u));
+    if (at + bytes > a.pool_cap) {
+        atomicOr(a.err, 32u);
+        return ~0ULL;
+    }
+    return at;
+}
+
+// connecting sequence of found path p into dst; returns its length
+__device__ uint32_t path_to_seq(const Search& S, uint32_t p, uint8_t* dst)
+{
+    const uint32_t k = S.k;
+    const uint32_t* P = S.found + p * kPathCap;
+    const u128 x0 = km_load(S.v[P[0]].km);
+    for (uint32_t i = 0; i < k; i++)
+        dst[i] = (uint8_t)("ACGT"[(uint32_t)(x0 >> (2 * (k - 1 - i))) & 3]);
+    for (uint32_t j = 1; j < S.found_len[p]; j++)
+        dst[k + j - 1] = (uint8_t)("ACGT"[S.v[P[j]].km[0] & 3]);
+    return k + S.found_len[p] - 1;
+}
+
+// merged = read1[0..sp) + cons + revcomp(read2[0..gp)), then maskNew(mask = 0)
+__device__ void write_merged(const CArgs& a, uint32_t gi, const uint8_t* r1, uint32_t l1,
+                             const uint8_t* r2, uint32_t l2, uint32_t sp, uint32_t gp,
+                             const uint8_t* cons, uint32_t lc)
+{
+    const uint32_t lm = sp + lc + gp;
+    const uint64_t at = pool_alloc(a, lm);
+    if (at == ~0ULL)
+        return;
+    uint8_t* m = a.pool + at;
+    for (uint32_t i = 0; i < sp; i++)
+        m[i] = r1[i];
+    for (uint32_t i = 0; i < lc; i++)
+        m[sp + i] = cons[i];
+    for (uint32_t i = 0; i < gp; i++)
+        m[sp + lc + i] = comp_base(r2[gp - 1 - i]);
+    for (uint32_t i = 0; i < l1 && i < lm; i++)
+        if (r1[i] == m[i])
+            m[i] = up(r1[i]);
+    if (l2 <= lm)
+        for (uint32_t i = 0; i < l2; i++) {
+            const uint8_t c = comp_base(r2[l2 - 1 - i]);
+            const uint32_t pos = i + lm - l2;
+            if (c == m[pos])
+                m[pos] = up(c);
+        }
+    a.fill_off[gi] = at;
+    a.fill_len[gi] = lm;
+}
+
+__device__ void connect_one(const CArgs& a, Search& S, uint32_t it, uint32_t wid, uint8_t* r1,
+                            uint8_t* r2, uint8_t* tmp)
+{
+    const uint32_t gi = a.work[it];
+    const Gap g = a.gaps[gi];
+    // still in `flanks`?  (last gap of its flank pair, left flank not closed at a larger k)
+    if (a.pair_last[g.pair_rep] != gi + 1 || a.closed_at[g.left_rep] <= a.ki)
+        return;
+    const Flank f = flank_of(a, gi);
+    const uint32_t k = a.k;
+    const uint32_t l1 = f.le - f.ls, l2 = f.re - f.rs;
+    if (l1 < k || l2 < k)
+        return;
+    const uint8_t* s = a.seq + a.off[g.contig];
+    for (uint32_t i = 0; i < l1; i++)
+        r1[i] = up(s[f.ls + i]);
+    for (uint32_t i = 0; i < l2; i++)
+        r2[i] = comp_base(up(s[f.re - 1 - i]));
+
+    S.a = &a;
+    S.bf = a.bf + ((uint64_t)a.contig_batch[g.contig] * a.n_k + a.ki) * a.bf_words;
+    S.k = k;
+    const uint64_t seeds[4] = { kSeedA, kSeedC, kSeedG, kSeedT };
+    for (int c = 0; c < 4; c++) {
+        S.st.s[c] = seeds[c];
+        S.st.sk[c] = sroln(seeds[c], k);
+        S.st.sk1[c] = sroln(seeds[c], k - 1);
+    }
+    S.tests = 0;
+    uint32_t sp = start_kmer_pos(S, r1, l1, 3);
+    uint32_t gp = kNoMatch;
+    if (sp != kNoMatch)
+        gp = start_kmer_pos(S, r2, l2, 3);
+    else
+        (void)start_kmer_pos(S, r2, l2, 3); // the reference evaluates both (probe count)
+    if (sp == kNoMatch || gp == kNoMatch) {
+        atomicAdd(&a.stats[6], S.tests);
+        return;
+    }
+    // ---- set the search up in this worker's arena
+    uint32_t ep = a.epoch[wid] + 1;
+    S.slots = a.slots + (uint64_t)wid * kSlots;
+    if (ep >= (1u << (32 - kSlotBits))) {
+        for (uint32_t i = 0; i < kSlots; i++)
+            S.slots[i] = 0;
+        ep = 1;
+    }
+    a.epoch[wid] = ep;
+    S.epoch = ep;
+    S.v = a.verts + (uint64_t)wid * kVertCap;
+    S.e = a.edges + (uint64_t)wid * kEdgeCap;
+    uint32_t* sc = a.scratch + (uint64_t)wid * kScratchWords;
+    S.q[0] = sc;
+    S.q[1] = sc + kVertCap;
+    S.dfs_path = sc + 2 * kVertCap;
+    S.dfs_it = S.dfs_path + 2 * kPathCap;
+    S.left = S.dfs_it + 2 * kPathCap;
+    S.right = S.left + kMaxPathsDev * kPathCap;
+    S.found = S.right + kMaxPathsDev * kPathCap;
+    S.nv = S.ne = 0;
+    S.qh[0] = S.qh[1] = S.qt[0] = S.qt[1] = 0;
+    S.left_n = S.right_n = S.found_n = 0;
+    S.n_ce = 0;
+    S.stamp = 0;
+    S.cost = 0;
+    S.too_many_branches = S.max_cost_exceeded = S.too_many_paths = S.overflow = false;
+    S.max_paths = a.max_paths;
+    S.max_branches = a.max_branches;
+    S.max_cost = a.max_cost;
+
+    uint64_t km[2], fh, rh;
+    kmer_of(S, r1 + sp, km, fh, rh);
+    S.start = vert_get(S, km, fh, rh);
+    uint8_t gk[64];
+    for (uint32_t i = 0; i < k; i++)
+        gk[i] = comp_base(r2[gp + k - 1 - i]);
+    kmer_of(S, gk, km, fh, rh);
+    S.goal = vert_get(S, km, fh, rh);
+
+    const uint32_t max_merged = a.max_gap + 2 * a.flank_len;
+    const uint32_t max_path = max_merged - k + 1 - sp - gp;
+    const int min_i = (int)(0u - k + 1 - sp - gp);
+    uint32_t min_path = (uint32_t)(min_i > 0 ? min_i : 0);
+    const uint32_t need = max(l1 - k + 1 - sp, l2 - k + 1 - gp);
+    min_path = max(min_path, need);
+    S.min_len = (uint16_t)min_path;
+    S.max_len = (uint16_t)max_path;
+    const uint16_t md = (uint16_t)(S.max_len - 1);
+    S.max_depth[FWD] = (uint16_t)(md / 2 + md % 2);
+    S.max_depth[REV] = (uint16_t)(md / 2);
+    if (S.start == S.goal && 1 >= S.min_len) {
+        S.found[0] = S.start;
+        S.found_len[0] = 1;
+        S.found_n = 1;
+    }
+    const int rc = bidi_search(S);
+    atomicAdd(&a.stats[6], S.tests);
+    if (S.overflow)
+        atomicOr(a.err, 64u);
+    if (rc != R_FOUND)
+        return;
+    // closing removes every gap that shares this left flank from the later k runs
+    atomicMin(&a.closed_at[g.left_rep], a.ki + 1);
+    atomicAdd(&a.stats[5], 1ull);
+    if (S.found_n == 1) {
+        const uint32_t lc = path_to_seq(S, 0, tmp);
+        write_merged(a, gi, r1, l1, r2, l2, sp, gp, tmp, lc);
+    } else {
+        // keep the alternative connecting sequences for the consensus pass
+        const uint32_t mi = atomicAdd(&a.queue[2], 1u);
+        if (mi >= a.multi_cap) {
+            atomicOr(a.err, 128u);
+            return;
+        }
+        MultiHdr& h = a.multi[mi];
+        h.gap = gi;
+        h.sp = sp;
+        h.gp = gp;
+        h.n_paths = S.found_n;
+        for (uint32_t p = 0; p < S.found_n; p++) {
+            const uint32_t lc = path_to_seq(S, p, tmp);
+            const uint64_t at = pool_alloc(a, lc);
+            h.len[p] = lc;
+            h.off[p] = at;
+            if (at != ~0ULL)
+                for (uint32_t i = 0; i < lc; i++)
+                    a.pool[at + i] = tmp[i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void sealer_connect(CArgs a)
+{
+    __shared__ Search S;
+    __shared__ uint8_t r1[64], r2[64], tmp[kPathCap + 64];
+    __shared__ uint32_t item;
+    const uint32_t wid = blockIdx.x, lane = threadIdx.x;
+    const uint32_t n_work = a.queue[0];
+    for (;;) {
+        if (lane == 0)
+            item = atomicAdd(&a.queue[1], 1u);
+        __syncthreads();
+        const uint32_t it = item;
+        __syncthreads();
+        if (it >= n_work)
+            break; // every wave leaves here once the queue has drained
+        // one lane walks the graph; the wave reconverges before the next fetch
+        if (lane == 0)
+            connect_one(a, S, it, wid, r1, r2, tmp);
+    }
+}
+
+// ------------------------------------------------------------- consensus
+__device__ inline uint32_t amb_mask(uint8_t c)
+{
+    const uint32_t tab[26] = { 0x1, 0xe, 0x2, 0xd, 0, 0, 0x4, 0xb, 0, 0, 0xc, 0, 0x3,
+                               0xf, 0, 0, 0, 0x5, 0x6, 0x8, 0, 0x7, 0x9, 0, 0xa, 0 };
+    const uint32_t i = (uint32_t)(up(c) - 'A');
+    return i < 26 ? tab[i] : 0;
+}
+
+__device__ inline uint8_t amb_or(uint8_t x, uint8_t y)
+{
+    const char* back = "NACMGRSVTWYHKDBN";
+    uint8_t c = (uint8_t)back[(amb_mask(x) | amb_mask(y)) & 15];
+    const bool lower = (x >= 'a' && x <= 'z') || (y >= 'a' && y <= 'z');
+    return lower ? (uint8_t)(c + 32) : c;
+}
+
+__device__ inline int nw_score(uint8_t x, uint8_t y, uint8_t& c)
+{
+    if (x == y) {
+        c = x;
+        return 5;
+    }
+    c = amb_or(x, y);
+    return (c == x || c == y) ? 5 : -4;
+}
+
+// Gotoh global alignment + consensus (Align/alignGlobal.cc:55-198); out gets the
+// consensus, returns its length
+__device__ uint32_t nw_consensus(const uint8_t* A, uint32_t la, const uint8_t* B, uint32_t lb,
+                                 int32_t* mat, uint8_t* out)
+{
+    const int OPEN = -12, EXT = -4, NEG = -(1 << 29);
+    const uint32_t W = lb + 1;
+    int32_t* f = mat;
+    int32_t* g = mat + (uint64_t)(kNwMax + 1) * (kNwMax + 1);
+    int32_t* h = g + (uint64_t)(kNwMax + 1) * (kNwMax + 1);
+#define F(i, j) f[(uint64_t)(i) * W + (j)]
+#define G(i, j) g[(uint64_t)(i) * W + (j)]
+#define H(i, j) h[(uint64_t)(i) * W + (j)]
+    for (uint32_t i = 0; i <= la; i++) {
+        F(i, 0) = G(i, 0) = i == 0 ? 0 : OPEN + EXT * ((int)i - 1);
+        H(i, 0) = NEG;
+    }
+    for (uint32_t j = 0; j <= lb; j++) {
+        F(0, j) = H(0, j) = j == 0 ? 0 : OPEN + EXT * ((int)j - 1);
+        G(0, j) = NEG;
+    }
+    uint8_t c;
+    for (uint32_t i = 1; i <= la; i++)
+        for (uint32_t j = 1; j <= lb; j++) {
+            const int a1 = F(i - 1, j) + OPEN, a2 = G(i - 1, j) + EXT;
+            G(i, j) = max(a1, a2);
+            const int b1 = F(i, j - 1) + OPEN, b2 = H(i, j - 1) + EXT;
+            H(i, j) = max(b1, b2);
+            const int d = F(i - 1, j - 1) + nw_score(A[i - 1], B[j - 1], c);
+            F(i, j) = max(d, max(G(i, j), H(i, j)));
+        }
+    uint32_t n = 0, i = la, j = lb;
+    while (i > 0 && j > 0) {
+        const int fij = F(i, j);
+        const uint8_t x = A[i - 1], y = B[j - 1];
+        const int sc = nw_score(x, y, c);
+        if (fij == F(i - 1, j - 1) + sc) {
+            out[n++] = c;
+            i--;
+            j--;
+        } else if (fij == F(i - 1, j) + OPEN || fij == G(i - 1, j) + EXT) {
+            while (i > 1 && G(i, j) == G(i - 1, j) + EXT) {
+                out[n++] = (uint8_t)(A[i - 1] | 0x20);
+                i--;
+            }
+            out[n++] = (uint8_t)(A[i - 1] | 0x20);
+            i--;
+        } else {
+            while (j > 1 && H(i, j) == H(i, j - 1) + EXT) {
+                out[n++] = (uint8_t)(B[j - 1] | 0x20);
+                j--;
+            }
+            out[n++] = (uint8_t)(B[j - 1] | 0x20);
+            j--;
+        }
+    }
+    while (i > 0)
+        out[n++] = (uint8_t)(A[--i] | 0x20);
+    while (j > 0)
+        out[n++] = (uint8_t)(B[--j] | 0x20);
+    for (uint32_t x = 0, y = n; x + 1 < y; x++, y--) {
+        const uint8_t t = out[x];
+        out[x] = out[y - 1];
+        out[y - 1] = t;
+    }
+#undef F
+#undef G
+#undef H
+    return n;
+}
+
+__device__ void consensus_one(const CArgs& a, uint32_t it, int32_t* mat, uint8_t* bufA,
+                              uint8_t* bufB, uint8_t* r1, uint8_t* r2)
+{
+    const MultiHdr h = a.multi[it];
+    bool ok = true;
+    for (uint32_t p = 0; p < h.n_paths; p++)
+        ok &= (h.off[p] != ~0ULL) && h.len[p] <= kNwMax;
+    if (!ok) {
+        atomicOr(a.err, 256u);
+        return;
+    }
+    // alignPair for two, alignMulti's left fold for more
+    uint32_t lc = nw_consensus(a.pool + h.off[0], h.len[0], a.pool + h.off[1], h.len[1], mat, bufA);
+    uint8_t* cur = bufA;
+    uint8_t* nxt = bufB;
+    for (uint32_t p = 2; p < h.n_paths && ok; p++) {
+        if (lc > kNwMax) {
+            ok = false;
+            break;
+        }
+        lc = nw_consensus(cur, lc, a.pool + h.off[p], h.len[p], mat, nxt);
+        uint8_t* t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    if (!ok) {
+        atomicOr(a.err, 256u);
+        return;
+    }
+    const Gap g = a.gaps[h.gap];
+    const Flank f = flank_of(a, h.gap);
+    const uint32_t l1 = f.le - f.ls, l2 = f.re - f.rs;
+    const uint8_t* s = a.seq + a.off[g.contig];
+    for (uint32_t i = 0; i < l1; i++)
+        r1[i] = up(s[f.ls + i]);
+    for (uint32_t i = 0; i < l2; i++)
+        r2[i] = comp_base(up(s[f.re - 1 - i]));
+    write_merged(a, h.gap, r1, l1, r2, l2, h.sp, h.gp, cur, lc);
+}
+
+__global__ __launch_bounds__(64) void sealer_consensus(CArgs a)
+{
+    __shared__ uint32_t item;
+    __shared__ uint8_t r1[64], r2[64];
+    const uint32_t wid = blockIdx.x, lane = threadIdx.x;
+    const uint32_t n_multi = min(a.queue[2], a.multi_cap);
+    // per worker: three score matrices, then two consensus buffers
+    const uint64_t mat_words = 3ull * (kNwMax + 1) * (kNwMax + 1);
+    const uint64_t stride = mat_words + 2 * (2 * kNwMax + 64) / 4 + 64;
+    int32_t* mat = a.nw + (uint64_t)wid * stride;
+    uint8_t* bufA = (uint8_t*)(mat + mat_words);
+    uint8_t* bufB = bufA + 2 * kNwMax + 64;
+    for (;;) {
+        if (lane == 0)
+            item = atomicAdd(&a.queue[3], 1u);
+        __syncthreads();
+        const uint32_t it = item;
+        __syncthreads();
+        if (it >= n_multi)
+            break;
+        if (lane == 0)
+            consensus_one(a, it, mat, bufA, bufB, r1, r2);
+    }
+}
+
+// --------------------------------------------------------------- splicing
+constexpr int kApplyThreads = 256;
+
+__global__ __launch_bounds__(kApplyThreads) void apply_fills(CArgs a, uint64_t slot_cap_unused)
+{
+    const uint32_t cid = blockIdx.x, tid = threadIdx.x;
+    if (a.dropped[cid])
+        return;
+    const uint32_t len = a.len_cur[cid];
+    const uint8_t* src = a.seq + a.off[cid];
+    uint8_t* dst = a.out + a.off[cid];
+    const uint32_t cap = (uint32_t)(a.off[cid + 1] - a.off[cid]);
+    const uint32_t n = a.n_gaps[cid], base = a.gap_off[cid];
+    // current string = src[0..P) + dst[sb..cap): the suffix grows leftwards
+    uint32_t P = len, sb = cap;
+    bool overflow = false;
+    for (uint32_t ii = n; ii-- > 0;) {
+        const uint32_t gi = base + ii;
+        const uint32_t fl = a.fill_len[gi];
+        if (!fl)
+            continue;
+        const Flank f = flank_of(a, gi);
+        const uint32_t pos = f.ls;
+        const uint32_t size = P + (cap - sb);
+        if (pos > size)
+            continue; // std::out_of_range in the reference
+        uint32_t cnt = f.re - f.ls;
+        if (cnt > size - pos)
+            cnt = size - pos;
+        // pos < P always (flanks lie left of everything spliced so far)
+        if (pos + cnt >= P) {
+            sb += pos + cnt - P; // the replaced range eats into the suffix
+        } else {
+            const uint32_t keep = P - (pos + cnt);
+            if (sb < keep + fl + pos) {
+                overflow = true;
+                break;
+            }
+            sb -= keep;
+            for (uint32_t i = tid; i < keep; i += kApplyThreads)
+                dst[sb + i] = src[pos + cnt + i];
+        }
+        if (sb < fl + pos) {
+            overflow = true;
+            break;
+        }
+        sb -= fl;
+        const uint8_t* fill = a.pool + a.fill_off[gi];
+        for (uint32_t i = tid; i < fl; i += kApplyThreads)
+            dst[sb + i] = fill[i];
+        P = pos;
+    }
+    if (overflow) {
+        if (tid == 0)
+            atomicOr(a.err, 512u);
+        return;
+    }
+    __syncthreads();
+    // result = src[0..P) + suffix; move the suffix down to P tile by tile (it only moves left)
+    const uint32_t ns = cap - sb;
+    if (sb != P) {
+        for (uint32_t t0 = 0; t0 < ns; t0 += kApplyThreads * 16) {
+            uint8_t v[16];
+            uint32_t cnt = 0;
+            for (uint32_t q = 0; q < 16; q++) {
+                const uint32_t i = t0 + q * kApplyThreads + tid;
+                if (i < ns) {
+                    v[q] = dst[sb + i];
+                    cnt = q + 1;
+                }
+            }
+            __syncthreads();
+            for (uint32_t q = 0; q < cnt; q++)
+                dst[P + t0 + q * kApplyThreads + tid] = v[q];
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < P; i += kApplyThreads)
+        dst[i] = src[i];
+    if (tid == 0)
+        a.len_next[cid] = P + ns;
+}
+
+// ------------------------------------------------------------------ host side
+static CState* cstate(gp_job* job) { return (CState*)job->bc->c_state; }
+
+int stage_c_prepare(gp_job* job)
+{
+    if (!job->prm.run_sealer)
+        return GP_OK;
+    const gp_params& p = job->prm;
+    if (p.sealer_max_paths > kMaxPathsDev - 2 || p.sealer_max_cost > kVertCap - 8 ||
+        p.sealer_max_gap + 2 * p.k[0] - p.k[p.n_k - 1] + 2 > kPathCap) {
+        set_error("Sealer limits beyond device arenas: max_paths <= 14, max_cost <= 131064");
+        return GP_ERR_UNSUPPORTED;
+    }
+    CState* c = new (std::nothrow) CState();
+    if (!c)
+        return GP_ERR_OOM;
+    job->bc->c_state = c;
+    const uint32_t n = job->n_contigs;
+    c->h_gap_off.resize((size_t)n + 1);
+    uint64_t g = 0, total_len = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        c->h_gap_off[i] = (uint32_t)g;
+        uint64_t cap = job->bc->h_off[i + 1] - job->bc->h_off[i];
+        g += cap / 4 + 64;
+        total_len += cap;
+    }
+    if (g >= (1ull << 31)) {
+        set_error("too many potential gaps in one job");
+        return GP_ERR_UNSUPPORTED;
+    }
+    c->h_gap_off[n] = (uint32_t)g;
+    c->gap_cap = (uint32_t)g;
+    uint32_t tb = 10;
+    while ((1ull << tb) < 2 * g)
+        tb++;
+    c->table_bits = tb;
+    c->multi_cap = (uint32_t)std::min<uint64_t>(g, 1u << 20);
+    c->pool_cap = 2 * total_len + (16ull << 20);
+    int rc;
+    if ((rc = c->gaps.alloc(g)) != GP_OK || (rc = c->gap_off.alloc((size_t)n + 1)) != GP_OK ||
+        (rc = c->n_gaps.alloc(n)) != GP_OK || (rc = c->pair_last.alloc(g)) != GP_OK ||
+        (rc = c->closed_at.alloc(g)) != GP_OK || (rc = c->fill_off.alloc(g)) != GP_OK ||
+        (rc = c->fill_len.alloc(g)) != GP_OK || (rc = c->table_left.alloc(1ull << tb)) != GP_OK ||
+        (rc = c->table_pair.alloc(1ull << tb)) != GP_OK || (rc = c->work.alloc(g)) != GP_OK ||
+        (rc = c->queue.alloc(8)) != GP_OK || (rc = c->pool.alloc(c->pool_cap)) != GP_OK ||
+        (rc = c->pool_head.alloc(1)) != GP_OK || (rc = c->multi.alloc(c->multi_cap)) != GP_OK ||
+        (rc = c->slots.alloc((uint64_t)kWorkers * kSlots)) != GP_OK ||
+        (rc = c->verts.alloc((uint64_t)kWorkers * kVertCap)) != GP_OK ||
+        (rc = c->edges.alloc((uint64_t)kWorkers * kEdgeCap)) != GP_OK ||
+        (rc = c->scratch.alloc((uint64_t)kWorkers * kScratchWords)) != GP_OK ||
+        (rc = c->nw.alloc((uint64_t)kNwWorkers *
+                          (3ull * (kNwMax + 1) * (kNwMax + 1) + 2 * (2 * kNwMax + 64) / 4 + 64))) != GP_OK ||
+        (rc = c->epoch.alloc(kWorkers)) != GP_OK)
+        return rc;
+    GP_HIP(hipMemcpy(c->gap_off.p, c->h_gap_off.data(), (n + 1) * sizeof(uint32_t),
+                     hipMemcpyHostToDevice));
+    GP_HIP(hipMemset(c->slots.p, 0, (uint64_t)kWorkers * kSlots * sizeof(uint32_t)));
+    GP_HIP(hipMemset(c->epoch.p, 0, kWorkers * sizeof(uint32_t)));
+    return GP_OK;
+}
+
+void stage_c_release(gp_job* job)
+{
+    if (job->bc && job->bc->c_state) {
+        delete (CState*)job->bc->c_state;
+        job->bc->c_state = nullptr;
+    }
+}
+
+int stage_c_run(gp_job* job)
+{
+    StageBC* b = job->bc;
+    CState* c = cstate(job);
+    const gp_params& p = job->prm;
+    if (!c || job->n_contigs == 0)
+        return GP_OK;
+    hipStream_t s = job->ctx->stream;
+    CArgs a{};
+    a.seq = b->seq[b->cur].p;
+    a.out = b->seq[b->cur ^ 1].p;
+    a.off = b->off.p;
+    a.len_cur = b->len[b->cur].p;
+    a.len_next = b->len[b->cur ^ 1].p;
+    a.dropped = b->dropped.p;
+    a.contig_batch = b->contig_batch.p;
+    a.bf = job->d_bf.p;
+    a.n_contigs = job->n_contigs;
+    a.n_k = p.n_k;
+    a.hash_num = p.hash_num;
+    a.bf_words = (uint32_t)(p.bf_bytes / 4);
+    a.bf_mod = make_fastmod(p.bf_bytes * 8);
+    a.flank_len = p.k[0]; // -L$(firstword K)
+    a.max_gap = p.sealer_max_gap;
+    a.max_paths = p.sealer_max_paths;
+    a.max_branches = p.sealer_max_branches;
+    a.max_cost = p.sealer_max_cost;
+    a.gaps = c->gaps.p;
+    a.gap_off = c->gap_off.p;
+    a.n_gaps = c->n_gaps.p;
+    a.pair_last = c->pair_last.p;
+    a.closed_at = c->closed_at.p;
+    a.fill_off = c->fill_off.p;
+    a.fill_len = c->fill_len.p;
+    a.table_left = c->table_left.p;
+    a.table_pair = c->table_pair.p;
+    a.table_bits = c->table_bits;
+    a.work = c->work.p;
+    a.queue = c->queue.p;
+    a.pool = c->pool.p;
+    a.pool_head = c->pool_head.p;
+    a.pool_cap = c->pool_cap;
+    a.multi = c->multi.p;
+    a.multi_cap = c->multi_cap;
+    a.slots = c->slots.p;
+    a.verts = c->verts.p;
+    a.edges = c->edges.p;
+    a.scratch = c->scratch.p;
+    a.nw = c->nw.p;
+    a.epoch = c->epoch.p;
+    a.err = b->err.p;
+    a.stats = b->stats.p;
+
+    GP_HIP(hipMemsetAsync(c->queue.p, 0, 8 * sizeof(uint32_t), s));
+    GP_HIP(hipMemsetAsync(c->pool_head.p, 0, sizeof(unsigned long long), s));
+    GP_HIP(hipMemsetAsync(c->table_left.p, 0, (1ull << c->table_bits) * sizeof(uint32_t), s));
+    GP_HIP(hipMemsetAsync(c->table_pair.p, 0, (1ull << c->table_bits) * sizeof(uint32_t), s));
+    GP_HIP(hipMemsetAsync(c->pair_last.p, 0, (uint64_t)c->gap_cap * sizeof(uint32_t), s));
+    int rc = job->t_bfs.begin(s, job->n_contigs);
+    if (rc != GP_OK)
+        return rc;
+    hipLaunchKernelGGL(find_gaps, dim3(job->n_contigs), dim3(kGapThreads), 0, s, a);
+    hipLaunchKernelGGL(prep_gaps, dim3(job->n_contigs), dim3(256), 0, s, a);
+    for (uint32_t ki = 0; ki < p.n_k; ki++) {
+        a.ki = ki;
+        a.k = p.k[ki];
+        // queue heads back to 0, counts stay
+        GP_HIP(hipMemsetAsync(c->queue.p + 1, 0, sizeof(uint32_t), s));
+        GP_HIP(hipMemsetAsync(c->queue.p + 2, 0, 2 * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(sealer_connect, dim3(kWorkers), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(sealer_consensus, dim3(kNwWorkers), dim3(64), 0, s, a);
+    }
+    hipLaunchKernelGGL(apply_fills, dim3(job->n_contigs), dim3(kApplyThreads), 0, s, a,
+                       (uint64_t)0);
+    GP_HIP(hipGetLastError());
+    if ((rc = job->t_bfs.end(s)) != GP_OK)
+        return rc;
+    b->cur ^= 1;
+    return GP_OK;
+}
+
+} // namespace gp

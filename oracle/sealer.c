@@ -654,8 +654,9 @@ static char* nw_consensus(const char* A, size_t la, const char* B, size_t lb, un
  * returns the merged sequence (malloc'd), else NULL; *why = PathSearchResult or
  * -1 for "no start/goal k-mer". */
 static char* connect_pairs(graph_t* g, const char* r1, size_t l1, const char* r2, size_t l2,
-                           const gpo_sealer_params* p, int* why)
+                           const gpo_sealer_params* p, int* why, unsigned* n_paths)
 {
+    *n_paths = 0;
     const unsigned k = g->k;
     *why = R_NO_PATH;
     if (l1 < k || l2 < k)
@@ -699,6 +700,7 @@ static char* connect_pairs(graph_t* g, const char* r1, size_t l1, const char* r2
     if (rc == R_FOUND) {
         /* connecting sequences */
         uint32_t np = S.found.n;
+        *n_paths = np;
         char** conn = (char**)malloc(np * sizeof(char*));
         for (uint32_t i = 0; i < np; i++) {
             const path_t* P = &S.found.p[i];
@@ -853,7 +855,13 @@ size_t gpo_sealer_record(const char* seq, size_t len, unsigned nk, const unsigne
             if (!gaps[i].alive)
                 continue;
             int why;
-            char* m = connect_pairs(&g, gaps[i].r1, gaps[i].l1, gaps[i].r2, gaps[i].l2, p, &why);
+            unsigned n_paths;
+            char* m = connect_pairs(&g, gaps[i].r1, gaps[i].l1, gaps[i].r2, gaps[i].l2, p, &why,
+                                    &n_paths);
+            if (st && n_paths == 1)
+                st->unique_path++;
+            if (st && n_paths > 1)
+                st->multiple_paths++;
             if (st) {
                 if (why == -1 || (why == R_NO_PATH && (gaps[i].l1 < g.k || gaps[i].l2 < g.k)))
                     st->no_start_goal++;
