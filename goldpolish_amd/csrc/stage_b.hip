@@ -1466,7 +1466,7 @@ int stage_bc_prepare(gp_job* job)
                      (job->n_batches + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
     GP_HIP(hipMemset(b->err.p, 0, 4 * sizeof(uint32_t)));
     GP_HIP(hipMemset(b->stats.p, 0, 16 * sizeof(unsigned long long)));
-    return GP_OK;
+    return stage_c_prepare(job);
 }
 
 void stage_bc_release(gp_job* job)
