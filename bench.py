@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- polished Mbp/s of the GoldPolish per-batch k-mer correction path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched
+under torch.distributed.run with one rank per GPU.  A step = one pass of the whole hot path
+(filter build -> ntEdit cascade + guard -> mask -> Sealer -> upper) over the rank's batches,
+with reads + contigs already resident in HBM; at N > 1 the step ends with the gather of the
+polished sequences on rank 0 (RCCL).  W untimed warm-up steps, then exactly K timed steps
+between barrier + synchronize; max over ranks; rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): one synthetic 10 Mbp contig (41 % GC, 1 % draft error)
++ 30x ONT-like reads (6 % error), k = 32 only, bsize = 1, per GPU (weak scaling: every rank
+polishes its own 10 Mbp contig).  `--workload goldenpath` instead cuts the same 10 Mbp into
+25 kbp contigs (the regime GoldPolish's fixed 10 MiB / 512 KiB filters are sized for) and runs
+the full k cascade; its figures are reported under "aux" by default.
+"""
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def make_workload(kind, seed):
+    from goldpolish_amd import synth
+    if kind == "config2":
+        return synth.make_workload([10_000_000], 30, seed=seed), [32]
+    if kind == "goldenpath":
+        return synth.make_workload([25_000] * 400, 30, seed=seed), [32, 28, 24, 20]
+    if kind == "tiny":
+        return synth.make_workload([200_000], 30, seed=seed), [32]
+    raise SystemExit(f"unknown workload {kind}")
+
+
+def algorithmic_bytes_per_bp(n_k, hash_num, coverage):
+    """stage A C*(1 + |K|*2H), stage B scan 6*|K|, mask+upper 2 B/bp."""
+    return coverage * (1 + n_k * 2 * hash_num) + 6 * n_k + 2
+
+
+def gather_to_rank0(seqs, rank, world, backend):
+    """Variable-length gather of the polished contigs on rank 0 (no other collective)."""
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    flat = np.frombuffer(b"".join(s for s in seqs if s is not None), dtype=np.uint8)
+    lens = torch.tensor([len(s) if s is not None else 0 for s in seqs], dtype=torch.int64, device=dev)
+    meta = torch.tensor([flat.size, lens.numel()], dtype=torch.int64, device=dev)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    payload = torch.from_numpy(flat.copy()).to(dev)
+    if rank == 0:
+        out = [seqs]
+        reqs, bufs = [], []
+        for r in range(1, world):
+            nb, nl = int(metas[r][0]), int(metas[r][1])
+            b = torch.empty(nb, dtype=torch.uint8, device=dev)
+            l = torch.empty(nl, dtype=torch.int64, device=dev)
+            reqs += [dist.irecv(l, src=r), dist.irecv(b, src=r)]
+            bufs.append((l, b))
+        for q in reqs:
+            q.wait()
+        for l, b in bufs:
+            l = l.cpu().numpy()
+            b = b.cpu().numpy().tobytes()
+            at, part = 0, []
+            for n in l:
+                part.append(b[at:at + int(n)])
+                at += int(n)
+            out.append(part)
+        return out
+    reqs = [dist.isend(lens, dst=0), dist.isend(payload, dst=0)]
+    for q in reqs:
+        q.wait()
+    return None
+
+
+def cpu_baseline(seed):
+    """The oracle (a scalar C port of the reference path) timed on this box's host cores, on a
+    bounded sample of the same kind of workload."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import subprocess
+    import oracle_lib
+    from goldpolish_amd import synth
+    so = ROOT / "oracle" / "libgpo.so"
+    if not so.exists():
+        subprocess.check_call(["make", "-C", str(ROOT / "oracle"), "libgpo.so"])
+    O = oracle_lib.Oracle(str(so))
+    sample_bp = 1_000_000
+    w = synth.make_workload([sample_bp], 30, seed=seed + 1000)
+    params = O.batch_params(k_values=(32,))
+    t = time.perf_counter()
+    O.polish_batch(w.names, [w.contig(0)], [w.reads_of(0)], [int(w.kmer_threshold[0])], params)
+    dt = time.perf_counter() - t
+    return {
+        "value": round(w.total_bp / dt / 1e6, 4), "unit": "Mbp/s", "cores": 1, "kind": "port",
+        "sample": f"one {sample_bp} bp contig + 30x reads, k=32, whole path, {dt:.1f} s of the "
+                  "single-threaded C oracle",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="config2")
+    ap.add_argument("--no-aux", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the polishing core has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    from goldpolish_amd import core
+
+    def run(kind, steps, warmup, want_roofline):
+        w, ks = make_workload(kind, seed=2 + rank)
+        params = core.default_params(k_values=ks)
+        ctx = core.Context(local_rank)
+        job = core.Job.from_workload(ctx, params, w)
+
+        def step():
+            job.polish(sync=True)
+            if world > 1:
+                gather_to_rank0(job.sequences(), rank, world, "nccl")
+
+        for _ in range(warmup):
+            step()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        res = {"bp_per_rank": w.total_bp, "dt": dt, "steps": steps, "counters": job.counters(),
+               "coverage": float(w.read_off[-1]) / max(w.total_bp, 1), "n_k": len(ks),
+               "n_contigs": w.n_contigs}
+        if want_roofline:
+            kt = {}
+            for name in ("cbf_first_pass", "cbf_round", "ntedit_walk", "mask", "sealer_bfs", "upper"):
+                ms, n, units = job.kernel_time(name)
+                kt[name] = {"ms": ms, "launches": n, "units": units}
+            res["kernels"] = kt
+        job.close()
+        ctx.close()
+        return res
+
+    main_res = run(args.workload, args.steps, args.warmup, True)
+    total_bp = main_res["bp_per_rank"] * world
+    value = total_bp * args.steps / main_res["dt"] / 1e6
+    line = {
+        "metric": "polished Mbp/sec (whole node), k={32,28,24,20}, 1/2/4/8 MI355X",
+        "value": round(value, 3), "unit": "Mbp/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(main_res["dt"] / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": ("BASELINE.json configs[1]: one synthetic 10 Mbp contig + 30x ONT-error "
+                         "reads per GPU, k=32 only, bsize=1" if args.workload == "config2"
+                         else args.workload),
+            "contigs_per_gpu": main_res["n_contigs"], "bp_per_gpu": main_res["bp_per_rank"],
+            "read_coverage": round(main_res["coverage"], 2), "k": "32" if main_res["n_k"] == 1 else "32,28,24,20",
+            "parallelism": f"batches sharded over {world} GPU(s), gather to rank 0",
+        },
+    }
+    if rank == 0:
+        # roofline of the dominant kernel: stage A's streaming pass (cbf_first_pass).  One
+        # launch covers `units` (read base, k) pairs; SURVEY 8d prices each at 1 B of sequence
+        # + 2H B of counter traffic.
+        k = main_res["kernels"]
+        dom = max(k, key=lambda n: k[n]["ms"])
+        fp = k["cbf_first_pass"]
+        H = 4
+        if fp["launches"]:
+            bytes_per_launch = (1 + 2 * H) * fp["units"] / fp["launches"]
+            avg_s = fp["ms"] / fp["launches"] / 1e3
+            achieved = bytes_per_launch / avg_s / 1e9
+        else:
+            bytes_per_launch, achieved = 0, 0.0
+        line["roofline"] = {
+            "bound": "hbm", "kernel": "cbf_first_pass", "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": None, "alg_bytes_per_launch": int(bytes_per_launch),
+            "avg_launch_ms": round(fp["ms"] / max(fp["launches"], 1), 4),
+            "largest_by_time": dom,
+            "whole_path_alg_GBps": round(
+                algorithmic_bytes_per_bp(main_res["n_k"], H, main_res["coverage"]) * value * 1e6 / 1e9, 2),
+            "kernel_ms_per_run": {n: round(v["ms"], 3) for n, v in k.items()},
+        }
+        line["counters"] = main_res["counters"]
+    if world == 1 and not args.no_aux and args.workload == "config2":
+        aux = run("goldenpath", max(1, min(args.steps, 3)), 1, True)
+        if rank == 0:
+            line["aux"] = {
+                "workload": "10 Mbp as 400 x 25 kbp contigs + 30x reads, k=32,28,24,20 "
+                            "(filters in their design regime: edits and gap fills happen)",
+                "value": round(aux["bp_per_rank"] * aux["steps"] / aux["dt"] / 1e6, 3),
+                "unit": "Mbp/s", "ms_per_step": round(aux["dt"] / aux["steps"] * 1e3, 2),
+                "counters": aux["counters"],
+                "kernel_ms_per_run": {n: round(v["ms"], 3) for n, v in aux["kernels"].items()},
+            }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(seed=2)
+    if rank == 0:
+        print(json.dumps(line))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,7 +123,7 @@ struct gp_job {
     // ---- stage B/C state (see stage_b.hip / stage_c.hip)
     gp::StageBC* bc = nullptr;
 
-    gp::KernelTimer t_first_pass, t_round, t_scan, t_walk, t_bfs;
+    gp::KernelTimer t_first_pass, t_round, t_scan, t_walk, t_bfs, t_mask, t_upper, t_reset;
     gp_counters counters{};
     bool filters_ready = false;
 };

@@ -58,6 +58,8 @@ struct WalkArgs {
     uint32_t max_del, jump, min_contig_len, soft_mask;
     uint32_t need_missing, need_edit, need_del; // integer forms of the float tests
     uint32_t insertion_cap;
+    const unsigned long long* bm_site; // bit (off[c] + p): k-mer at p is testable and absent
+    uint32_t* n_nodes;                 // live nodes per contig after the walk
     uint32_t* err;
     unsigned long long* stats;
 };
@@ -104,6 +106,10 @@ struct Shared {
     uint32_t char_in;
     int32_t cur_tested;
     uint32_t min_tested_ti;   // k-mers whose tail is left of this are still being skipped
+    uint32_t clean_from;      // k-mers starting at or right of this coordinate are untouched contig
+    uint32_t bit_from;        // first k-mer start the bitmap search looks at
+    uint32_t need_hash;       // the walker jumped: hash of the current k-mer must be rebuilt
+    uint32_t fast_head;       // window can be read straight from the contig at S.hi
     int32_t request;
     uint32_t nz;              // chars available in Z
     uint32_t scan_j0, scan_n; // first k-mer index / number of k-mers of the scan
@@ -123,7 +129,7 @@ struct Shared {
     uint8_t cand_sup[kMaxCand];
 };
 
-enum { REQ_DONE = 0, REQ_SCAN, REQ_SITE, REQ_NEXT };
+enum { REQ_DONE = 0, REQ_SCAN, REQ_SITE, REQ_NEXT, REQ_BITSCAN };
 
 __device__ inline uint64_t roll_f(const HashTab& t, uint64_t fh, uint8_t out, uint8_t in)
 {
@@ -487,6 +493,7 @@ __device__ void make_edit(const Ctx& c, Shared& S, uint8_t draft, Best& b)
             c.nd[S.tn].c = b.sub_base;
         changelast(ht, S.fh, S.rh, draft, b.sub_base);
         S.st_edits++;
+        S.clean_from = max(S.clean_from, tnode.type == 0 ? S.ti + 1 : S.ti);
         break;
     case 2: {
         bool skipped = false;
@@ -536,6 +543,9 @@ __device__ void make_edit(const Ctx& c, Shared& S, uint8_t draft, Best& b)
             make_insertion(c, S, S.tn, (int)S.ti, b.indel, b.indel_len);
             changelast(ht, S.fh, S.rh, draft, b.indel[0]);
             S.st_edits++;
+            S.clean_from = max(S.clean_from, S.ti); // k-mers from the draft base on are untouched
+        } else {
+            S.clean_from = c.len;
         }
         break;
     }
@@ -543,6 +553,8 @@ __device__ void make_edit(const Ctx& c, Shared& S, uint8_t draft, Best& b)
         make_deletion(c, S, S.tn, S.ti, b.indel_len);
         changelast(ht, S.fh, S.rh, draft, get_char(c, S.ti, nd_get(c, S, S.tn)));
         S.st_edits++;
+        // the base pulled in as the new last one was never looked at by the skip logic
+        S.clean_from = max(S.clean_from, S.ti + 1);
         break;
     default:
         if (c.a->soft_mask) {
@@ -756,6 +768,9 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
         S.char_in = 0;
         S.cur_tested = 0;
         S.min_tested_ti = 0;
+        S.clean_from = 0;
+        S.need_hash = 0;
+        S.fast_head = 0;
         if (hi + k - 1 < len) {
             hash_kmer(S.ht, c.seq + hi, k, S.fh, S.rh);
             S.char_in = c.seq[S.ti];
@@ -778,9 +793,22 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
         if (tid == 0 && S.request == REQ_NEXT) {
             Node tnode = nd_get(c, S, S.tn);
             const bool plain = tnode.type == 0 && tnode.e == len - 1 && S.ti <= tnode.e;
-            if (plain) {
+            const bool clean = plain && S.hn == S.tn && S.hi >= S.clean_from && a.bm_site != nullptr;
+            if (clean) {
+                // everything from the head on is untouched contig: the precomputed bitmap
+                // says where the next testable, absent k-mer starts
+                const uint32_t start = S.hi + (S.cur_tested ? 1u : 0u);
+                if (start + k > len) {
+                    S.request = REQ_DONE;
+                } else {
+                    S.bit_from = start;
+                    S.request = REQ_BITSCAN;
+                }
+            } else if (plain) {
                 // scan: current k-mer chars via the cursor, lookahead straight from the contig
-                uint32_t got = gather(c, S, S.Z, k);
+                Node hnode = nd_get(c, S, S.hn);
+                S.fast_head = (hnode.type == 0 && S.hi + k - 1 <= hnode.e) ? 1u : 0u;
+                uint32_t got = S.fast_head ? k : gather(c, S, S.Z, k);
                 if (got < k) {
                     S.request = REQ_DONE; // cannot happen while the tail is in range
                 } else {
@@ -833,9 +861,50 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
         if (req == REQ_DONE)
             break;
 
+        if (req == REQ_BITSCAN) {
+            const uint32_t from = S.bit_from, last_p = len - k;
+            const uint64_t base_bit = a.off[cid];
+            const uint64_t w_first = (base_bit + from) >> 6, w_last = (base_bit + last_p) >> 6;
+            uint32_t found = 0xFFFFFFFFu;
+            for (uint64_t w0 = w_first; w0 <= w_last && found == 0xFFFFFFFFu; w0 += kWalkThreads) {
+                const uint64_t w = w0 + tid;
+                uint32_t hit = 0xFFFFFFFFu;
+                if (w <= w_last) {
+                    unsigned long long bits = a.bm_site[w];
+                    if (w == w_first)
+                        bits &= ~0ULL << ((base_bit + from) & 63);
+                    if (w == w_last && ((base_bit + last_p) & 63) != 63)
+                        bits &= (1ULL << (((base_bit + last_p) & 63) + 1)) - 1;
+                    if (bits)
+                        hit = (uint32_t)((w << 6) + (uint64_t)(__ffsll((long long)bits) - 1) - base_bit);
+                }
+                found = block_min(S, hit);
+            }
+            if (tid == 0) {
+                if (found == 0xFFFFFFFFu) {
+                    S.st_scan += last_p - from + 1;
+                    S.request = REQ_DONE; // nothing absent up to the end of the contig
+                } else {
+                    S.st_scan += found - from + 1;
+                    S.hi = found;
+                    S.ti = found + k - 1;
+                    S.char_in = c.seq[S.ti];
+                    S.cur_tested = 1;
+                    S.need_hash = 1;
+                    S.min_tested_ti = 0;
+                    S.request = REQ_SITE;
+                }
+            }
+            __syncthreads();
+            continue;
+        }
+
         if (req == REQ_SCAN) {
             // lookahead chars Z[k..nz) come straight from the (untouched) contig
             const uint32_t j0 = S.scan_j0, n = S.scan_n, ti0 = S.ti;
+            if (S.fast_head)
+                for (uint32_t i = tid; i < k; i += kWalkThreads)
+                    S.Z[i] = c.seq[S.hi + i];
             for (uint32_t i = k + tid; i < S.nz; i += kWalkThreads)
                 S.Z[i] = c.seq[ti0 + 1 + (i - k)];
             __syncthreads();
@@ -862,8 +931,15 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
                 for (uint32_t i = k; i < k + dest && i < S.nz; i++)
                     if (!is_accepted_u(S.Z[i]))
                         S.min_tested_ti = max(S.min_tested_ti, ti0 + 1 + (i - k) + k);
-                for (uint32_t s = 0; s < dest; s++)
-                    increment(c, S, S.hi, S.hn);
+                {
+                    Node hnode = nd_get(c, S, S.hn);
+                    if (hnode.type == 0 && S.hi + dest <= hnode.e) {
+                        S.hi += dest;
+                    } else {
+                        for (uint32_t s = 0; s < dest; s++)
+                            increment(c, S, S.hi, S.hn);
+                    }
+                }
                 S.ti = ti0 + dest;
                 // tn stays: the tail never leaves the final node
                 S.fh = S.scan_fh[dest - j0];
@@ -881,11 +957,33 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
 
         // ------------------------------------------------------------ REQ_SITE
         if (tid == 0) {
-            S.nz = gather(c, S, S.Z, 2 * k + 12);
+            const uint32_t want = 2 * k + 12;
+            Node hnode = nd_get(c, S, S.hn);
+            const bool in_final = hnode.type == 0 && hnode.e == len - 1 && S.hi <= hnode.e;
+            const bool inside = hnode.type == 0 && S.hi + want - 1 <= hnode.e;
+            if (in_final || inside) {
+                S.fast_head = 1;
+                S.nz = min(want, hnode.e - S.hi + 1);
+            } else {
+                S.fast_head = 0;
+                S.nz = gather(c, S, S.Z, want);
+            }
             S.draft = to_upper((uint8_t)S.char_in);
             S.best_key = 0;
         }
         __syncthreads();
+        if (S.fast_head) {
+            for (uint32_t i = tid; i < S.nz; i += kWalkThreads)
+                S.Z[i] = c.seq[S.hi + i];
+            __syncthreads();
+        }
+        if (S.need_hash) {
+            if (tid == 0) {
+                hash_kmer(S.ht, S.Z, k, S.fh, S.rh);
+                S.need_hash = 0;
+            }
+            __syncthreads();
+        }
         {
             // confirm: k more k-mers, every jump-th one probed
             uint32_t miss = 0, bad = 0;
@@ -1042,36 +1140,149 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
         __syncthreads();
     }
 
-    // ---- write the edited contig: nodes in order, every thread copies a slice
+    // ---- lay the edited contig out: every live node learns where its bytes go
+    // (materialize_kernel then copies with the whole chip)
     __syncthreads();
-    uint8_t* out = a.out + a.off[cid];
-    uint32_t o = 0;
-    const uint32_t nn = S.nn;
-    for (uint32_t ni = 0; ni < nn; ni++) {
-        const Node n = c.nd[ni];
-        if (n.type == -1)
-            break;
-        if (n.type == 0) {
-            uint32_t s = n.s, cnt = n.e - n.s + 1;
-            if (s <= len) {
-                if (cnt > len - s)
-                    cnt = len - s;
-                for (uint32_t i = tid; i < cnt; i += kWalkThreads)
-                    out[o + i] = c.seq[s + i];
-                o += cnt;
-            }
-        } else {
-            if (tid == 0)
-                out[o] = (uint8_t)n.c;
-            o++;
-        }
-    }
     if (tid == 0) {
+        uint32_t o = 0, live = 0;
+        const uint32_t nn = S.nn;
+        for (uint32_t ni = 0; ni < nn; ni++) {
+            Node n = c.nd[ni];
+            if (n.type == -1)
+                break;
+            live++;
+            if (n.type == 0) {
+                uint32_t cnt = 0;
+                if (n.s <= len) {
+                    cnt = n.e - n.s + 1;
+                    if (cnt > len - n.s)
+                        cnt = len - n.s;
+                }
+                c.nd[ni].c = o; // output offset of a position run
+                c.nd[ni].e = n.s + cnt; // exclusive end, clamped like substr()
+                o += cnt;
+            } else {
+                c.nd[ni].s = o; // output offset of an inserted base
+                o++;
+            }
+        }
+        a.n_nodes[cid] = live;
         a.len_next[cid] = o;
         atomicAdd(&a.stats[0], S.st_scan);
         atomicAdd(&a.stats[1], S.st_sites);
         atomicAdd(&a.stats[2], S.st_probes);
         atomicAdd(&a.stats[3], S.st_edits);
+    }
+}
+
+constexpr int kMatTile = 4096;
+
+// copies output tile blockIdx.x of contig blockIdx.y
+__global__ __launch_bounds__(256) void materialize_kernel(const uint8_t* seq, uint8_t* out,
+                                                          const uint64_t* off,
+                                                          const uint32_t* len_next,
+                                                          const uint8_t* dropped, const Node* nodes,
+                                                          const uint64_t* node_off,
+                                                          const uint32_t* n_nodes,
+                                                          const uint32_t* tile_contig,
+                                                          const uint32_t* tile_first)
+{
+    const uint32_t cid = tile_contig[blockIdx.x];
+    if (dropped[cid])
+        return;
+    const uint32_t total = len_next[cid];
+    const uint32_t t0 = (blockIdx.x - tile_first[cid]) * kMatTile;
+    if (t0 >= total)
+        return;
+    const uint32_t t1 = min(total, t0 + kMatTile);
+    const Node* nd = nodes + node_off[cid];
+    const uint32_t nn = n_nodes[cid];
+    const uint8_t* src = seq + off[cid];
+    uint8_t* dst = out + off[cid];
+    // last node whose output offset is <= t0
+    uint32_t lo = 0, hi = nn;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const Node m = nd[mid];
+        const uint32_t o = m.type == 0 ? m.c : m.s;
+        if (o <= t0)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    for (uint32_t ni = lo; ni < nn; ni++) {
+        const Node n = nd[ni];
+        const uint32_t o = n.type == 0 ? n.c : n.s;
+        if (o >= t1)
+            break;
+        if (n.type == 0) {
+            const uint32_t cnt = n.e - n.s;
+            const uint32_t a0 = max(o, t0), a1 = min(o + cnt, t1);
+            for (uint32_t i = a0 + threadIdx.x; i < a1; i += blockDim.x)
+                dst[i] = src[n.s + (i - o)];
+        } else if (threadIdx.x == 0) {
+            dst[o] = (uint8_t)n.c;
+        }
+    }
+}
+
+// bit (off[c] + p) of bm_site: the k-mer starting at p has only accepted bases and is not
+// in the filter.  One workgroup covers 1024 consecutive slot positions (4 x 256 lanes; a
+// wave's ballot is one 64-bit word of the bitmap).
+constexpr int kScanTile = 1024;
+
+__global__ __launch_bounds__(256) void ntedit_scan(WalkArgs a, uint32_t n_contigs,
+                                                   unsigned long long* bm_site)
+{
+    __shared__ uint8_t z[kScanTile + kMaxK];
+    __shared__ HashTab ht;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kScanTile;
+    // contig whose slot holds tile0
+    uint32_t lo = 0, hi = n_contigs;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.off[mid] <= tile0)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint32_t cid = lo;
+    const uint32_t len = a.dropped[cid] ? 0u : a.len_cur[cid];
+    const uint64_t p0 = tile0 - a.off[cid];
+    const uint32_t k = a.k;
+    if (len < a.min_contig_len || p0 + k > len)
+        return; // the walker never looks here
+    if (threadIdx.x < 5) {
+        const uint32_t code = threadIdx.x;
+        const uint64_t s = code < 4 ? seed_of_code(code) : 0ULL;
+        ht.f[code] = s;
+        ht.r[code] = s;
+        ht.fk[code] = sroln(s, k);
+        ht.rk[code] = sroln(s, k);
+    }
+    const uint8_t* seq = a.seq + a.off[cid];
+    for (uint32_t i = threadIdx.x; i < kScanTile + k - 1; i += 256)
+        z[i] = (p0 + i < len) ? seq[p0 + i] : (uint8_t)'N';
+    __syncthreads();
+    const uint32_t* bf = a.bf + ((uint64_t)a.contig_batch[cid] * a.n_k + a.ki) * a.bf_words;
+    for (uint32_t sub = 0; sub < kScanTile / 256; sub++) {
+        const uint32_t i = sub * 256 + threadIdx.x;
+        const uint64_t p = p0 + i;
+        bool site = false;
+        if (p + k <= len) {
+            uint64_t f = 0, r = 0;
+            bool ok = true;
+            for (uint32_t j = 0; j < k; j++) {
+                const uint8_t cf = z[i + j];
+                ok &= is_accepted_u(cf);
+                f = srol1(f) ^ ht.f[fcode(cf)];
+                r = srol1(r) ^ ht.r[rcode(z[i + k - 1 - j])];
+            }
+            site = ok && !bf_contains(a, bf, f + r);
+        }
+        const unsigned long long word = __ballot(site);
+        if ((threadIdx.x & 63) == 0)
+            bm_site[(tile0 + i) >> 6] = word;
     }
 }
 
@@ -1427,7 +1638,7 @@ int stage_bc_prepare(gp_job* job)
         b->h_node_off[c] = noff;
         // room for net insertions (ntEdit) and gap fills (Sealer)
         uint64_t cap = len + len / 2 + 4096;
-        cap = (cap + 63) & ~63ull;
+        cap = (cap + 1023) & ~1023ull; // slots start on ntedit_scan tile boundaries
         off += cap;
         noff += len + 256;
     }
@@ -1448,8 +1659,28 @@ int stage_bc_prepare(gp_job* job)
         (rc = b->in_len.alloc(n)) != GP_OK || (rc = b->in_off.alloc((size_t)n + 1)) != GP_OK ||
         (rc = b->batch_begin.alloc((size_t)job->n_batches + 1)) != GP_OK ||
         (rc = b->err.alloc(4)) != GP_OK || (rc = b->stats.alloc(16)) != GP_OK ||
-        (rc = b->batch_skip.alloc(job->n_batches)) != GP_OK)
+        (rc = b->batch_skip.alloc(job->n_batches)) != GP_OK ||
+        (rc = b->bm_site.alloc(off / 64 + 64)) != GP_OK || (rc = b->n_nodes.alloc(n)) != GP_OK ||
+        (rc = b->tile_first.alloc((size_t)n + 1)) != GP_OK)
         return rc;
+    {
+        std::vector<uint32_t> tf((size_t)n + 1), tc;
+        for (uint32_t c = 0; c < n; c++) {
+            tf[c] = (uint32_t)tc.size();
+            uint64_t cap = b->h_off[c + 1] - b->h_off[c];
+            for (uint64_t t = 0; t < (cap + kMatTile - 1) / kMatTile; t++)
+                tc.push_back(c);
+        }
+        tf[n] = (uint32_t)tc.size();
+        b->n_tiles = (uint32_t)tc.size();
+        if ((rc = b->tile_contig.alloc(tc.size())) != GP_OK)
+            return rc;
+        if (!tc.empty())
+            GP_HIP(hipMemcpy(b->tile_contig.p, tc.data(), tc.size() * sizeof(uint32_t),
+                             hipMemcpyHostToDevice));
+        GP_HIP(hipMemcpy(b->tile_first.p, tf.data(), tf.size() * sizeof(uint32_t),
+                         hipMemcpyHostToDevice));
+    }
     GP_HIP(hipMemcpy(b->off.p, b->h_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
     GP_HIP(hipMemcpy(b->node_off.p, b->h_node_off.data(), (n + 1) * sizeof(uint64_t),
                      hipMemcpyHostToDevice));
@@ -1496,6 +1727,12 @@ int stage_b_reset(gp_job* job)
     }
     job->counters.b_scan_kmers = job->counters.b_sites = job->counters.b_probes =
         job->counters.b_edits = 0;
+    job->t_walk.reset();
+    job->t_scan.reset();
+    job->t_mask.reset();
+    job->t_upper.reset();
+    job->t_bfs.reset();
+    job->t_reset.reset();
     return GP_OK;
 }
 
@@ -1514,6 +1751,11 @@ static int pull_stats(gp_job* job)
     job->counters.c_gaps = st[4];
     job->counters.c_closed = st[5];
     job->counters.c_vertex_tests = st[6];
+    int rc;
+    if ((rc = job->t_walk.collect()) != GP_OK || (rc = job->t_scan.collect()) != GP_OK ||
+        (rc = job->t_mask.collect()) != GP_OK || (rc = job->t_upper.collect()) != GP_OK ||
+        (rc = job->t_bfs.collect()) != GP_OK || (rc = job->t_reset.collect()) != GP_OK)
+        return rc;
     if (err) {
         set_error("device work buffer overflow (code " + std::to_string(err) + ")");
         return GP_ERR_STATE;
@@ -1558,11 +1800,27 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     a.insertion_cap = (uint32_t)(kf * 1.5f);
     a.err = b->err.p;
     a.stats = b->stats.p;
+    a.bm_site = b->bm_site.p;
+    a.n_nodes = b->n_nodes.p;
     hipStream_t s = job->ctx->stream;
-    int rc = job->t_walk.begin(s, job->h_contig_off[job->n_contigs]);
+    // 1. membership bitmap of the pass's input, every CU
+    int rc = job->t_scan.begin(s, b->total_slots);
     if (rc != GP_OK)
         return rc;
+    hipLaunchKernelGGL(ntedit_scan, dim3((unsigned)((b->total_slots + kScanTile - 1) / kScanTile)),
+                       dim3(256), 0, s, a, job->n_contigs, b->bm_site.p);
+    GP_HIP(hipGetLastError());
+    if ((rc = job->t_scan.end(s)) != GP_OK)
+        return rc;
+    // 2. the ordered walk, one workgroup per contig; 3. copy the edited contigs out
+    if ((rc = job->t_walk.begin(s, job->h_contig_off[job->n_contigs])) != GP_OK)
+        return rc;
     hipLaunchKernelGGL(ntedit_walk, dim3(job->n_contigs), dim3(kWalkThreads), 0, s, a);
+    hipLaunchKernelGGL(materialize_kernel, dim3(b->n_tiles), dim3(256), 0, s,
+                       (const uint8_t*)a.seq, a.out, a.off, (const uint32_t*)a.len_next,
+                       (const uint8_t*)a.dropped, (const Node*)a.nodes, a.node_off,
+                       (const uint32_t*)a.n_nodes, (const uint32_t*)b->tile_contig.p,
+                       (const uint32_t*)b->tile_first.p);
     GP_HIP(hipGetLastError());
     if ((rc = job->t_walk.end(s)) != GP_OK)
         return rc;
@@ -1596,11 +1854,16 @@ int stage_mask(gp_job* job)
     if (job->n_contigs == 0)
         return GP_OK;
     hipStream_t s = job->ctx->stream;
+    int rc = job->t_mask.begin(s, job->n_contigs);
+    if (rc != GP_OK)
+        return rc;
     hipLaunchKernelGGL(mask_kernel, dim3(job->n_contigs), dim3(kMaskThreads), 0, s,
                        (const uint8_t*)b->seq[b->cur].p, (const uint64_t*)b->off.p,
                        (const uint32_t*)b->len[b->cur].p, b->seq[b->cur ^ 1].p,
                        b->len[b->cur ^ 1].p, (const uint8_t*)b->dropped.p, job->prm.k[0]);
     GP_HIP(hipGetLastError());
+    if ((rc = job->t_mask.end(s)) != GP_OK)
+        return rc;
     b->cur ^= 1;
     return GP_OK;
 }
@@ -1611,10 +1874,15 @@ int stage_upper(gp_job* job)
     if (job->n_contigs == 0)
         return GP_OK;
     hipStream_t s = job->ctx->stream;
+    int rc0 = job->t_upper.begin(s, job->n_contigs);
+    if (rc0 != GP_OK)
+        return rc0;
     hipLaunchKernelGGL(upper_kernel, dim3(64, job->n_contigs), dim3(256), 0, s, b->seq[b->cur].p,
                        (const uint64_t*)b->off.p, (const uint32_t*)b->len[b->cur].p,
                        (const uint8_t*)b->dropped.p);
     GP_HIP(hipGetLastError());
+    if ((rc0 = job->t_upper.end(s)) != GP_OK)
+        return rc0;
     return pull_stats(job);
 }
 
