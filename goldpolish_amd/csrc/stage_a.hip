@@ -415,8 +415,33 @@ int stage_a_run(gp_job* job)
         return GP_OK;
     }
 
-    for (uint64_t w0 = 0; w0 < job->read_positions; w0 += job->window) {
-        const uint64_t w1 = std::min(job->read_positions, w0 + job->window);
+    // Window = the slice of read positions hashed per first-pass launch.  What makes the
+    // reservation rounds expensive is many waiting operations per counter, so a window
+    // takes at most `lim` positions of any one batch (hash_num * lim touches over
+    // cbf_bytes counters: a load of 1/4 at scale 1) but as many whole batches as fit.
+    // Once a filter is saturated nearly everything settles in the first pass; the
+    // window then grows again (feedback on the waiting fraction of the last window).
+    std::vector<uint64_t> batch_pos(job->n_batches + 1);
+    for (uint32_t bi = 0; bi < job->n_batches; bi++)
+        batch_pos[bi] = job->h_seg_start[job->h_batch_contig_begin[bi]];
+    batch_pos[job->n_batches] = job->read_positions;
+    const uint64_t lim0 = std::max<uint64_t>(kTile, p.cbf_bytes / (4ull * p.hash_num));
+    uint64_t scale = 1;
+    uint32_t bcur = 0;
+    for (uint64_t w0 = 0; w0 < job->read_positions;) {
+        const uint64_t lim = lim0 * scale;
+        uint64_t w1 = w0;
+        while (bcur + 1 < job->n_batches && batch_pos[bcur + 1] <= w0)
+            bcur++;
+        for (uint32_t bi = bcur; w1 < job->read_positions && w1 - w0 < job->window; bi++) {
+            const uint64_t b_end = batch_pos[bi + 1];
+            const uint64_t take = std::min({ b_end - w1, lim, job->window - (w1 - w0) });
+            w1 += take;
+            if (w1 < b_end)
+                break;
+        }
+        if (w1 == w0) // empty batches at the cursor
+            w1 = std::min(job->read_positions, w0 + 1);
         GP_HIP(hipMemsetAsync(job->d_counts.p, 0, (kMaxRounds + 2) * sizeof(uint32_t), s));
         a.win_start = w0;
         a.win_end = w1;
@@ -439,6 +464,7 @@ int stage_a_run(gp_job* job)
         // after each chunk (a launch on an empty list costs a few microseconds)
         uint32_t round = 0, chunk = 2;
         uint64_t rounds_here = 0;
+        uint32_t waiting_first = 0;
         for (;;) {
             // every round finishes at least the earliest waiting operation, so this
             // is a bug trap, not a limit anyone should meet
@@ -462,7 +488,11 @@ int stage_a_run(gp_job* job)
                 return rc;
             GP_HIP(hipMemcpyAsync(job->h_count_pinned, job->d_counts.p + round, sizeof(uint32_t),
                                   hipMemcpyDeviceToHost, s));
+            GP_HIP(hipMemcpyAsync(job->h_count_pinned + 1, job->d_counts.p, sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, s));
             GP_HIP(hipStreamSynchronize(s));
+            if (rounds_here == chunk)
+                waiting_first = job->h_count_pinned[1];
             job->counters.a_rounds += chunk;
             if (*job->h_count_pinned == 0)
                 break;
@@ -478,6 +508,16 @@ int stage_a_run(gp_job* job)
             }
             chunk = std::min<uint32_t>(chunk * 2, 64);
         }
+        {
+            const double frac = (double)waiting_first / (double)((w1 - w0) * p.n_k);
+            if (frac < 0.05)
+                scale = std::min<uint64_t>(scale * 4, 1u << 16);
+            else if (frac < 0.15)
+                scale = std::min<uint64_t>(scale * 2, 1u << 16);
+            else if (frac > 0.6 && scale > 1)
+                scale /= 2;
+        }
+        w0 = w1;
     }
     unsigned long long st[3];
     GP_HIP(hipMemcpyAsync(st, job->d_stats.p, sizeof st, hipMemcpyDeviceToHost, s));

@@ -37,6 +37,7 @@
 namespace gp {
 
 constexpr int kWalkThreads = 256;
+constexpr int kMatTile = 4096; // bytes per workgroup in the tile-parallel copy kernels
 constexpr int kMaxK = 64;
 constexpr int kZMax = 2 * kMaxK + 16 + kWalkThreads; // window chars in LDS
 constexpr int kMaxCand = 341 + 16;
@@ -1175,7 +1176,6 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
     }
 }
 
-constexpr int kMatTile = 4096;
 
 // copies output tile blockIdx.x of contig blockIdx.y
 __global__ __launch_bounds__(256) void materialize_kernel(const uint8_t* seq, uint8_t* out,
@@ -1287,23 +1287,31 @@ __global__ __launch_bounds__(256) void ntedit_scan(WalkArgs a, uint32_t n_contig
 }
 
 // ------------------------------------------------------------- small kernels
-__global__ void copy_contigs(const uint8_t* src, const uint64_t* src_off, const uint32_t* src_len,
-                             uint8_t* dst, const uint64_t* dst_off, uint32_t* dst_len,
-                             uint8_t* dropped, const uint8_t* only_if_batch_skip,
-                             const uint32_t* contig_batch)
+__global__ __launch_bounds__(256) void copy_contigs(const uint8_t* src, const uint64_t* src_off,
+                                                    const uint32_t* src_len, uint8_t* dst,
+                                                    const uint64_t* dst_off, uint32_t* dst_len,
+                                                    uint8_t* dropped,
+                                                    const uint8_t* only_if_batch_skip,
+                                                    const uint32_t* contig_batch,
+                                                    const uint32_t* tile_contig,
+                                                    const uint32_t* tile_first)
 {
-    const uint32_t cid = blockIdx.x;
+    const uint32_t cid = tile_contig[blockIdx.x];
     if (only_if_batch_skip && !only_if_batch_skip[contig_batch[cid]])
         return;
     const uint32_t n = src_len[cid];
-    const uint8_t* s = src + src_off[cid];
-    uint8_t* d = dst + dst_off[cid];
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
-        d[i] = s[i];
-    if (threadIdx.x == 0) {
+    const uint32_t t0 = (blockIdx.x - tile_first[cid]) * kMatTile;
+    if (t0 == 0 && threadIdx.x == 0) {
         dst_len[cid] = n;
         dropped[cid] = 0;
     }
+    if (t0 >= n)
+        return;
+    const uint32_t t1 = min(n, t0 + kMatTile);
+    const uint8_t* s = src + src_off[cid];
+    uint8_t* d = dst + dst_off[cid];
+    for (uint32_t i = t0 + threadIdx.x; i < t1; i += blockDim.x)
+        d[i] = s[i];
 }
 
 // scripts/goldpolish-ntedit:31-40: bytes(out)/bytes(in) truncated to 4 decimals < 0.75
@@ -1396,6 +1404,40 @@ __global__ __launch_bounds__(kMaskThreads) void mask_kernel(const uint8_t* src,
     const uint32_t len = len_cur[cid];
     const uint8_t* s = src + off[cid];
     uint8_t* d = dst + off[cid];
+    // fast path: a contig of nothing but upper-case ACGT is one run that the rule leaves
+    // alone (or, if shorter than k, lower-cases as a whole); checked with coalesced 16-byte
+    // loads (slots are 1024-byte aligned)
+    {
+        __shared__ uint32_t not_plain;
+        if (tid == 0)
+            not_plain = 0;
+        __syncthreads();
+        uint32_t bad = 0;
+        const uint32_t n16 = len / 16;
+        const uint4* s4 = reinterpret_cast<const uint4*>(s);
+        for (uint32_t i = tid; i < n16 && !bad; i += kMaskThreads) {
+            const uint4 v = s4[i];
+            const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+            for (int q = 0; q < 4; q++)
+                for (int r = 0; r < 4; r++)
+                    bad |= !cls_acgt((uint8_t)(w[q] >> (8 * r)));
+        }
+        for (uint32_t i = n16 * 16 + tid; i < len; i += kMaskThreads)
+            bad |= !cls_acgt(s[i]);
+        if (bad)
+            atomicOr(&not_plain, 1u);
+        __syncthreads();
+        if (!not_plain && len >= k && len > 0) {
+            uint4* d4 = reinterpret_cast<uint4*>(d);
+            for (uint32_t i = tid; i < n16; i += kMaskThreads)
+                d4[i] = s4[i];
+            for (uint32_t i = n16 * 16 + tid; i < len; i += kMaskThreads)
+                d[i] = s[i];
+            if (tid == 0)
+                len_next[cid] = len;
+            return;
+        }
+    }
     const uint32_t chunk = (len + kMaskThreads - 1) / kMaskThreads;
     const uint32_t b = min(len, tid * chunk), e = min(len, b + chunk);
 
@@ -1718,11 +1760,12 @@ int stage_b_reset(gp_job* job)
     GP_HIP(hipMemsetAsync(b->stats.p, 0, 16 * sizeof(unsigned long long), s));
     GP_HIP(hipMemsetAsync(b->err.p, 0, 4 * sizeof(uint32_t), s));
     if (job->n_contigs) {
-        hipLaunchKernelGGL(copy_contigs, dim3(job->n_contigs), dim3(256), 0, s,
+        hipLaunchKernelGGL(copy_contigs, dim3(b->n_tiles), dim3(256), 0, s,
                            (const uint8_t*)job->d_contigs_in.p, (const uint64_t*)b->in_off.p,
                            (const uint32_t*)b->in_len.p, b->seq[0].p, (const uint64_t*)b->off.p,
                            b->len[0].p, b->dropped.p, (const uint8_t*)nullptr,
-                           (const uint32_t*)b->contig_batch.p);
+                           (const uint32_t*)b->contig_batch.p, (const uint32_t*)b->tile_contig.p,
+                           (const uint32_t*)b->tile_first.p);
         GP_HIP(hipGetLastError());
     }
     job->counters.b_scan_kmers = job->counters.b_sites = job->counters.b_probes =
@@ -1839,11 +1882,12 @@ int stage_b_guard(gp_job* job)
                        (const uint32_t*)b->name_len.p, (const uint32_t*)b->in_len.p,
                        (const uint32_t*)b->len[b->cur].p, (const uint8_t*)b->dropped.p,
                        b->batch_skip.p);
-    hipLaunchKernelGGL(copy_contigs, dim3(job->n_contigs), dim3(256), 0, s,
+    hipLaunchKernelGGL(copy_contigs, dim3(b->n_tiles), dim3(256), 0, s,
                        (const uint8_t*)job->d_contigs_in.p, (const uint64_t*)b->in_off.p,
                        (const uint32_t*)b->in_len.p, b->seq[b->cur].p, (const uint64_t*)b->off.p,
                        b->len[b->cur].p, b->dropped.p, (const uint8_t*)b->batch_skip.p,
-                       (const uint32_t*)b->contig_batch.p);
+                       (const uint32_t*)b->contig_batch.p, (const uint32_t*)b->tile_contig.p,
+                       (const uint32_t*)b->tile_first.p);
     GP_HIP(hipGetLastError());
     return GP_OK;
 }

@@ -197,6 +197,33 @@ __global__ __launch_bounds__(kGapThreads) void find_gaps(CArgs a)
     }
     const uint32_t len = a.len_cur[cid];
     const uint8_t* s = a.seq + a.off[cid];
+    {
+        // most contigs of a clean assembly hold no gap character at all
+        __shared__ uint32_t any_gap;
+        if (tid == 0)
+            any_gap = 0;
+        __syncthreads();
+        uint32_t hit = 0;
+        const uint32_t n16 = len / 16;
+        const uint4* s4 = reinterpret_cast<const uint4*>(s);
+        for (uint32_t i = tid; i < n16 && !hit; i += kGapThreads) {
+            const uint4 v = s4[i];
+            const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+            for (int q = 0; q < 4; q++)
+                for (int r = 0; r < 4; r++)
+                    hit |= is_gap_char((uint8_t)(w[q] >> (8 * r)));
+        }
+        for (uint32_t i = n16 * 16 + tid; i < len; i += kGapThreads)
+            hit |= is_gap_char(s[i]);
+        if (hit)
+            atomicOr(&any_gap, 1u);
+        __syncthreads();
+        if (!any_gap) {
+            if (tid == 0)
+                a.n_gaps[cid] = 0;
+            return;
+        }
+    }
     const uint32_t chunk = (len + kGapThreads - 1) / kGapThreads;
     const uint32_t b = min(len, tid * chunk), e = min(len, b + chunk);
     uint32_t n = 0;
@@ -1228,8 +1255,15 @@ __global__ __launch_bounds__(kApplyThreads) void apply_fills(CArgs a, uint64_t s
             __syncthreads();
         }
     }
-    for (uint32_t i = tid; i < P; i += kApplyThreads)
-        dst[i] = src[i];
+    {
+        const uint32_t n16 = P / 16;
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        for (uint32_t i = tid; i < n16; i += kApplyThreads)
+            d4[i] = s4[i];
+        for (uint32_t i = n16 * 16 + tid; i < P; i += kApplyThreads)
+            dst[i] = src[i];
+    }
     if (tid == 0)
         a.len_next[cid] = P + ns;
 }
