@@ -1,0 +1,111 @@
+"""Full-size checks on a real MI355X (BASELINE.json configs[1]: one 10 Mbp contig + 30x
+reads, k=32) and the frozen self-generated vectors, through the C ABI.
+
+At this size the oracle is only run for the filter (about 20 s); the rest uses properties
+that do not depend on size: the result must not depend on how the work is scheduled
+(window size), on which other batches share the job, or on being repeated."""
+import hashlib
+import json
+import pathlib
+
+import numpy as np
+import pytest
+
+from goldpolish_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = pathlib.Path(__file__).parent / "golden"
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def gp():
+    from goldpolish_amd import core
+    ctx = core.Context(0)
+    yield core, ctx
+    ctx.close()
+
+
+def test_frozen_vectors_through_the_abi(gp):
+    core, ctx = gp
+    for case in json.loads((GOLD / "pipeline_small.json").read_text()):
+        w = synth.make_workload(case["lens"], case["coverage"], seed=case["seed"], **case["extra"])
+        p = core.default_params(k_values=case["k"])
+        with core.Job.from_workload(ctx, p, w) as job:
+            job.build_filters()
+            for c, want in enumerate(case["contigs"]):
+                got = [sha(job.get_filter(c, ki).tobytes()) for ki in range(p.n_k)]
+                assert got == want["filters"], (case["name"], c)
+            for ki in range(p.n_k):
+                job.ntedit_pass(ki)
+                seqs = job.sequences()
+                for c, want in enumerate(case["contigs"]):
+                    assert sha(seqs[c]) == want["ntedit"][ki]["sha"], (case["name"], c, ki)
+            job.ntedit_guard()
+            job.mask()
+            for c, s in enumerate(job.sequences()):
+                assert sha(s) == case["contigs"][c]["mask"]["sha"]
+            job.sealer()
+            for c, s in enumerate(job.sequences()):
+                assert sha(s) == case["contigs"][c]["sealer"]["sha"]
+            job.upper()
+            for c, s in enumerate(job.sequences()):
+                assert sha(s) == case["contigs"][c]["final"]["sha"]
+            # and in one call
+            job.polish()
+            for c, s in enumerate(job.sequences()):
+                assert sha(s) == case["contigs"][c]["final"]["sha"]
+
+
+def test_config2_full_size(gp, oracle, monkeypatch):
+    core, ctx = gp
+    w = synth.make_workload([10_000_000], 30, seed=2)
+    p = core.default_params(k_values=[32])
+    with core.Job.from_workload(ctx, p, w) as job:
+        job.polish()
+        out = job.sequences()[0]
+        f_a = job.get_filter(0, 0).copy()
+        c_a = job.counters()
+        # the whole filter against the serial oracle (296 M insert_thresh_contains calls)
+        _, bfs = oracle.fill_bfs(w.reads_of(0), [32], int(w.kmer_threshold[0]), p.cbf_bytes,
+                                 p.bf_bytes)
+        assert np.array_equal(f_a, bfs[0])
+        # idempotence
+        job.polish()
+        assert job.sequences()[0] == out and np.array_equal(job.get_filter(0, 0), f_a)
+    # schedule independence: a very different window size gives the same bits
+    monkeypatch.setenv("GP_STAGE_A_WINDOW", str(3 << 20))
+    with core.Job.from_workload(ctx, p, w) as job:
+        job.build_filters()
+        assert np.array_equal(job.get_filter(0, 0), f_a)
+        assert job.counters()["a_ops"] == c_a["a_ops"]
+    # the polished contig: same length class, upper case, and what the oracle's ntEdit,
+    # mask and Sealer make of it given that filter
+    assert out == out.upper()
+    cur, _ = oracle.ntedit(w.contig(0), f_a, 32)
+    m = oracle.mask(cur, 32)
+    s, _ = oracle.sealer(m, [32], [f_a])
+    assert out == s.upper()
+
+
+def test_batches_do_not_influence_each_other(gp):
+    core, ctx = gp
+    w = synth.make_workload([30000, 18000, 25000, 9000, 40000], 30, seed=61)
+    p = core.default_params()
+    with core.Job.from_workload(ctx, p, w) as job:
+        job.polish()
+        together = job.sequences()
+    for c in (0, 3, 4):
+        one = synth.Workload(
+            names=[w.names[c]], contig_buf=np.frombuffer(w.contig(c), dtype=np.uint8),
+            contig_off=np.array([0, len(w.contig(c))], dtype=np.uint64),
+            read_buf=np.frombuffer(b"".join(w.reads_of(c)), dtype=np.uint8),
+            read_off=np.concatenate([[0], np.cumsum([len(r) for r in w.reads_of(c)])]).astype(np.uint64),
+            contig_read_begin=np.array([0, len(w.reads_of(c))], dtype=np.uint32),
+            kmer_threshold=w.kmer_threshold[c:c + 1])
+        with core.Job.from_workload(ctx, p, one) as job:
+            job.polish()
+            assert job.sequences()[0] == together[c], c

@@ -1,0 +1,86 @@
+"""CPU tests of the host side: the synthetic workload generator, the multi-rank gather of
+polished sequences (gloo, world_size 2) and the oracle under AddressSanitizer."""
+import os
+import pathlib
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+
+
+def test_workload_generator_is_seeded_and_ranked():
+    from goldpolish_amd import synth
+    a = synth.make_workload([4000, 2500], 20, seed=9)
+    b = synth.make_workload([4000, 2500], 20, seed=9)
+    assert np.array_equal(a.read_buf, b.read_buf) and np.array_equal(a.contig_buf, b.contig_buf)
+    assert a.n_contigs == 2 and a.contig_read_begin[0] == 0
+    # per-contig cap size_t(len * 40 / 10000)
+    for c in range(2):
+        n = int(a.contig_read_begin[c + 1] - a.contig_read_begin[c])
+        assert n <= int(len(a.contig(c)) * 40 / 10000)
+    assert set(np.unique(a.read_buf)) <= set(b"ACGT")
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[3])
+import torch.distributed as dist
+import bench
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[4], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+mine = [bytes([65 + rank]) * (10 + 7 * rank), None, b"ACGT" * (3 + rank)]
+out = bench.gather_to_rank0(mine, rank, world, "gloo")
+if rank == 0:
+    assert len(out) == world
+    for r in range(world):
+        exp = [bytes([65 + r]) * (10 + 7 * r), b"", b"ACGT" * (3 + r)]
+        got = [x if x is not None else b"" for x in out[r]]
+        assert got == exp, (r, got, exp)
+    print("GATHER_OK")
+else:
+    assert out is None
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_gather_of_polished_segments_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(ROOT), port],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GATHER_OK" in outs[0]
+
+
+_ASAN = r'''
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import oracle_lib
+from goldpolish_amd import synth
+O = oracle_lib.Oracle(sys.argv[1] + "/oracle/libgpo_asan.so")
+w = synth.make_workload([3000, 1200], 25, seed=77, draft_err=0.03)
+for c in range(w.n_contigs):
+    outs, st, _ = O.polish_batch([w.names[c]], [w.contig(c)], [w.reads_of(c)], [int(w.kmer_threshold[c])])
+    assert outs[0]
+print("ASAN_OK")
+'''
+
+
+def test_oracle_under_address_sanitizer(tmp_path):
+    """GPU sanitizers are not available on the pool; the CPU oracle at least runs clean"""
+    subprocess.check_call(["make", "-C", str(ROOT / "oracle"), "libgpo_asan.so"],
+                          stdout=subprocess.DEVNULL)
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    script = tmp_path / "asan.py"
+    script.write_text(_ASAN)
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")
+    r = subprocess.run([sys.executable, str(script), str(ROOT)], env=env, text=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and "ASAN_OK" in r.stdout, r.stdout[-3000:]
