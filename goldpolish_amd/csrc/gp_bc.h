@@ -26,7 +26,7 @@ struct StageBC {
     DevBuf<uint32_t> err;     // device-side error word
     DevBuf<unsigned long long> stats; // b_scan_kmers, b_sites, b_probes, b_edits, c_*
     DevBuf<uint8_t> batch_skip;
-    DevBuf<unsigned long long> bm_site; // stage B membership bitmap, one bit per slot position
+    DevBuf<unsigned long long> bm_site, bm_ok; // stage B bitmaps, one bit per slot position
     DevBuf<uint32_t> n_nodes;           // [n_contigs]
     DevBuf<uint32_t> tile_contig, tile_first; // output tiles of materialize_kernel
     uint32_t n_tiles = 0;

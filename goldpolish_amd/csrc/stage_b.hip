@@ -59,7 +59,8 @@ struct WalkArgs {
     uint32_t max_del, jump, min_contig_len, soft_mask;
     uint32_t need_missing, need_edit, need_del; // integer forms of the float tests
     uint32_t insertion_cap;
-    const unsigned long long* bm_site; // bit (off[c] + p): k-mer at p is testable and absent
+    const unsigned long long* bm_site; // bit (off[c] + p): k-mer at p is absent from the filter
+    const unsigned long long* bm_ok;   // bit (off[c] + p): bases p .. p+k-1 are all accepted
     uint32_t* n_nodes;                 // live nodes per contig after the walk
     uint32_t* err;
     unsigned long long* stats;
@@ -111,6 +112,7 @@ struct Shared {
     uint32_t bit_from;        // first k-mer start the bitmap search looks at
     uint32_t need_hash;       // the walker jumped: hash of the current k-mer must be rebuilt
     uint32_t fast_head;       // window can be read straight from the contig at S.hi
+    uint32_t confirmed;       // the bitmap already did the confirm step for this site
     int32_t request;
     uint32_t nz;              // chars available in Z
     uint32_t scan_j0, scan_n; // first k-mer index / number of k-mers of the scan
@@ -772,6 +774,7 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
         S.clean_from = 0;
         S.need_hash = 0;
         S.fast_head = 0;
+        S.confirmed = 0;
         if (hi + k - 1 < len) {
             hash_kmer(S.ht, c.seq + hi, k, S.fh, S.rh);
             S.char_in = c.seq[S.ti];
@@ -796,15 +799,68 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
             const bool plain = tnode.type == 0 && tnode.e == len - 1 && S.ti <= tnode.e;
             const bool clean = plain && S.hn == S.tn && S.hi >= S.clean_from && a.bm_site != nullptr;
             if (clean) {
-                // everything from the head on is untouched contig: the precomputed bitmap
-                // says where the next testable, absent k-mer starts
-                const uint32_t start = S.hi + (S.cur_tested ? 1u : 0u);
-                if (start + k > len) {
-                    S.request = REQ_DONE;
-                } else {
-                    S.bit_from = start;
-                    S.request = REQ_BITSCAN;
+                // everything from the head on is untouched contig: the precomputed bitmaps
+                // say where the next testable, absent k-mer starts AND whether the k k-mers
+                // after it confirm it, so unconfirmed candidates cost no barrier at all
+                uint32_t p = S.hi + (S.cur_tested ? 1u : 0u);
+                const uint32_t last_p = len - k;
+                const uint64_t base_bit = a.off[cid];
+                uint32_t words_left = 16;
+                int32_t next_req = REQ_DONE;
+                while (p <= last_p) {
+                    const uint64_t bit = base_bit + p;
+                    unsigned long long w = a.bm_site[bit >> 6] & a.bm_ok[bit >> 6];
+                    w &= ~0ULL << (bit & 63);
+                    if (!w) {
+                        const uint32_t np = (uint32_t)((((bit >> 6) + 1) << 6) - base_bit);
+                        S.st_scan += min(np, last_p + 1) - p;
+                        p = np;
+                        if (--words_left == 0) {
+                            next_req = REQ_BITSCAN; // long quiet stretch: search with every lane
+                            break;
+                        }
+                        continue;
+                    }
+                    const uint32_t cand = (uint32_t)(((bit >> 6) << 6) + (uint64_t)(__ffsll((long long)w) - 1) - base_bit);
+                    if (cand > last_p) {
+                        S.st_scan += last_p + 1 - p;
+                        p = last_p + 1;
+                        break;
+                    }
+                    S.st_scan += cand - p + 1;
+                    // confirm (ntedit.cpp:1487-1523): the next k bases must exist and be
+                    // accepted, and enough of every jump-th following k-mer must be absent
+                    bool ok = (uint64_t)cand + 2ull * k <= len;
+                    if (ok) {
+                        const uint64_t b2 = base_bit + cand + k;
+                        ok = (a.bm_ok[b2 >> 6] >> (b2 & 63)) & 1ULL;
+                    }
+                    uint32_t missing = 0;
+                    if (ok) {
+                        for (uint32_t q = 0; q < k; q += jump) {
+                            const uint64_t b3 = base_bit + cand + 1 + q;
+                            missing += (uint32_t)((a.bm_site[b3 >> 6] >> (b3 & 63)) & 1ULL);
+                        }
+                        S.st_probes += (k + jump - 1) / jump;
+                    }
+                    if (ok && missing >= a.need_missing) {
+                        S.hi = cand;
+                        S.ti = cand + k - 1;
+                        S.char_in = c.seq[S.ti];
+                        S.cur_tested = 1;
+                        S.need_hash = 1;
+                        S.confirmed = 1;
+                        S.min_tested_ti = 0;
+                        next_req = REQ_SITE;
+                        break;
+                    }
+                    p = cand + 1;
                 }
+                if (next_req == REQ_BITSCAN)
+                    S.bit_from = p;
+                // REQ_DONE here means the scan ran off the end of the contig: nothing is left
+                // that the reference could act on
+                S.request = next_req;
             } else if (plain) {
                 // scan: current k-mer chars via the cursor, lookahead straight from the contig
                 Node hnode = nd_get(c, S, S.hn);
@@ -871,7 +927,7 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
                 const uint64_t w = w0 + tid;
                 uint32_t hit = 0xFFFFFFFFu;
                 if (w <= w_last) {
-                    unsigned long long bits = a.bm_site[w];
+                    unsigned long long bits = a.bm_site[w] & a.bm_ok[w];
                     if (w == w_first)
                         bits &= ~0ULL << ((base_bit + from) & 63);
                     if (w == w_last && ((base_bit + last_p) & 63) != 63)
@@ -886,14 +942,18 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
                     S.st_scan += last_p - from + 1;
                     S.request = REQ_DONE; // nothing absent up to the end of the contig
                 } else {
-                    S.st_scan += found - from + 1;
-                    S.hi = found;
-                    S.ti = found + k - 1;
-                    S.char_in = c.seq[S.ti];
-                    S.cur_tested = 1;
-                    S.need_hash = 1;
+                    // park the head just left of the candidate; thread 0 takes it from there
+                    S.st_scan += found - from;
+                    if (found == 0) {
+                        S.hi = 0;
+                        S.cur_tested = 0;
+                    } else {
+                        S.hi = found - 1;
+                        S.cur_tested = 1;
+                    }
+                    S.ti = S.hi + k - 1;
                     S.min_tested_ti = 0;
-                    S.request = REQ_SITE;
+                    S.request = REQ_NEXT;
                 }
             }
             __syncthreads();
@@ -973,19 +1033,33 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
             S.best_key = 0;
         }
         __syncthreads();
-        if (S.fast_head) {
+        // flags are read once, here, by everybody; thread 0 only rewrites them behind barriers
+        const uint32_t f_fast = S.fast_head, f_hash = S.need_hash, f_confirmed = S.confirmed;
+        if (f_fast) {
             for (uint32_t i = tid; i < S.nz; i += kWalkThreads)
                 S.Z[i] = c.seq[S.hi + i];
             __syncthreads();
         }
-        if (S.need_hash) {
-            if (tid == 0) {
-                hash_kmer(S.ht, S.Z, k, S.fh, S.rh);
-                S.need_hash = 0;
+        if (f_hash) {
+            // hash of Z[0..k) as an XOR of k independently rotated seeds, reduced by one wave
+            if (tid < 64) {
+                uint64_t f = 0, r = 0;
+                if (tid < k) {
+                    f = sroln(S.ht.f[fcode(S.Z[tid])], k - 1 - tid);
+                    r = sroln(S.ht.r[rcode(S.Z[tid])], tid);
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    f ^= __shfl_xor(f, o);
+                    r ^= __shfl_xor(r, o);
+                }
+                if (tid == 0) {
+                    S.fh = f;
+                    S.rh = r;
+                }
             }
             __syncthreads();
         }
-        {
+        if (!f_confirmed) {
             // confirm: k more k-mers, every jump-th one probed
             uint32_t miss = 0, bad = 0;
             if (tid < k) {
@@ -1009,9 +1083,11 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
             }
             __syncthreads();
         }
-        if (S.confirm_bad || S.confirm_missing < a.need_missing) {
-            if (tid == 0)
+        if (!f_confirmed && (S.confirm_bad || S.confirm_missing < a.need_missing)) {
+            if (tid == 0) {
                 S.request = REQ_NEXT;
+                S.need_hash = 0;
+            }
             __syncthreads();
             continue;
         }
@@ -1019,6 +1095,8 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
         // substitution trials: one wave-sized slice of work per candidate base
         if (tid == 0) {
             S.st_sites++;
+            S.confirmed = 0;
+            S.need_hash = 0;
             const char* s;
             switch ((uint8_t)S.draft) {
             case 'A': s = "TCG"; break;
@@ -1232,7 +1310,8 @@ __global__ __launch_bounds__(256) void materialize_kernel(const uint8_t* seq, ui
 constexpr int kScanTile = 1024;
 
 __global__ __launch_bounds__(256) void ntedit_scan(WalkArgs a, uint32_t n_contigs,
-                                                   unsigned long long* bm_site)
+                                                   unsigned long long* bm_site,
+                                                   unsigned long long* bm_ok)
 {
     __shared__ uint8_t z[kScanTile + kMaxK];
     __shared__ HashTab ht;
@@ -1268,7 +1347,7 @@ __global__ __launch_bounds__(256) void ntedit_scan(WalkArgs a, uint32_t n_contig
     for (uint32_t sub = 0; sub < kScanTile / 256; sub++) {
         const uint32_t i = sub * 256 + threadIdx.x;
         const uint64_t p = p0 + i;
-        bool site = false;
+        bool site = false, okb = false;
         if (p + k <= len) {
             uint64_t f = 0, r = 0;
             bool ok = true;
@@ -1278,11 +1357,14 @@ __global__ __launch_bounds__(256) void ntedit_scan(WalkArgs a, uint32_t n_contig
                 f = srol1(f) ^ ht.f[fcode(cf)];
                 r = srol1(r) ^ ht.r[rcode(z[i + k - 1 - j])];
             }
-            site = ok && !bf_contains(a, bf, f + r);
+            okb = ok;
+            site = !bf_contains(a, bf, f + r);
         }
-        const unsigned long long word = __ballot(site);
-        if ((threadIdx.x & 63) == 0)
+        const unsigned long long word = __ballot(site), word_ok = __ballot(okb);
+        if ((threadIdx.x & 63) == 0) {
             bm_site[(tile0 + i) >> 6] = word;
+            bm_ok[(tile0 + i) >> 6] = word_ok;
+        }
     }
 }
 
@@ -1702,7 +1784,8 @@ int stage_bc_prepare(gp_job* job)
         (rc = b->batch_begin.alloc((size_t)job->n_batches + 1)) != GP_OK ||
         (rc = b->err.alloc(4)) != GP_OK || (rc = b->stats.alloc(16)) != GP_OK ||
         (rc = b->batch_skip.alloc(job->n_batches)) != GP_OK ||
-        (rc = b->bm_site.alloc(off / 64 + 64)) != GP_OK || (rc = b->n_nodes.alloc(n)) != GP_OK ||
+        (rc = b->bm_site.alloc(off / 64 + 64)) != GP_OK ||
+        (rc = b->bm_ok.alloc(off / 64 + 64)) != GP_OK || (rc = b->n_nodes.alloc(n)) != GP_OK ||
         (rc = b->tile_first.alloc((size_t)n + 1)) != GP_OK)
         return rc;
     {
@@ -1844,6 +1927,7 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     a.err = b->err.p;
     a.stats = b->stats.p;
     a.bm_site = b->bm_site.p;
+    a.bm_ok = b->bm_ok.p;
     a.n_nodes = b->n_nodes.p;
     hipStream_t s = job->ctx->stream;
     // 1. membership bitmap of the pass's input, every CU
@@ -1851,7 +1935,7 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     if (rc != GP_OK)
         return rc;
     hipLaunchKernelGGL(ntedit_scan, dim3((unsigned)((b->total_slots + kScanTile - 1) / kScanTile)),
-                       dim3(256), 0, s, a, job->n_contigs, b->bm_site.p);
+                       dim3(256), 0, s, a, job->n_contigs, b->bm_site.p, b->bm_ok.p);
     GP_HIP(hipGetLastError());
     if ((rc = job->t_scan.end(s)) != GP_OK)
         return rc;
