@@ -112,7 +112,7 @@ struct gp_job {
     gp::DevBuf<uint32_t> d_bf;            // [n_batches][n_k][bf_bytes/4]
 
     // ---- stage A work buffers
-    gp::DevBuf<uint32_t> d_resv[2];       // reservation tables (hashed slots)
+    gp::DevBuf<unsigned long long> d_resv; // reservation slots (hashed), (tag << 32) | position
     uint32_t resv_bits = 0;
     gp::DevBuf<uint4> d_pending[2];       // {hash lo, hash hi, pos, meta}
     gp::DevBuf<uint32_t> d_counts;        // [kMaxRounds+2] pending count per round

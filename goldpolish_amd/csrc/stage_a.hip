@@ -59,8 +59,12 @@ struct AArgs {
     uint32_t bf_words;
     FastMod cbf_mod, bf_mod;
     KConsts kc[GP_MAX_K_VALUES];
-    uint32_t* resv_cur;  // table the incoming list reserved in
-    uint32_t* resv_next; // table losers reserve in for the next round
+    // reservation slots, (round tag << 32) | window position; two tables alternate so that
+    // the reservations a launch makes never disturb the ones it is still checking
+    unsigned long long* resv;      // table the incoming list reserved in
+    unsigned long long* resv_out;  // table this launch reserves in
+    uint32_t tag_cur;    // tag the incoming list reserved with
+    uint32_t tag_next;   // tag for reservations made by this launch (always smaller: newer wins)
     uint32_t resv_bits;
     uint4* list_in;
     uint4* list_out;
@@ -116,11 +120,43 @@ __device__ inline bool try_settle(const AArgs& a, uint32_t stream, uint32_t thr,
     return true;
 }
 
-__device__ inline void reserve(const AArgs& a, uint32_t* table, uint32_t stream,
-                               const uint32_t* idx, uint32_t pos)
+// the same for an operation whose counter indices are already known
+__device__ inline bool try_settle_idx(const AArgs& a, uint32_t stream, uint32_t thr, uint32_t k,
+                                      uint64_t base, const uint32_t* idx)
 {
+    uint8_t* cb = a.cbf + (uint64_t)stream * a.cbf_bytes;
+    uint32_t c[kMaxHash];
+    uint32_t m = 255;
+    for (uint32_t i = 0; i < a.hash_num; i++) {
+        c[i] = cb[idx[i]];
+        m = min(m, c[i]);
+    }
+    if (m + 1 < thr)
+        return false;
     for (uint32_t i = 0; i < a.hash_num; i++)
-        atomicMin(&table[resv_slot(a, stream, idx[i])], pos);
+        if (c[i] < thr)
+            cb[idx[i]] = (uint8_t)thr;
+    uint64_t hv[kMaxHash];
+    hv[0] = base;
+    for (uint32_t i = 1; i < a.hash_num; i++)
+        hv[i] = ext_hash(base, k, i);
+    bf_insert(a, stream, hv);
+    return true;
+}
+
+// A reservation is (tag, position) packed so that atomicMin prefers the newer round first
+// and the earlier position second; stale entries of older rounds never need clearing.
+__device__ inline unsigned long long resv_word(uint32_t tag, uint32_t pos)
+{
+    return ((unsigned long long)tag << 32) | pos;
+}
+
+__device__ inline void reserve(const AArgs& a, uint32_t stream, const uint32_t* idx,
+                               uint32_t pos)
+{
+    const unsigned long long w = resv_word(a.tag_next, pos);
+    for (uint32_t i = 0; i < a.hash_num; i++)
+        atomicMin(&a.resv_out[resv_slot(a, stream, idx[i])], w);
 }
 
 // ---- first pass over a window: hash, settle what can be settled, reserve the rest
@@ -200,10 +236,11 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
                 continue;
             n_ordered++;
             const uint32_t rel = (uint32_t)(pos - a.win_start);
-            reserve(a, a.resv_cur, stream, idx, rel);
+            reserve(a, stream, idx, rel);
             uint32_t at = wave_append(&a.counts[0]);
-            a.list_out[at] = make_uint4((uint32_t)base, (uint32_t)(base >> 32), rel,
-                                        (seg << 3) | ki);
+            a.list_out[2 * at] = make_uint4((uint32_t)base, (uint32_t)(base >> 32), rel,
+                                            (seg << 3) | ki);
+            a.list_out[2 * at + 1] = make_uint4(idx[0], idx[1], idx[2], idx[3]);
         }
     }
     atomicAdd(&s_stats[0], (unsigned long long)n_positions);
@@ -220,30 +257,28 @@ __global__ __launch_bounds__(256) void cbf_round(AArgs a)
     const uint32_t n_in = a.counts[a.round];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in;
          i += gridDim.x * blockDim.x) {
-        const uint4 rec = a.list_in[i];
+        const uint4 rec = a.list_in[2 * i];
+        const uint4 rix = a.list_in[2 * i + 1];
         const uint64_t base = ((uint64_t)rec.y << 32) | rec.x;
         const uint32_t pos = rec.z;
         const uint32_t ki = rec.w & 7, seg = rec.w >> 3;
         const uint32_t k = a.kc[ki].k;
         const uint32_t stream = a.seg_batch[seg] * a.n_k + ki;
         const uint32_t thr = a.seg_thr[seg] - 2 + ki;
-
-        uint64_t hv[kMaxHash];
-        uint32_t idx[kMaxHash], slot[kMaxHash];
-        hv[0] = base;
-        bool mine = true;
-        for (uint32_t h = 0; h < a.hash_num; h++) {
-            if (h)
-                hv[h] = ext_hash(base, k, h);
-            idx[h] = (uint32_t)fastmod(hv[h], a.cbf_mod);
-            slot[h] = resv_slot(a, stream, idx[h]);
-            mine &= (a.resv_cur[slot[h]] == pos);
+        uint32_t idx[kMaxHash] = { rix.x, rix.y, rix.z, rix.w };
+        if (a.hash_num > 4) {
+            // only four indices travel with the record; the rest are recomputed
+            for (uint32_t h = 4; h < a.hash_num; h++)
+                idx[h] = (uint32_t)fastmod(ext_hash(base, k, h), a.cbf_mod);
+        } else if (a.hash_num < 4) {
+            for (uint32_t h = a.hash_num; h < 4; h++)
+                idx[h] = idx[0];
         }
-        // hand back whatever this operation holds, winner or not, so the table
-        // is all-free again when it is reused two rounds later
+
+        const unsigned long long want = resv_word(a.tag_cur, pos);
+        bool mine = true;
         for (uint32_t h = 0; h < a.hash_num; h++)
-            if (a.resv_cur[slot[h]] == pos)
-                a.resv_cur[slot[h]] = kNoResv;
+            mine &= (a.resv[resv_slot(a, stream, idx[h])] == want);
 
         uint8_t* cb = a.cbf + (uint64_t)stream * a.cbf_bytes;
         if (mine) {
@@ -259,16 +294,21 @@ __global__ __launch_bounds__(256) void cbf_round(AArgs a)
                         cb[idx[h]] = (uint8_t)(m + 1);
                 m++;
             }
-            if (m >= thr)
+            if (m >= thr) {
+                uint64_t hv[kMaxHash];
+                hv[0] = base;
+                for (uint32_t h = 1; h < a.hash_num; h++)
+                    hv[h] = ext_hash(base, k, h);
                 bf_insert(a, stream, hv);
+            }
             continue;
         }
-        uint32_t idx2[kMaxHash];
-        if (try_settle(a, stream, thr, k, base, idx2))
+        if (try_settle_idx(a, stream, thr, k, base, idx))
             continue;
-        reserve(a, a.resv_next, stream, idx, pos);
+        reserve(a, stream, idx, pos);
         uint32_t at = wave_append(&a.counts[a.round + 1]);
-        a.list_out[at] = rec;
+        a.list_out[2 * at] = rec;
+        a.list_out[2 * at + 1] = rix;
     }
 }
 
@@ -345,16 +385,15 @@ int stage_a_prepare(gp_job* job)
     }
     int rc;
     for (int i = 0; i < 2; i++)
-        if ((rc = job->d_pending[i].alloc(max_pending)) != GP_OK)
+        if ((rc = job->d_pending[i].alloc(2 * max_pending)) != GP_OK) // two uint4 per record
             return rc;
-    // reservation slots: >= 8 per possible pending counter touch, power of two
+    // reservation slots: two per possible waiting counter touch, power of two, <= 1 GiB
     uint32_t bits = 16;
-    while ((1ull << bits) < max_pending * p.hash_num * 2 && bits < 28)
+    while ((1ull << bits) < max_pending * p.hash_num * 2 && bits < 26)
         bits++;
     job->resv_bits = bits;
-    for (int i = 0; i < 2; i++)
-        if ((rc = job->d_resv[i].alloc(1ull << bits)) != GP_OK)
-            return rc;
+    if ((rc = job->d_resv.alloc(2ull << bits)) != GP_OK) // two tables
+        return rc;
     if ((rc = job->d_counts.alloc(kMaxRounds + 2)) != GP_OK)
         return rc;
     if ((rc = job->d_stats.alloc(16)) != GP_OK)
@@ -407,8 +446,8 @@ int stage_a_run(gp_job* job)
     GP_HIP(hipMemsetAsync(job->d_cbf.p, 0, job->d_cbf.n, s));
     GP_HIP(hipMemsetAsync(job->d_bf.p, 0, job->d_bf.n * sizeof(uint32_t), s));
     GP_HIP(hipMemsetAsync(job->d_stats.p, 0, 16 * sizeof(unsigned long long), s));
-    for (int i = 0; i < 2; i++)
-        GP_HIP(hipMemsetAsync(job->d_resv[i].p, 0xFF, job->d_resv[i].n * sizeof(uint32_t), s));
+    GP_HIP(hipMemsetAsync(job->d_resv.p, 0xFF, job->d_resv.n * sizeof(unsigned long long), s));
+    uint32_t gen = 1; // every launch that reserves gets a fresh, smaller tag
 
     if (job->read_positions == 0 || job->n_contigs == 0) {
         job->filters_ready = true;
@@ -446,8 +485,11 @@ int stage_a_run(gp_job* job)
         a.win_start = w0;
         a.win_end = w1;
         a.counts = job->d_counts.p;
-        a.resv_cur = job->d_resv[0].p;
-        a.resv_next = job->d_resv[1].p;
+        a.resv = nullptr;
+        a.resv_out = job->d_resv.p;
+        a.tag_cur = 0;
+        gen++; // never share a tag with the previous window's last launch
+        a.tag_next = 0xFFFFFFFFu - gen;
         a.list_in = nullptr;
         a.list_out = job->d_pending[0].p;
         a.round = 0;
@@ -477,8 +519,11 @@ int stage_a_run(gp_job* job)
                 return rc;
             for (uint32_t c = 0; c < chunk && round < kMaxRounds; c++, round++) {
                 a.round = round;
-                a.resv_cur = job->d_resv[round & 1].p;
-                a.resv_next = job->d_resv[(round + 1) & 1].p;
+                a.tag_cur = 0xFFFFFFFFu - gen;
+                gen++;
+                a.tag_next = 0xFFFFFFFFu - gen;
+                a.resv = job->d_resv.p + ((uint64_t)(round & 1) << job->resv_bits);
+                a.resv_out = job->d_resv.p + ((uint64_t)((round + 1) & 1) << job->resv_bits);
                 a.list_in = job->d_pending[round & 1].p;
                 a.list_out = job->d_pending[(round + 1) & 1].p;
                 hipLaunchKernelGGL(cbf_round, dim3(kRoundBlocks), dim3(256), 0, s, a);
