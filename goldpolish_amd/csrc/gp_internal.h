@@ -119,6 +119,7 @@ struct gp_job {
     gp::DevBuf<unsigned long long> d_stats; // device-side gp_counters
     uint64_t window = 0;
     uint32_t* h_count_pinned = nullptr;
+    hipEvent_t a_ev[16] = {};
 
     // ---- stage B/C state (see stage_b.hip / stage_c.hip)
     gp::StageBC* bc = nullptr;

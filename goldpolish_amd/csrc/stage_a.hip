@@ -44,6 +44,7 @@ constexpr int kBlock = kTile / kPerThread;
 constexpr int kHalo = 64;          // k <= 64
 constexpr uint32_t kMaxRounds = 4094;
 constexpr int kRoundBlocks = 2048;
+constexpr uint32_t kRing = 16;
 
 struct AArgs {
     const uint8_t* reads;
@@ -63,8 +64,10 @@ struct AArgs {
     // the reservations a launch makes never disturb the ones it is still checking
     unsigned long long* resv;      // table the incoming list reserved in
     unsigned long long* resv_out;  // table this launch reserves in
-    uint32_t tag_cur;    // tag the incoming list reserved with
-    uint32_t tag_next;   // tag for reservations made by this launch (always smaller: newer wins)
+    uint64_t tag_cur;    // 40-bit tag the incoming list reserved with
+    uint64_t tag_next;   // tag for reservations made by this launch (always smaller: newer wins)
+    uint32_t tail_from;  // first round the tail kernel may take over (see cbf_tail)
+    uint32_t tail_max;   // lists up to this long are left to the tail kernel
     uint32_t resv_bits;
     uint4* list_in;
     uint4* list_out;
@@ -112,10 +115,10 @@ __device__ inline bool try_settle(const AArgs& a, uint32_t stream, uint32_t thr,
     }
     if (m + 1 < thr)
         return false;
-    // every counter is already >= thr-1: order cannot matter any more
-    for (uint32_t i = 0; i < a.hash_num; i++)
-        if (c[i] < thr)
-            cb[idx[i]] = (uint8_t)thr;
+    // Every counter is already >= thr-1: the k-mer goes in whatever happens before this
+    // operation.  Its own update would only lift counters from thr-1 to thr, and no later
+    // decision can tell those two values apart (a minimum of thr-1 or thr both mean
+    // "insert", and neither is ever incremented from below again), so nothing is written.
     bf_insert(a, stream, hv);
     return true;
 }
@@ -146,9 +149,9 @@ __device__ inline bool try_settle_idx(const AArgs& a, uint32_t stream, uint32_t 
 
 // A reservation is (tag, position) packed so that atomicMin prefers the newer round first
 // and the earlier position second; stale entries of older rounds never need clearing.
-__device__ inline unsigned long long resv_word(uint32_t tag, uint32_t pos)
+__device__ inline unsigned long long resv_word(uint64_t tag, uint32_t pos)
 {
-    return ((unsigned long long)tag << 32) | pos;
+    return ((unsigned long long)tag << 24) | pos; // window positions are < 2^24
 }
 
 __device__ inline void reserve(const AArgs& a, uint32_t stream, const uint32_t* idx,
@@ -251,65 +254,162 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
         atomicAdd(&a.stats[threadIdx.x], s_stats[threadIdx.x]);
 }
 
-// ---- one reservation round: commit the holders, let the others retry
+// loads that must see what other waves of the SAME launch wrote (tail kernel): agent-scope
+// atomic loads bypass the CU's vector L1
+template <bool FRESH, typename T>
+__device__ inline T ld(const T* p)
+{
+    if (FRESH)
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
+// One waiting operation in one round.  Returns true when it is still waiting (it has then
+// reserved for the next round with tag_next in resv_out).
+template <bool FRESH>
+__device__ inline bool round_op(const AArgs& a, const uint4 rec, const uint4 rix,
+                                const unsigned long long* resv_in, unsigned long long* resv_out,
+                                uint64_t tag_cur, uint64_t tag_next)
+{
+    const uint64_t base = ((uint64_t)rec.y << 32) | rec.x;
+    const uint32_t pos = rec.z;
+    const uint32_t ki = rec.w & 7, seg = rec.w >> 3;
+    const uint32_t k = a.kc[ki].k;
+    const uint32_t stream = a.seg_batch[seg] * a.n_k + ki;
+    const uint32_t thr = a.seg_thr[seg] - 2 + ki;
+    uint32_t idx[kMaxHash] = { rix.x, rix.y, rix.z, rix.w };
+    // only four indices travel with the record; the rest are recomputed
+    for (uint32_t h = 4; h < a.hash_num; h++)
+        idx[h] = (uint32_t)fastmod(ext_hash(base, k, h), a.cbf_mod);
+
+    const unsigned long long want = resv_word(tag_cur, pos);
+    bool mine = true;
+    for (uint32_t h = 0; h < a.hash_num; h++)
+        mine &= (ld<FRESH>(&resv_in[resv_slot(a, stream, idx[h])]) == want);
+
+    uint8_t* cb = a.cbf + (uint64_t)stream * a.cbf_bytes;
+    uint32_t c[kMaxHash], m = 255;
+    for (uint32_t h = 0; h < a.hash_num; h++) {
+        c[h] = ld<FRESH>(&cb[idx[h]]);
+        m = min(m, c[h]);
+    }
+    bool insert;
+    if (mine) {
+        // no earlier unfinished operation touches these counters: the serial update
+        if (m < thr) {
+            for (uint32_t h = 0; h < a.hash_num; h++)
+                if (c[h] == m)
+                    cb[idx[h]] = (uint8_t)(m + 1);
+            m++;
+        }
+        insert = m >= thr;
+    } else if (m + 1 >= thr) {
+        insert = true; // settled (see try_settle): no counter needs writing
+    } else {
+        const unsigned long long w = resv_word(tag_next, pos);
+        for (uint32_t h = 0; h < a.hash_num; h++)
+            atomicMin(&resv_out[resv_slot(a, stream, idx[h])], w);
+        return true;
+    }
+    if (insert) {
+        uint64_t hv[kMaxHash];
+        hv[0] = base;
+        for (uint32_t h = 1; h < a.hash_num; h++)
+            hv[h] = ext_hash(base, k, h);
+        bf_insert(a, stream, hv);
+    }
+    return false;
+}
+
+// ---- one reservation round over a long list: every CU
 __global__ __launch_bounds__(256) void cbf_round(AArgs a)
 {
     const uint32_t n_in = a.counts[a.round];
+    if (a.round >= a.tail_from && n_in <= a.tail_max)
+        return; // short list: cbf_tail finishes it without further launches
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in;
          i += gridDim.x * blockDim.x) {
         const uint4 rec = a.list_in[2 * i];
         const uint4 rix = a.list_in[2 * i + 1];
-        const uint64_t base = ((uint64_t)rec.y << 32) | rec.x;
-        const uint32_t pos = rec.z;
-        const uint32_t ki = rec.w & 7, seg = rec.w >> 3;
-        const uint32_t k = a.kc[ki].k;
-        const uint32_t stream = a.seg_batch[seg] * a.n_k + ki;
-        const uint32_t thr = a.seg_thr[seg] - 2 + ki;
-        uint32_t idx[kMaxHash] = { rix.x, rix.y, rix.z, rix.w };
-        if (a.hash_num > 4) {
-            // only four indices travel with the record; the rest are recomputed
-            for (uint32_t h = 4; h < a.hash_num; h++)
-                idx[h] = (uint32_t)fastmod(ext_hash(base, k, h), a.cbf_mod);
-        } else if (a.hash_num < 4) {
-            for (uint32_t h = a.hash_num; h < 4; h++)
-                idx[h] = idx[0];
+        if (round_op<false>(a, rec, rix, a.resv, a.resv_out, a.tag_cur, a.tag_next)) {
+            uint32_t at = wave_append(&a.counts[a.round + 1]);
+            a.list_out[2 * at] = rec;
+            a.list_out[2 * at + 1] = rix;
         }
-
-        const unsigned long long want = resv_word(a.tag_cur, pos);
-        bool mine = true;
-        for (uint32_t h = 0; h < a.hash_num; h++)
-            mine &= (a.resv[resv_slot(a, stream, idx[h])] == want);
-
-        uint8_t* cb = a.cbf + (uint64_t)stream * a.cbf_bytes;
-        if (mine) {
-            // no earlier unfinished operation touches these counters: serial update
-            uint32_t c[kMaxHash], m = 255;
-            for (uint32_t h = 0; h < a.hash_num; h++) {
-                c[h] = cb[idx[h]];
-                m = min(m, c[h]);
-            }
-            if (m < thr) {
-                for (uint32_t h = 0; h < a.hash_num; h++)
-                    if (c[h] == m)
-                        cb[idx[h]] = (uint8_t)(m + 1);
-                m++;
-            }
-            if (m >= thr) {
-                uint64_t hv[kMaxHash];
-                hv[0] = base;
-                for (uint32_t h = 1; h < a.hash_num; h++)
-                    hv[h] = ext_hash(base, k, h);
-                bf_insert(a, stream, hv);
-            }
-            continue;
-        }
-        if (try_settle_idx(a, stream, thr, k, base, idx))
-            continue;
-        reserve(a, stream, idx, pos);
-        uint32_t at = wave_append(&a.counts[a.round + 1]);
-        a.list_out[2 * at] = rec;
-        a.list_out[2 * at + 1] = rix;
     }
+}
+
+// ---- the tail of a window: one workgroup keeps running rounds on the list the grid-wide
+// rounds left (the first list no longer than tail_max, or whatever is left after the last
+// of them) until nothing waits.  Rounds are separated by workgroup barriers; every load of
+// data another wave may have written in an earlier round bypasses L1.
+constexpr int kTailThreads = 1024;
+
+struct TailArgs {
+    uint4* list[2];
+    unsigned long long* resv[2];
+    uint64_t tag_first;   // tag of round 0 of this window; round r uses tag_first - r
+    uint32_t n_rounds;    // grid-wide rounds that were launched
+    uint32_t max_rounds;  // bug trap
+    uint32_t* err;
+    uint32_t* info;       // [0] round at which the tail took over, [1] list length then
+    unsigned long long* stats; // [3] rounds run by the tail
+};
+
+__global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
+{
+    __shared__ uint32_t s_n, s_out;
+    if (threadIdx.x == 0) {
+        uint32_t r = 0;
+        while (r < t.n_rounds && !(r >= a.tail_from && a.counts[r] <= a.tail_max))
+            r++;
+        s_n = a.counts[r];
+        s_out = r; // reused below as "current round" until the loop starts
+        t.info[0] = r;
+        t.info[1] = s_n;
+    }
+    __syncthreads();
+    uint32_t n = s_n, round = s_out;
+    __syncthreads();
+    uint32_t done_rounds = 0;
+    while (n > 0) {
+        if (threadIdx.x == 0)
+            s_out = 0;
+        __syncthreads();
+        const uint4* in = t.list[round & 1];
+        uint4* out = t.list[(round + 1) & 1];
+        const uint64_t tag_cur = t.tag_first - round, tag_next = tag_cur - 1;
+        for (uint32_t i = threadIdx.x; i < n; i += kTailThreads) {
+            uint4 rec, rix;
+            {
+                // records may have been written by another wave in the previous round
+                const unsigned long long* q = reinterpret_cast<const unsigned long long*>(in + 2 * i);
+                unsigned long long w0 = ld<true>(q), w1 = ld<true>(q + 1), w2 = ld<true>(q + 2),
+                                   w3 = ld<true>(q + 3);
+                rec = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
+                rix = make_uint4((uint32_t)w2, (uint32_t)(w2 >> 32), (uint32_t)w3, (uint32_t)(w3 >> 32));
+            }
+            if (round_op<true>(a, rec, rix, t.resv[round & 1], t.resv[(round + 1) & 1], tag_cur,
+                               tag_next)) {
+                uint32_t at = atomicAdd(&s_out, 1u);
+                out[2 * at] = rec;
+                out[2 * at + 1] = rix;
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        n = s_out;
+        round++;
+        done_rounds++;
+        __syncthreads();
+        if (done_rounds > t.max_rounds) {
+            if (threadIdx.x == 0)
+                atomicOr(t.err, 1u);
+            break;
+        }
+    }
+    if (threadIdx.x == 0 && done_rounds)
+        atomicAdd(&t.stats[3], (unsigned long long)done_rounds);
 }
 
 // ------------------------------------------------------------------ host side
@@ -398,7 +498,9 @@ int stage_a_prepare(gp_job* job)
         return rc;
     if ((rc = job->d_stats.alloc(16)) != GP_OK)
         return rc;
-    GP_HIP(hipHostMalloc((void**)&job->h_count_pinned, 64));
+    GP_HIP(hipHostMalloc((void**)&job->h_count_pinned, 256));
+    for (uint32_t i = 0; i < kRing; i++)
+        GP_HIP(hipEventCreateWithFlags(&job->a_ev[i], hipEventDisableTiming));
     return GP_OK;
 }
 
@@ -407,6 +509,9 @@ void stage_a_release(gp_job* job)
     if (job->h_count_pinned)
         (void)hipHostFree(job->h_count_pinned);
     job->h_count_pinned = nullptr;
+    for (uint32_t i = 0; i < kRing; i++)
+        if (job->a_ev[i])
+            (void)hipEventDestroy(job->a_ev[i]);
 }
 
 int stage_a_run(gp_job* job)
@@ -446,8 +551,8 @@ int stage_a_run(gp_job* job)
     GP_HIP(hipMemsetAsync(job->d_cbf.p, 0, job->d_cbf.n, s));
     GP_HIP(hipMemsetAsync(job->d_bf.p, 0, job->d_bf.n * sizeof(uint32_t), s));
     GP_HIP(hipMemsetAsync(job->d_stats.p, 0, 16 * sizeof(unsigned long long), s));
+    GP_HIP(hipMemsetAsync(job->d_counts.p, 0, (kMaxRounds + 2) * sizeof(uint32_t), s));
     GP_HIP(hipMemsetAsync(job->d_resv.p, 0xFF, job->d_resv.n * sizeof(unsigned long long), s));
-    uint32_t gen = 1; // every launch that reserves gets a fresh, smaller tag
 
     if (job->read_positions == 0 || job->n_contigs == 0) {
         job->filters_ready = true;
@@ -464,10 +569,64 @@ int stage_a_run(gp_job* job)
     for (uint32_t bi = 0; bi < job->n_batches; bi++)
         batch_pos[bi] = job->h_seg_start[job->h_batch_contig_begin[bi]];
     batch_pos[job->n_batches] = job->read_positions;
-    const uint64_t lim0 = std::max<uint64_t>(kTile, p.cbf_bytes / (4ull * p.hash_num));
-    uint64_t scale = 1;
+    const uint64_t load_div = std::max<uint64_t>(1, env_u64("GP_STAGE_A_LOAD_DIV", 4));
+    const uint64_t lim0 = std::max<uint64_t>(kTile, p.cbf_bytes / (load_div * p.hash_num));
+    const uint32_t n_rounds = (uint32_t)std::min<uint64_t>(env_u64("GP_STAGE_A_ROUNDS", 6), kMaxRounds);
+    const uint64_t tag_max = (1ull << 40) - 1, tail_span = 1ull << 22;
+    a.tail_from = 2;
+    a.tail_max = (uint32_t)env_u64("GP_STAGE_A_TAIL", 4096);
+    TailArgs t{};
+    t.list[0] = job->d_pending[0].p;
+    t.list[1] = job->d_pending[1].p;
+    t.resv[0] = job->d_resv.p;
+    t.resv[1] = job->d_resv.p + (1ull << job->resv_bits);
+    t.n_rounds = n_rounds;
+    t.max_rounds = (uint32_t)tail_span - 16;
+    t.err = job->d_counts.p + kMaxRounds + 1; // last word of the counter array doubles as a flag
+    t.info = job->d_counts.p + kMaxRounds - 2;
+    t.stats = job->d_stats.p;
+    uint64_t scale = 1, gen = 1;
     uint32_t bcur = 0;
+    double last_frac = 1.0; // waiting fraction of the most recent window we know about
+    uint32_t want_rounds = n_rounds; // grid-wide rounds per window, steered by the same feedback
+    // feedback ring: waiting count of a window, read back without stalling the stream
+    uint32_t ring_head = 0, ring_tail = 0, ring_slot = 0; // [tail, head) outstanding
+    uint64_t ring_units[kRing];
+    auto drain = [&](bool block) -> int {
+        while (ring_tail != ring_head) {
+            const uint32_t i = ring_tail % kRing;
+            if (block) {
+                GP_HIP(hipEventSynchronize(job->a_ev[i]));
+            } else {
+                hipError_t q = hipEventQuery(job->a_ev[i]);
+                if (q == hipErrorNotReady)
+                    break;
+                if (q != hipSuccess)
+                    return hip_fail(q, "hipEventQuery", __FILE__, __LINE__);
+            }
+            const double frac = (double)job->h_count_pinned[4 * i] / (double)ring_units[i];
+            last_frac = frac;
+            // did the grid-wide rounds hand the tail a short list, and how early?
+            const uint32_t took_at = job->h_count_pinned[4 * i + 1];
+            const uint32_t took_len = job->h_count_pinned[4 * i + 2];
+            if (took_len > a.tail_max)
+                want_rounds = std::min<uint32_t>(want_rounds * 2, 64);
+            else if (took_at + 2 < want_rounds && want_rounds > 2)
+                want_rounds--;
+            if (frac < 0.05)
+                scale = std::min<uint64_t>(scale * 4, 1u << 16);
+            else if (frac < 0.15)
+                scale = std::min<uint64_t>(scale * 2, 1u << 16);
+            else if (frac > 0.6 && scale > 1)
+                scale /= 2;
+            ring_tail++;
+        }
+        return GP_OK;
+    };
     for (uint64_t w0 = 0; w0 < job->read_positions;) {
+        int rc = drain(ring_head - ring_tail >= kRing);
+        if (rc != GP_OK)
+            return rc;
         const uint64_t lim = lim0 * scale;
         uint64_t w1 = w0;
         while (bcur + 1 < job->n_batches && batch_pos[bcur + 1] <= w0)
@@ -481,95 +640,87 @@ int stage_a_run(gp_job* job)
         }
         if (w1 == w0) // empty batches at the cursor
             w1 = std::min(job->read_positions, w0 + 1);
-        GP_HIP(hipMemsetAsync(job->d_counts.p, 0, (kMaxRounds + 2) * sizeof(uint32_t), s));
+        GP_HIP(hipMemsetAsync(job->d_counts.p, 0, (want_rounds + 2) * sizeof(uint32_t), s));
+        const uint64_t g0 = gen;
         a.win_start = w0;
         a.win_end = w1;
         a.counts = job->d_counts.p;
         a.resv = nullptr;
-        a.resv_out = job->d_resv.p;
+        a.resv_out = t.resv[0];
         a.tag_cur = 0;
-        gen++; // never share a tag with the previous window's last launch
-        a.tag_next = 0xFFFFFFFFu - gen;
+        a.tag_next = tag_max - g0;
         a.list_in = nullptr;
         a.list_out = job->d_pending[0].p;
         a.round = 0;
         dim3 grid((unsigned)((w1 - w0 + kTile - 1) / kTile), p.n_k);
-        int rc = job->t_first_pass.begin(s, (w1 - w0) * p.n_k);
-        if (rc != GP_OK)
+        if ((rc = job->t_first_pass.begin(s, (w1 - w0) * p.n_k)) != GP_OK)
             return rc;
         hipLaunchKernelGGL(cbf_first_pass, grid, dim3(kBlock), 0, s, a);
         GP_HIP(hipGetLastError());
         if ((rc = job->t_first_pass.end(s)) != GP_OK)
             return rc;
-
-        // rounds: launched in growing chunks, the pending count is read back
-        // after each chunk (a launch on an empty list costs a few microseconds)
-        uint32_t round = 0, chunk = 2;
-        uint64_t rounds_here = 0;
-        uint32_t waiting_first = 0;
-        for (;;) {
-            // every round finishes at least the earliest waiting operation, so this
-            // is a bug trap, not a limit anyone should meet
-            if (rounds_here > (1u << 22)) {
-                set_error("stage A: reservation rounds did not converge");
-                return GP_ERR_STATE;
-            }
-            rounds_here += chunk;
-            if ((rc = job->t_round.begin(s, chunk)) != GP_OK)
-                return rc;
-            for (uint32_t c = 0; c < chunk && round < kMaxRounds; c++, round++) {
-                a.round = round;
-                a.tag_cur = 0xFFFFFFFFu - gen;
-                gen++;
-                a.tag_next = 0xFFFFFFFFu - gen;
-                a.resv = job->d_resv.p + ((uint64_t)(round & 1) << job->resv_bits);
-                a.resv_out = job->d_resv.p + ((uint64_t)((round + 1) & 1) << job->resv_bits);
-                a.list_in = job->d_pending[round & 1].p;
-                a.list_out = job->d_pending[(round + 1) & 1].p;
-                hipLaunchKernelGGL(cbf_round, dim3(kRoundBlocks), dim3(256), 0, s, a);
-            }
-            GP_HIP(hipGetLastError());
-            if ((rc = job->t_round.end(s)) != GP_OK)
-                return rc;
-            GP_HIP(hipMemcpyAsync(job->h_count_pinned, job->d_counts.p + round, sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, s));
-            GP_HIP(hipMemcpyAsync(job->h_count_pinned + 1, job->d_counts.p, sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, s));
-            GP_HIP(hipStreamSynchronize(s));
-            if (rounds_here == chunk)
-                waiting_first = job->h_count_pinned[1];
-            job->counters.a_rounds += chunk;
-            if (*job->h_count_pinned == 0)
-                break;
-            if (round >= kMaxRounds) {
-                // carry the survivors over into a fresh counter array
-                uint32_t left = *job->h_count_pinned;
-                GP_HIP(hipMemsetAsync(job->d_counts.p, 0, (kMaxRounds + 2) * sizeof(uint32_t), s));
-                GP_HIP(hipMemcpyAsync(job->d_counts.p, job->h_count_pinned, sizeof(uint32_t),
-                                      hipMemcpyHostToDevice, s));
-                (void)left;
-                // parity of `round` (even: kMaxRounds is even) keeps list/table roles
-                round = 0;
-            }
-            chunk = std::min<uint32_t>(chunk * 2, 64);
-        }
         {
-            const double frac = (double)waiting_first / (double)((w1 - w0) * p.n_k);
-            if (frac < 0.05)
-                scale = std::min<uint64_t>(scale * 4, 1u << 16);
-            else if (frac < 0.15)
-                scale = std::min<uint64_t>(scale * 2, 1u << 16);
-            else if (frac > 0.6 && scale > 1)
-                scale /= 2;
+            // how much of this window had to wait steers the size of the next ones
+            const uint32_t i = ring_head % kRing;
+            ring_units[i] = (w1 - w0) * p.n_k;
+            ring_slot = i;
         }
+        // a fixed number of grid-wide rounds, then one workgroup finishes the stragglers;
+        // nothing here waits for the device
+        // a saturated filter leaves next to nothing waiting: two small launches are enough
+        const uint32_t rounds_now = std::min<uint32_t>(want_rounds, kMaxRounds - 8);
+        t.n_rounds = rounds_now;
+        if ((rc = job->t_round.begin(s, rounds_now + 1)) != GP_OK)
+            return rc;
+        for (uint32_t round = 0; round < rounds_now; round++) {
+            a.round = round;
+            a.tag_cur = tag_max - (g0 + round);
+            a.tag_next = a.tag_cur - 1;
+            a.resv = t.resv[round & 1];
+            a.resv_out = t.resv[(round + 1) & 1];
+            a.list_in = job->d_pending[round & 1].p;
+            a.list_out = job->d_pending[(round + 1) & 1].p;
+            const unsigned blocks = last_frac < 0.01 ? 256u : (unsigned)kRoundBlocks;
+            hipLaunchKernelGGL(cbf_round, dim3(blocks), dim3(256), 0, s, a);
+        }
+        t.tag_first = tag_max - g0;
+        hipLaunchKernelGGL(cbf_tail, dim3(1), dim3(kTailThreads), 0, s, a, t);
+        GP_HIP(hipGetLastError());
+        if ((rc = job->t_round.end(s)) != GP_OK)
+            return rc;
+        {
+            // feedback for the windows to come, read back without stalling the stream
+            const uint32_t i = ring_slot;
+            GP_HIP(hipMemcpyAsync(job->h_count_pinned + 4 * i, job->d_counts.p, sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, s));
+            GP_HIP(hipMemcpyAsync(job->h_count_pinned + 4 * i + 1, t.info, 2 * sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, s));
+            GP_HIP(hipEventRecord(job->a_ev[i], s));
+            ring_head++;
+        }
+        job->counters.a_rounds += rounds_now + 1;
+        gen = g0 + rounds_now + tail_span + 1;
         w0 = w1;
     }
-    unsigned long long st[3];
+    {
+        int rc = drain(true);
+        if (rc != GP_OK)
+            return rc;
+    }
+    unsigned long long st[4];
+    uint32_t tail_err = 0;
     GP_HIP(hipMemcpyAsync(st, job->d_stats.p, sizeof st, hipMemcpyDeviceToHost, s));
+    GP_HIP(hipMemcpyAsync(&tail_err, job->d_counts.p + kMaxRounds + 1, sizeof tail_err,
+                          hipMemcpyDeviceToHost, s));
     GP_HIP(hipStreamSynchronize(s));
     job->counters.a_positions = st[0];
     job->counters.a_ops = st[1];
     job->counters.a_ordered_ops = st[2];
+    job->counters.a_rounds += st[3];
+    if (tail_err) {
+        set_error("stage A: reservation rounds did not converge");
+        return GP_ERR_STATE;
+    }
     int rc = job->t_first_pass.collect();
     if (rc != GP_OK)
         return rc;
