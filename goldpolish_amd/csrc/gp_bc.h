@@ -28,6 +28,7 @@ struct StageBC {
     DevBuf<uint8_t> batch_skip;
     DevBuf<unsigned long long> bm_site, bm_ok; // stage B bitmaps, one bit per slot position
     DevBuf<uint32_t> n_nodes;           // [n_contigs]
+    DevBuf<uint32_t> flags;             // [n_contigs] classify_kernel: 1 = not plain ACGT, 2 = has a gap char
     DevBuf<uint32_t> tile_contig, tile_first; // output tiles of materialize_kernel
     uint32_t n_tiles = 0;
     std::vector<uint64_t> h_off, h_node_off;
@@ -38,6 +39,9 @@ struct StageBC {
 };
 
 
+// tile-parallel helpers of stage_b.hip that stage C reuses
+int launch_classify(gp_job* job);
+int launch_copy_flagged(gp_job* job, uint32_t reject);
 int stage_c_prepare(gp_job* job);
 void stage_c_release(gp_job* job);
 

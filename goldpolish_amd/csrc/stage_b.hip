@@ -66,6 +66,13 @@ struct WalkArgs {
     unsigned long long* stats;
 };
 
+__device__ inline uint32_t __reduce_or_sync_compat(uint32_t v)
+{
+    for (int o = 32; o > 0; o >>= 1)
+        v |= (uint32_t)__shfl_xor((int)v, o);
+    return v;
+}
+
 // ---------------------------------------------------------------- hashing
 struct HashTab {
     uint64_t f[5], fk[5], r[5], rk[5]; // seeds (index 4 = 0) plain and rotated by k
@@ -1413,6 +1420,92 @@ __global__ void guard_kernel(const uint32_t* batch_begin, uint32_t n_batches,
     batch_skip[b] = (in_bytes > 0 && (out_bytes * 10000ull) / in_bytes < 7500ull) ? 1 : 0;
 }
 
+// One pass over every tile of every live contig: bit 0 of flags[c] = some byte is not
+// upper-case ACGT (the mask rule has work to do), bit 1 = some byte is a Sealer gap
+// character.  Lets the per-contig kernels below skip clean contigs, which are then
+// copied by copy_flagged with the whole chip.
+__device__ inline bool gap_char_b(uint8_t c)
+{
+    switch (c) {
+    case 'N': case 'n': case 'a': case 't': case 'c': case 'g': case 'u': case 'r': case 'y':
+    case 'k': case 'm': case 's': case 'w': case 'b': case 'd': case 'h': case 'v': case 'x':
+        return true;
+    default:
+        return false;
+    }
+}
+
+__global__ __launch_bounds__(256) void classify_kernel(const uint8_t* seq, const uint64_t* off,
+                                                       const uint32_t* len, const uint8_t* dropped,
+                                                       const uint32_t* tile_contig,
+                                                       const uint32_t* tile_first, uint32_t* flags)
+{
+    const uint32_t cid = tile_contig[blockIdx.x];
+    if (dropped[cid])
+        return;
+    const uint32_t n = len[cid];
+    const uint32_t t0 = (blockIdx.x - tile_first[cid]) * kMatTile;
+    if (t0 >= n)
+        return;
+    const uint32_t t1 = min(n, t0 + kMatTile);
+    const uint8_t* s = seq + off[cid];
+    uint32_t f = 0;
+    // kMatTile = 256 lanes x 16 bytes; slots are 1024-byte aligned
+    const uint32_t i0 = t0 + threadIdx.x * 16;
+    if (i0 + 16 <= t1) {
+        const uint4 v = *reinterpret_cast<const uint4*>(s + i0);
+        const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+        for (int q = 0; q < 4; q++)
+            for (int r = 0; r < 4; r++) {
+                const uint8_t ch = (uint8_t)(w[q] >> (8 * r));
+                f |= (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') ? 0u : 1u;
+                f |= gap_char_b(ch) ? 2u : 0u;
+            }
+    } else {
+        for (uint32_t i = i0; i < t1; i++) {
+            const uint8_t ch = s[i];
+            f |= (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') ? 0u : 1u;
+            f |= gap_char_b(ch) ? 2u : 0u;
+        }
+    }
+    // one atomic per wave at most
+    const uint32_t wf = __reduce_or_sync_compat(f);
+    if ((threadIdx.x & 63) == 0 && wf)
+        atomicOr(&flags[cid], wf);
+}
+
+// dst := src for every contig whose flags & reject == 0 (and len >= min_len); per tile
+__global__ __launch_bounds__(256) void copy_flagged(const uint8_t* src, uint8_t* dst,
+                                                    const uint64_t* off, const uint32_t* len,
+                                                    uint32_t* len_next, const uint8_t* dropped,
+                                                    const uint32_t* tile_contig,
+                                                    const uint32_t* tile_first,
+                                                    const uint32_t* flags, uint32_t reject,
+                                                    uint32_t min_len)
+{
+    const uint32_t cid = tile_contig[blockIdx.x];
+    if (dropped[cid] || (flags[cid] & reject))
+        return;
+    const uint32_t n = len[cid];
+    if (n < min_len)
+        return;
+    const uint32_t t0 = (blockIdx.x - tile_first[cid]) * kMatTile;
+    if (t0 == 0 && threadIdx.x == 0)
+        len_next[cid] = n;
+    if (t0 >= n)
+        return;
+    const uint32_t t1 = min(n, t0 + kMatTile);
+    const uint8_t* s = src + off[cid];
+    uint8_t* d = dst + off[cid];
+    const uint32_t i0 = t0 + threadIdx.x * 16;
+    if (i0 + 16 <= t1) {
+        *reinterpret_cast<uint4*>(d + i0) = *reinterpret_cast<const uint4*>(s + i0);
+    } else {
+        for (uint32_t i = i0; i < t1; i++)
+            d[i] = s[i];
+    }
+}
+
 // ---- soft mask (scripts/goldpolish-mask:44-72), one workgroup per contig.
 // The regex ([ACTG]+|[Nn]+|[actgUNMRWSYKVHDBunmrwsykvhdb]+) is a 4-state
 // machine over the bytes; each thread runs it over its own chunk for every
@@ -1468,7 +1561,8 @@ __global__ __launch_bounds__(kMaskThreads) void mask_kernel(const uint8_t* src,
                                                             const uint64_t* off,
                                                             const uint32_t* len_cur, uint8_t* dst,
                                                             uint32_t* len_next,
-                                                            const uint8_t* dropped, uint32_t k)
+                                                            const uint8_t* dropped, uint32_t k,
+                                                            const uint32_t* flags)
 {
     __shared__ uint8_t exit_state[kMaskThreads][4];
     __shared__ uint32_t run_open_len[kMaskThreads][4]; // length of the run still open at chunk end
@@ -1486,40 +1580,10 @@ __global__ __launch_bounds__(kMaskThreads) void mask_kernel(const uint8_t* src,
     const uint32_t len = len_cur[cid];
     const uint8_t* s = src + off[cid];
     uint8_t* d = dst + off[cid];
-    // fast path: a contig of nothing but upper-case ACGT is one run that the rule leaves
-    // alone (or, if shorter than k, lower-cases as a whole); checked with coalesced 16-byte
-    // loads (slots are 1024-byte aligned)
-    {
-        __shared__ uint32_t not_plain;
-        if (tid == 0)
-            not_plain = 0;
-        __syncthreads();
-        uint32_t bad = 0;
-        const uint32_t n16 = len / 16;
-        const uint4* s4 = reinterpret_cast<const uint4*>(s);
-        for (uint32_t i = tid; i < n16 && !bad; i += kMaskThreads) {
-            const uint4 v = s4[i];
-            const uint32_t w[4] = { v.x, v.y, v.z, v.w };
-            for (int q = 0; q < 4; q++)
-                for (int r = 0; r < 4; r++)
-                    bad |= !cls_acgt((uint8_t)(w[q] >> (8 * r)));
-        }
-        for (uint32_t i = n16 * 16 + tid; i < len; i += kMaskThreads)
-            bad |= !cls_acgt(s[i]);
-        if (bad)
-            atomicOr(&not_plain, 1u);
-        __syncthreads();
-        if (!not_plain && len >= k && len > 0) {
-            uint4* d4 = reinterpret_cast<uint4*>(d);
-            for (uint32_t i = tid; i < n16; i += kMaskThreads)
-                d4[i] = s4[i];
-            for (uint32_t i = n16 * 16 + tid; i < len; i += kMaskThreads)
-                d[i] = s[i];
-            if (tid == 0)
-                len_next[cid] = len;
-            return;
-        }
-    }
+    // a contig of nothing but upper-case ACGT, at least k long, is one run that the rule
+    // leaves alone: copy_flagged has already copied it
+    if (!(flags[cid] & 1u) && len >= k && len > 0)
+        return;
     const uint32_t chunk = (len + kMaskThreads - 1) / kMaskThreads;
     const uint32_t b = min(len, tid * chunk), e = min(len, b + chunk);
 
@@ -1786,7 +1850,7 @@ int stage_bc_prepare(gp_job* job)
         (rc = b->batch_skip.alloc(job->n_batches)) != GP_OK ||
         (rc = b->bm_site.alloc(off / 64 + 64)) != GP_OK ||
         (rc = b->bm_ok.alloc(off / 64 + 64)) != GP_OK || (rc = b->n_nodes.alloc(n)) != GP_OK ||
-        (rc = b->tile_first.alloc((size_t)n + 1)) != GP_OK)
+        (rc = b->tile_first.alloc((size_t)n + 1)) != GP_OK || (rc = b->flags.alloc(n)) != GP_OK)
         return rc;
     {
         std::vector<uint32_t> tf((size_t)n + 1), tc;
@@ -1985,14 +2049,55 @@ int stage_mask(gp_job* job)
     int rc = job->t_mask.begin(s, job->n_contigs);
     if (rc != GP_OK)
         return rc;
+    GP_HIP(hipMemsetAsync(b->flags.p, 0, job->n_contigs * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(classify_kernel, dim3(b->n_tiles), dim3(256), 0, s,
+                       (const uint8_t*)b->seq[b->cur].p, (const uint64_t*)b->off.p,
+                       (const uint32_t*)b->len[b->cur].p, (const uint8_t*)b->dropped.p,
+                       (const uint32_t*)b->tile_contig.p, (const uint32_t*)b->tile_first.p,
+                       b->flags.p);
+    hipLaunchKernelGGL(copy_flagged, dim3(b->n_tiles), dim3(256), 0, s,
+                       (const uint8_t*)b->seq[b->cur].p, b->seq[b->cur ^ 1].p,
+                       (const uint64_t*)b->off.p, (const uint32_t*)b->len[b->cur].p,
+                       b->len[b->cur ^ 1].p, (const uint8_t*)b->dropped.p,
+                       (const uint32_t*)b->tile_contig.p, (const uint32_t*)b->tile_first.p,
+                       (const uint32_t*)b->flags.p, 1u, job->prm.k[0]);
     hipLaunchKernelGGL(mask_kernel, dim3(job->n_contigs), dim3(kMaskThreads), 0, s,
                        (const uint8_t*)b->seq[b->cur].p, (const uint64_t*)b->off.p,
                        (const uint32_t*)b->len[b->cur].p, b->seq[b->cur ^ 1].p,
-                       b->len[b->cur ^ 1].p, (const uint8_t*)b->dropped.p, job->prm.k[0]);
+                       b->len[b->cur ^ 1].p, (const uint8_t*)b->dropped.p, job->prm.k[0],
+                       (const uint32_t*)b->flags.p);
     GP_HIP(hipGetLastError());
     if ((rc = job->t_mask.end(s)) != GP_OK)
         return rc;
     b->cur ^= 1;
+    return GP_OK;
+}
+
+int launch_classify(gp_job* job)
+{
+    StageBC* b = job->bc;
+    hipStream_t s = job->ctx->stream;
+    GP_HIP(hipMemsetAsync(b->flags.p, 0, job->n_contigs * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(classify_kernel, dim3(b->n_tiles), dim3(256), 0, s,
+                       (const uint8_t*)b->seq[b->cur].p, (const uint64_t*)b->off.p,
+                       (const uint32_t*)b->len[b->cur].p, (const uint8_t*)b->dropped.p,
+                       (const uint32_t*)b->tile_contig.p, (const uint32_t*)b->tile_first.p,
+                       b->flags.p);
+    GP_HIP(hipGetLastError());
+    return GP_OK;
+}
+
+int launch_copy_flagged(gp_job* job, uint32_t reject)
+{
+    StageBC* b = job->bc;
+    hipStream_t s = job->ctx->stream;
+    hipLaunchKernelGGL(copy_flagged, dim3(b->n_tiles), dim3(256), 0, s,
+                       (const uint8_t*)b->seq[b->cur].p, b->seq[b->cur ^ 1].p,
+                       (const uint64_t*)b->off.p, (const uint32_t*)b->len[b->cur].p,
+                       b->len[b->cur ^ 1].p, (const uint8_t*)b->dropped.p,
+                       (const uint32_t*)b->tile_contig.p, (const uint32_t*)b->tile_first.p,
+                       (const uint32_t*)b->flags.p, reject, 0u);
+    GP_HIP(hipGetLastError());
     return GP_OK;
 }
 

@@ -144,7 +144,7 @@ struct CArgs {
     uint32_t* epoch;
     uint32_t* err;
     unsigned long long* stats; // [4] gaps [5] closed [6] vertex tests
-    uint64_t cap_of_slot;      // unused
+    const uint32_t* flags;     // classify_kernel: bit 1 = the contig holds a gap character
 };
 
 __device__ inline bool is_gap_char(uint8_t c)
@@ -197,32 +197,11 @@ __global__ __launch_bounds__(kGapThreads) void find_gaps(CArgs a)
     }
     const uint32_t len = a.len_cur[cid];
     const uint8_t* s = a.seq + a.off[cid];
-    {
-        // most contigs of a clean assembly hold no gap character at all
-        __shared__ uint32_t any_gap;
+    if (!(a.flags[cid] & 2u)) {
+        // no gap character anywhere (classify_kernel): nothing to seal
         if (tid == 0)
-            any_gap = 0;
-        __syncthreads();
-        uint32_t hit = 0;
-        const uint32_t n16 = len / 16;
-        const uint4* s4 = reinterpret_cast<const uint4*>(s);
-        for (uint32_t i = tid; i < n16 && !hit; i += kGapThreads) {
-            const uint4 v = s4[i];
-            const uint32_t w[4] = { v.x, v.y, v.z, v.w };
-            for (int q = 0; q < 4; q++)
-                for (int r = 0; r < 4; r++)
-                    hit |= is_gap_char((uint8_t)(w[q] >> (8 * r)));
-        }
-        for (uint32_t i = n16 * 16 + tid; i < len; i += kGapThreads)
-            hit |= is_gap_char(s[i]);
-        if (hit)
-            atomicOr(&any_gap, 1u);
-        __syncthreads();
-        if (!any_gap) {
-            if (tid == 0)
-                a.n_gaps[cid] = 0;
-            return;
-        }
+            a.n_gaps[cid] = 0;
+        return;
     }
     const uint32_t chunk = (len + kGapThreads - 1) / kGapThreads;
     const uint32_t b = min(len, tid * chunk), e = min(len, b + chunk);
@@ -1184,8 +1163,8 @@ constexpr int kApplyThreads = 256;
 __global__ __launch_bounds__(kApplyThreads) void apply_fills(CArgs a, uint64_t slot_cap_unused)
 {
     const uint32_t cid = blockIdx.x, tid = threadIdx.x;
-    if (a.dropped[cid])
-        return;
+    if (a.dropped[cid] || !(a.flags[cid] & 2u))
+        return; // gap-free contigs were copied by copy_flagged
     const uint32_t len = a.len_cur[cid];
     const uint8_t* src = a.seq + a.off[cid];
     uint8_t* dst = a.out + a.off[cid];
@@ -1389,6 +1368,7 @@ int stage_c_run(gp_job* job)
     a.epoch = c->epoch.p;
     a.err = b->err.p;
     a.stats = b->stats.p;
+    a.flags = b->flags.p;
 
     GP_HIP(hipMemsetAsync(c->queue.p, 0, 8 * sizeof(uint32_t), s));
     GP_HIP(hipMemsetAsync(c->pool_head.p, 0, sizeof(unsigned long long), s));
@@ -1397,6 +1377,8 @@ int stage_c_run(gp_job* job)
     GP_HIP(hipMemsetAsync(c->pair_last.p, 0, (uint64_t)c->gap_cap * sizeof(uint32_t), s));
     int rc = job->t_bfs.begin(s, job->n_contigs);
     if (rc != GP_OK)
+        return rc;
+    if ((rc = launch_classify(job)) != GP_OK || (rc = launch_copy_flagged(job, 2u)) != GP_OK)
         return rc;
     hipLaunchKernelGGL(find_gaps, dim3(job->n_contigs), dim3(kGapThreads), 0, s, a);
     hipLaunchKernelGGL(prep_gaps, dim3(job->n_contigs), dim3(256), 0, s, a);
