@@ -70,6 +70,26 @@ def test_small_filters_heavy_collisions_and_saturation(gp, oracle):
         run_and_compare(core, ctx, oracle, w, p)
 
 
+def test_byte_counter_fallback_and_wide_thresholds(gp, oracle, monkeypatch):
+    """optional 4-bit packed counters (GP_STAGE_A_NIBBLE=1); thresholds above 15 use bytes"""
+    core, ctx = gp
+    w = synth.make_workload([12000, 7000], 25, seed=15)
+    monkeypatch.setenv("GP_STAGE_A_NIBBLE", "1")
+    run_and_compare(core, ctx, oracle, w, core.default_params(k_values=[32, 24]))
+    # 8 k values and kmer_threshold 13: thresholds 11..18 do not fit a nibble
+    w.kmer_threshold[:] = 13
+    p = core.default_params(k_values=[32, 30, 28, 26, 24, 22, 20, 18], cbf_bytes=200_000,
+                            bf_bytes=1 << 16)
+    run_and_compare(core, ctx, oracle, w, p)
+    # many repeats so that counters really climb to 14 in nibble mode
+    rng = np.random.default_rng(3)
+    g = synth.random_genome(3000, rng).tobytes()
+    w2 = _custom_workload([g], [[g] * 40], [13])
+    run_and_compare(core, ctx, oracle, w2, core.default_params())
+    monkeypatch.delenv("GP_STAGE_A_NIBBLE")
+    run_and_compare(core, ctx, oracle, w2, core.default_params())
+
+
 def test_many_windows(gp, oracle, monkeypatch):
     core, ctx = gp
     monkeypatch.setenv("GP_STAGE_A_WINDOW", "4096")
