@@ -45,6 +45,20 @@ def algorithmic_bytes_per_bp(n_k, hash_num, coverage):
     return coverage * (1 + n_k * 2 * hash_num) + 6 * n_k + 2
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command, see
+    tools/make_profiles.sh; FETCH_SIZE calibrated 1:1 on classify_kernel's 16 B/lane stream)."""
+    files = sorted((ROOT / "profiles").glob("r*_config2_pmc_traffic.json"))
+    if not files:
+        return None, None
+    t = json.loads(files[-1].read_text()).get("gp::" + kernel)
+    if not t or "FETCH_SIZE" not in t or "WRITE_SIZE" not in t:
+        return None, None
+    per_launch = (t["FETCH_SIZE"]["per_launch_KB"] + t["WRITE_SIZE"]["per_launch_KB"]) * 1024
+    return int(per_launch), f"profiles/{files[-1].name}"
+
+
 def gather_to_rank0(seqs, rank, world, backend):
     """Variable-length gather of the polished contigs on rank 0 (no other collective)."""
     import torch
@@ -202,10 +216,12 @@ def main():
             achieved = bytes_per_launch / avg_s / 1e9
         else:
             bytes_per_launch, achieved = 0, 0.0
+        traffic, traffic_src = pmc_traffic("cbf_first_pass")
         line["roofline"] = {
             "bound": "hbm", "kernel": "cbf_first_pass", "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": None, "alg_bytes_per_launch": int(bytes_per_launch),
+            "traffic": traffic, "traffic_source": traffic_src,
+            "alg_bytes_per_launch": int(bytes_per_launch),
             "avg_launch_ms": round(fp["ms"] / max(fp["launches"], 1), 4),
             "largest_by_time": dom,
             "whole_path_alg_GBps": round(
