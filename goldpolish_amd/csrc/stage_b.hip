@@ -120,6 +120,12 @@ struct Shared {
     uint32_t need_hash;       // the walker jumped: hash of the current k-mer must be rebuilt
     uint32_t fast_head;       // window can be read straight from the contig at S.hi
     uint32_t confirmed;       // the bitmap already did the confirm step for this site
+    uint32_t nc_idx[2];       // tiny cache of the node list (thread 0 only): indices ...
+    Node nc_node[2];          // ... and copies; dropped whenever the list is edited
+    uint32_t nc_next;
+    // site window as prefix XORs of rotated seeds: any k-mer hash of the window in O(1)
+    uint64_t PF[2 * kMaxK + 16], QR[2 * kMaxK + 16];
+    uint64_t wave_f[kWalkThreads / 64], wave_r[kWalkThreads / 64];
     int32_t request;
     uint32_t nz;              // chars available in Z
     uint32_t scan_j0, scan_n; // first k-mer index / number of k-mers of the scan
@@ -216,6 +222,44 @@ __device__ inline void nd_put(const Ctx& c, Shared& S, uint32_t i, Node n)
     } else {
         atomicOr(c.a->err, 1u); // node list overflow
     }
+}
+
+// thread 0's view of the node list through a two-entry cache (head node, tail node)
+__device__ inline Node nd_cached(const Ctx& c, Shared& S, uint32_t i)
+{
+    if (S.nc_idx[0] == i)
+        return S.nc_node[0];
+    if (S.nc_idx[1] == i)
+        return S.nc_node[1];
+    Node n = nd_get(c, S, i);
+    const uint32_t slot = S.nc_next & 1u;
+    S.nc_next++;
+    S.nc_idx[slot] = i;
+    S.nc_node[slot] = n;
+    return n;
+}
+
+__device__ inline void nd_cache_drop(Shared& S) { S.nc_idx[0] = S.nc_idx[1] = 0xFFFFFFFEu; }
+
+// inverse of sroln
+__device__ inline uint64_t srorn(uint64_t x, uint32_t n)
+{
+    uint64_t hi = x >> 33, lo = x & 0x1FFFFFFFFULL;
+    const uint32_t a = n % 31u, b = n % 33u;
+    hi = ((hi >> a) | (hi << (31u - a))) & 0x7FFFFFFFULL;
+    lo = ((lo >> b) | (lo << (33u - b))) & 0x1FFFFFFFFULL;
+    return (hi << 33) | lo;
+}
+
+// hashes of the k-mer Z[a .. a+k) from the prefix arrays
+__device__ inline uint64_t win_f(const Shared& S, uint32_t a, uint32_t k)
+{
+    return sroln(S.PF[a + k] ^ S.PF[a], a + k - 1);
+}
+
+__device__ inline uint64_t win_r(const Shared& S, uint32_t a, uint32_t k)
+{
+    return srorn(S.QR[a + k] ^ S.QR[a], a);
 }
 
 __device__ inline uint8_t get_char(const Ctx& c, uint32_t pos, const Node& n)
@@ -494,7 +538,9 @@ __device__ void make_edit(const Ctx& c, Shared& S, uint8_t draft, Best& b)
 {
     const HashTab& ht = S.ht;
     const uint32_t k = c.k;
-    Node tnode = nd_get(c, S, S.tn);
+    Node tnode = nd_cached(c, S, S.tn);
+    if (b.type == 2 || b.type == 3 || tnode.type != 0)
+        nd_cache_drop(S); // the node list is about to change
     switch (b.type) {
     case 1:
         if (tnode.type == 0)
@@ -782,6 +828,8 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
         S.need_hash = 0;
         S.fast_head = 0;
         S.confirmed = 0;
+        S.nc_next = 0;
+        nd_cache_drop(S);
         if (hi + k - 1 < len) {
             hash_kmer(S.ht, c.seq + hi, k, S.fh, S.rh);
             S.char_in = c.seq[S.ti];
@@ -802,7 +850,7 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
         }
         // ---------------- thread 0: decide how to reach the next untested k-mer
         if (tid == 0 && S.request == REQ_NEXT) {
-            Node tnode = nd_get(c, S, S.tn);
+            Node tnode = nd_cached(c, S, S.tn);
             const bool plain = tnode.type == 0 && tnode.e == len - 1 && S.ti <= tnode.e;
             const bool clean = plain && S.hn == S.tn && S.hi >= S.clean_from && a.bm_site != nullptr;
             if (clean) {
@@ -853,7 +901,6 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
                     if (ok && missing >= a.need_missing) {
                         S.hi = cand;
                         S.ti = cand + k - 1;
-                        S.char_in = c.seq[S.ti];
                         S.cur_tested = 1;
                         S.need_hash = 1;
                         S.confirmed = 1;
@@ -870,7 +917,7 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
                 S.request = next_req;
             } else if (plain) {
                 // scan: current k-mer chars via the cursor, lookahead straight from the contig
-                Node hnode = nd_get(c, S, S.hn);
+                Node hnode = nd_cached(c, S, S.hn);
                 S.fast_head = (hnode.type == 0 && S.hi + k - 1 <= hnode.e) ? 1u : 0u;
                 uint32_t got = S.fast_head ? k : gather(c, S, S.Z, k);
                 if (got < k) {
@@ -1000,7 +1047,7 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
                     if (!is_accepted_u(S.Z[i]))
                         S.min_tested_ti = max(S.min_tested_ti, ti0 + 1 + (i - k) + k);
                 {
-                    Node hnode = nd_get(c, S, S.hn);
+                    Node hnode = nd_cached(c, S, S.hn);
                     if (hnode.type == 0 && S.hi + dest <= hnode.e) {
                         S.hi += dest;
                     } else {
@@ -1026,7 +1073,7 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
         // ------------------------------------------------------------ REQ_SITE
         if (tid == 0) {
             const uint32_t want = 2 * k + 12;
-            Node hnode = nd_get(c, S, S.hn);
+            Node hnode = nd_cached(c, S, S.hn);
             const bool in_final = hnode.type == 0 && hnode.e == len - 1 && S.hi <= hnode.e;
             const bool inside = hnode.type == 0 && S.hi + want - 1 <= hnode.e;
             if (in_final || inside) {
@@ -1047,22 +1094,48 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
                 S.Z[i] = c.seq[S.hi + i];
             __syncthreads();
         }
-        if (f_hash) {
-            // hash of Z[0..k) as an XOR of k independently rotated seeds, reduced by one wave
-            if (tid < 64) {
-                uint64_t f = 0, r = 0;
-                if (tid < k) {
-                    f = sroln(S.ht.f[fcode(S.Z[tid])], k - 1 - tid);
-                    r = sroln(S.ht.r[rcode(S.Z[tid])], tid);
+        {
+            // prefix XORs of the rotated seeds of the whole window (one element per lane):
+            // PF[i] = xor_{j<i} ror^j(fwd(Z_j)), QR[i] = xor_{j<i} rol^j(rev(Z_j))
+            const uint32_t nzz = S.nz;
+            uint64_t tf = 0, tr = 0;
+            if (tid < nzz) {
+                tf = srorn(S.ht.f[fcode(S.Z[tid])], tid);
+                tr = sroln(S.ht.r[rcode(S.Z[tid])], tid);
+            }
+            const int lane = tid & 63, wave = tid >> 6;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint64_t uf = __shfl_up(tf, o), ur = __shfl_up(tr, o);
+                if (lane >= o) {
+                    tf ^= uf;
+                    tr ^= ur;
                 }
-                for (int o = 32; o > 0; o >>= 1) {
-                    f ^= __shfl_xor(f, o);
-                    r ^= __shfl_xor(r, o);
-                }
-                if (tid == 0) {
-                    S.fh = f;
-                    S.rh = r;
-                }
+            }
+            if (lane == 63) {
+                S.wave_f[wave] = tf;
+                S.wave_r[wave] = tr;
+            }
+            __syncthreads();
+            uint64_t pf = 0, pr = 0;
+            for (int w = 0; w < wave; w++) {
+                pf ^= S.wave_f[w];
+                pr ^= S.wave_r[w];
+            }
+            if (tid < nzz) {
+                S.PF[tid + 1] = tf ^ pf;
+                S.QR[tid + 1] = tr ^ pr;
+            }
+            if (tid == 0) {
+                S.PF[0] = 0;
+                S.QR[0] = 0;
+            }
+            __syncthreads();
+            if (f_hash && tid == 0) {
+                // the walker jumped here: rebuild its rolling state from the window
+                S.fh = win_f(S, 0, k);
+                S.rh = win_r(S, 0, k);
+                S.char_in = S.Z[k - 1];
+                S.draft = to_upper(S.Z[k - 1]);
             }
             __syncthreads();
         }
@@ -1077,11 +1150,8 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
                     bad = 1;
             }
             bad = block_sum(S, bad);
-            if (!bad && tid < k && tid % jump == 0) {
-                uint64_t fh, rh;
-                hash_kmer(S.ht, S.Z + tid + 1, k, fh, rh);
-                miss = bf_contains(a, c.bf, fh + rh) ? 0u : 1u;
-            }
+            if (!bad && tid < k && tid % jump == 0)
+                miss = bf_contains(a, c.bf, win_f(S, tid + 1, k) + win_r(S, tid + 1, k)) ? 0u : 1u;
             miss = block_sum(S, miss);
             if (tid == 0) {
                 S.confirm_bad = bad;
@@ -1143,16 +1213,13 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
                     if (bf_contains(a, c.bf, fh + rh))
                         S.sub_in_bf[si] = 1;
                 } else if (q < k && q % jump == 0 && k + q < S.nz) {
-                    // k-mer = Z[q+1 .. q+1+k) with Z[k-1] replaced by sb
-                    uint64_t f = 0, r = 0;
-                    const uint8_t* z = S.Z + q + 1;
-                    const uint32_t at = k - 1 - (q + 1); // index of the site inside this k-mer
-                    for (uint32_t i = 0; i < k; i++) {
-                        uint8_t cf = (i == at) ? sb : z[i];
-                        uint32_t ir = k - 1 - i;
-                        uint8_t cr = (ir == at) ? sb : z[ir];
-                        f = srol1(f) ^ S.ht.f[fcode(cf)];
-                        r = srol1(r) ^ S.ht.r[rcode(cr)];
+                    // k-mer = Z[q+1 .. q+1+k) with Z[k-1] replaced by sb: O(1) from the prefixes
+                    const uint32_t a0 = q + 1, site = k - 1;
+                    uint64_t f = win_f(S, a0, k), r = win_r(S, a0, k);
+                    if (a0 <= site) {
+                        const uint8_t old_c = S.Z[site];
+                        f ^= sroln(S.ht.f[fcode(old_c)] ^ S.ht.f[fcode(sb)], (a0 + k - 1) - site);
+                        r ^= sroln(S.ht.r[rcode(old_c)] ^ S.ht.r[rcode(sb)], site - a0);
                     }
                     if (bf_contains(a, c.bf, f + r))
                         atomicAdd(&S.sub_present[si], 1u);
@@ -1172,11 +1239,13 @@ __global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
                 continue;
             if (tid == 0) {
                 // trial + revert leaves the UPPER-case draft base behind (:1608-1615)
-                Node tnode = nd_get(c, S, S.tn);
-                if (tnode.type == 0)
+                Node tnode = nd_cached(c, S, S.tn);
+                if (tnode.type == 0) {
                     c.seq[S.ti] = (uint8_t)S.draft;
-                else if (tnode.type == 1)
+                } else if (tnode.type == 1) {
                     c.nd[S.tn].c = S.draft;
+                    nd_cache_drop(S);
+                }
                 S.st_probes += 1 + (k + jump - 1) / jump;
             }
             const uint32_t present = S.sub_present[si];
