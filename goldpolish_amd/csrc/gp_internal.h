@@ -114,12 +114,14 @@ struct gp_job {
     // ---- stage A work buffers
     gp::DevBuf<unsigned long long> d_resv; // reservation slots (hashed), (tag << 32) | position
     uint32_t resv_bits = 0;
-    gp::DevBuf<uint4> d_pending[2];       // {hash lo, hash hi, pos, meta}
+    gp::DevBuf<uint4> d_pending[4];       // [set][list] of {hash lo, hash hi, pos, meta},{idx x4}
     gp::DevBuf<uint32_t> d_counts;        // [kMaxRounds+2] pending count per round
     gp::DevBuf<unsigned long long> d_stats; // device-side gp_counters
     uint64_t window = 0;
     uint32_t* h_count_pinned = nullptr;
     hipEvent_t a_ev[16] = {};
+    hipEvent_t a_ev_fp[2] = {}, a_ev_tail[2] = {}, a_ev_init = nullptr;
+    hipStream_t a_stream2 = nullptr;
 
     // ---- stage B/C state (see stage_b.hip / stage_c.hip)
     gp::StageBC* bc = nullptr;

@@ -491,23 +491,31 @@ int stage_a_prepare(gp_job* job)
         return GP_ERR_INVALID_ARG;
     }
     int rc;
-    for (int i = 0; i < 2; i++)
-        if ((rc = job->d_pending[i].alloc(2 * max_pending)) != GP_OK) // two uint4 per record
+    // two sets (windows alternate between them so that the first pass of window w+1 can
+    // run beside the rounds of window w), two lists per set, two uint4 per record
+    for (int i = 0; i < 4; i++)
+        if ((rc = job->d_pending[i].alloc(2 * max_pending)) != GP_OK)
             return rc;
     // reservation slots: two per possible waiting counter touch, power of two, <= 1 GiB
     uint32_t bits = 16;
     while ((1ull << bits) < max_pending * p.hash_num * 2 && bits < 26)
         bits++;
     job->resv_bits = bits;
-    if ((rc = job->d_resv.alloc(2ull << bits)) != GP_OK) // two tables
+    if ((rc = job->d_resv.alloc(4ull << bits)) != GP_OK) // two tables per set
         return rc;
-    if ((rc = job->d_counts.alloc(kMaxRounds + 2)) != GP_OK)
+    if ((rc = job->d_counts.alloc(2 * (kMaxRounds + 2))) != GP_OK)
         return rc;
     if ((rc = job->d_stats.alloc(16)) != GP_OK)
         return rc;
     GP_HIP(hipHostMalloc((void**)&job->h_count_pinned, 256));
     for (uint32_t i = 0; i < kRing; i++)
         GP_HIP(hipEventCreateWithFlags(&job->a_ev[i], hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) {
+        GP_HIP(hipEventCreateWithFlags(&job->a_ev_fp[i], hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&job->a_ev_tail[i], hipEventDisableTiming));
+    }
+    GP_HIP(hipEventCreateWithFlags(&job->a_ev_init, hipEventDisableTiming));
+    GP_HIP(hipStreamCreateWithFlags(&job->a_stream2, hipStreamNonBlocking));
     return GP_OK;
 }
 
@@ -519,6 +527,16 @@ void stage_a_release(gp_job* job)
     for (uint32_t i = 0; i < kRing; i++)
         if (job->a_ev[i])
             (void)hipEventDestroy(job->a_ev[i]);
+    for (int i = 0; i < 2; i++) {
+        if (job->a_ev_fp[i])
+            (void)hipEventDestroy(job->a_ev_fp[i]);
+        if (job->a_ev_tail[i])
+            (void)hipEventDestroy(job->a_ev_tail[i]);
+    }
+    if (job->a_ev_init)
+        (void)hipEventDestroy(job->a_ev_init);
+    if (job->a_stream2)
+        (void)hipStreamDestroy(job->a_stream2);
 }
 
 int stage_a_run(gp_job* job)
@@ -569,8 +587,12 @@ int stage_a_run(gp_job* job)
                           std::min<uint64_t>(job->d_cbf.n, (uint64_t)job->n_batches * p.n_k * a.cbf_stride + 8), s));
     GP_HIP(hipMemsetAsync(job->d_bf.p, 0, job->d_bf.n * sizeof(uint32_t), s));
     GP_HIP(hipMemsetAsync(job->d_stats.p, 0, 16 * sizeof(unsigned long long), s));
-    GP_HIP(hipMemsetAsync(job->d_counts.p, 0, (kMaxRounds + 2) * sizeof(uint32_t), s));
+    GP_HIP(hipMemsetAsync(job->d_counts.p, 0, 2 * (kMaxRounds + 2) * sizeof(uint32_t), s));
     GP_HIP(hipMemsetAsync(job->d_resv.p, 0xFF, job->d_resv.n * sizeof(unsigned long long), s));
+    // stream `s` runs the first passes, stream `s2` the rounds and tails
+    hipStream_t s2 = job->a_stream2;
+    GP_HIP(hipEventRecord(job->a_ev_init, s));
+    GP_HIP(hipStreamWaitEvent(s2, job->a_ev_init, 0));
 
     if (job->read_positions == 0 || job->n_contigs == 0) {
         job->filters_ready = true;
@@ -594,15 +616,11 @@ int stage_a_run(gp_job* job)
     a.tail_from = 2;
     a.tail_max = (uint32_t)env_u64("GP_STAGE_A_TAIL", 4096);
     TailArgs t{};
-    t.list[0] = job->d_pending[0].p;
-    t.list[1] = job->d_pending[1].p;
-    t.resv[0] = job->d_resv.p;
-    t.resv[1] = job->d_resv.p + (1ull << job->resv_bits);
     t.n_rounds = n_rounds;
     t.max_rounds = (uint32_t)tail_span - 16;
-    t.err = job->d_counts.p + kMaxRounds + 1; // last word of the counter array doubles as a flag
-    t.info = job->d_counts.p + kMaxRounds - 2;
+    t.err = job->d_counts.p + kMaxRounds + 1; // last word of set 0's counter array is a flag
     t.stats = job->d_stats.p;
+    uint64_t wi = 0; // window index; its parity picks the buffer set
     uint64_t scale = 1, gen = 1;
     uint32_t bcur = 0;
     double last_frac = 1.0; // waiting fraction of the most recent window we know about
@@ -658,17 +676,27 @@ int stage_a_run(gp_job* job)
         }
         if (w1 == w0) // empty batches at the cursor
             w1 = std::min(job->read_positions, w0 + 1);
-        GP_HIP(hipMemsetAsync(job->d_counts.p, 0, (want_rounds + 2) * sizeof(uint32_t), s));
+        const uint32_t set = (uint32_t)(wi & 1);
+        uint32_t* counts = job->d_counts.p + set * (kMaxRounds + 2);
+        t.list[0] = job->d_pending[2 * set].p;
+        t.list[1] = job->d_pending[2 * set + 1].p;
+        t.resv[0] = job->d_resv.p + ((uint64_t)(2 * set) << job->resv_bits);
+        t.resv[1] = job->d_resv.p + ((uint64_t)(2 * set + 1) << job->resv_bits);
+        t.info = counts + kMaxRounds - 2;
+        // this set's buffers were last used by window wi-2: wait for its tail
+        if (wi >= 2)
+            GP_HIP(hipStreamWaitEvent(s, job->a_ev_tail[set], 0));
+        GP_HIP(hipMemsetAsync(counts, 0, (want_rounds + 2) * sizeof(uint32_t), s));
         const uint64_t g0 = gen;
         a.win_start = w0;
         a.win_end = w1;
-        a.counts = job->d_counts.p;
+        a.counts = counts;
         a.resv = nullptr;
         a.resv_out = t.resv[0];
         a.tag_cur = 0;
         a.tag_next = tag_max - g0;
         a.list_in = nullptr;
-        a.list_out = job->d_pending[0].p;
+        a.list_out = t.list[0];
         a.round = 0;
         dim3 grid((unsigned)((w1 - w0 + kTile - 1) / kTile), p.n_k);
         if ((rc = job->t_first_pass.begin(s, (w1 - w0) * p.n_k)) != GP_OK)
@@ -677,18 +705,18 @@ int stage_a_run(gp_job* job)
         GP_HIP(hipGetLastError());
         if ((rc = job->t_first_pass.end(s)) != GP_OK)
             return rc;
+        GP_HIP(hipEventRecord(job->a_ev_fp[set], s));
         {
-            // how much of this window had to wait steers the size of the next ones
             const uint32_t i = ring_head % kRing;
             ring_units[i] = (w1 - w0) * p.n_k;
             ring_slot = i;
         }
-        // a fixed number of grid-wide rounds, then one workgroup finishes the stragglers;
-        // nothing here waits for the device
-        // a saturated filter leaves next to nothing waiting: two small launches are enough
+        // Rounds and tail on the second stream: they need this window's first pass and, by
+        // stream order, the previous window's tail.  Nothing here waits for the device.
+        GP_HIP(hipStreamWaitEvent(s2, job->a_ev_fp[set], 0));
         const uint32_t rounds_now = std::min<uint32_t>(want_rounds, kMaxRounds - 8);
         t.n_rounds = rounds_now;
-        if ((rc = job->t_round.begin(s, rounds_now + 1)) != GP_OK)
+        if ((rc = job->t_round.begin(s2, rounds_now + 1)) != GP_OK)
             return rc;
         for (uint32_t round = 0; round < rounds_now; round++) {
             a.round = round;
@@ -696,26 +724,28 @@ int stage_a_run(gp_job* job)
             a.tag_next = a.tag_cur - 1;
             a.resv = t.resv[round & 1];
             a.resv_out = t.resv[(round + 1) & 1];
-            a.list_in = job->d_pending[round & 1].p;
-            a.list_out = job->d_pending[(round + 1) & 1].p;
+            a.list_in = t.list[round & 1];
+            a.list_out = t.list[(round + 1) & 1];
             const unsigned blocks = last_frac < 0.01 ? 256u : (unsigned)kRoundBlocks;
-            hipLaunchKernelGGL(cbf_round, dim3(blocks), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(cbf_round, dim3(blocks), dim3(256), 0, s2, a);
         }
         t.tag_first = tag_max - g0;
-        hipLaunchKernelGGL(cbf_tail, dim3(1), dim3(kTailThreads), 0, s, a, t);
+        hipLaunchKernelGGL(cbf_tail, dim3(1), dim3(kTailThreads), 0, s2, a, t);
         GP_HIP(hipGetLastError());
-        if ((rc = job->t_round.end(s)) != GP_OK)
+        if ((rc = job->t_round.end(s2)) != GP_OK)
             return rc;
+        GP_HIP(hipEventRecord(job->a_ev_tail[set], s2));
         {
-            // feedback for the windows to come, read back without stalling the stream
+            // feedback for the windows to come, read back without stalling anything
             const uint32_t i = ring_slot;
-            GP_HIP(hipMemcpyAsync(job->h_count_pinned + 4 * i, job->d_counts.p, sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, s));
+            GP_HIP(hipMemcpyAsync(job->h_count_pinned + 4 * i, counts, sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, s2));
             GP_HIP(hipMemcpyAsync(job->h_count_pinned + 4 * i + 1, t.info, 2 * sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, s));
-            GP_HIP(hipEventRecord(job->a_ev[i], s));
+                                  hipMemcpyDeviceToHost, s2));
+            GP_HIP(hipEventRecord(job->a_ev[i], s2));
             ring_head++;
         }
+        wi++;
         job->counters.a_rounds += rounds_now + 1;
         gen = g0 + rounds_now + tail_span + 1;
         w0 = w1;
@@ -725,6 +755,9 @@ int stage_a_run(gp_job* job)
         if (rc != GP_OK)
             return rc;
     }
+    // the rest of the pipeline (stream `s`) continues behind the last tail
+    GP_HIP(hipEventRecord(job->a_ev_init, s2));
+    GP_HIP(hipStreamWaitEvent(s, job->a_ev_init, 0));
     unsigned long long st[4];
     uint32_t tail_err = 0;
     GP_HIP(hipMemcpyAsync(st, job->d_stats.p, sizeof st, hipMemcpyDeviceToHost, s));
