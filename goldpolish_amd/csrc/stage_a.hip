@@ -609,7 +609,7 @@ int stage_a_run(gp_job* job)
     for (uint32_t bi = 0; bi < job->n_batches; bi++)
         batch_pos[bi] = job->h_seg_start[job->h_batch_contig_begin[bi]];
     batch_pos[job->n_batches] = job->read_positions;
-    const uint64_t load_div = std::max<uint64_t>(1, env_u64("GP_STAGE_A_LOAD_DIV", 4));
+    const uint64_t load_div = std::max<uint64_t>(1, env_u64("GP_STAGE_A_LOAD_DIV", 6));
     const uint64_t lim0 = std::max<uint64_t>(kTile, p.cbf_bytes / (load_div * p.hash_num));
     const uint32_t n_rounds = (uint32_t)std::min<uint64_t>(env_u64("GP_STAGE_A_ROUNDS", 6), kMaxRounds);
     const uint64_t tag_max = (1ull << 40) - 1, tail_span = 1ull << 22;
@@ -646,9 +646,11 @@ int stage_a_run(gp_job* job)
             const uint32_t took_at = job->h_count_pinned[4 * i + 1];
             const uint32_t took_len = job->h_count_pinned[4 * i + 2];
             if (took_len > a.tail_max)
-                want_rounds = std::min<uint32_t>(want_rounds * 2, 64);
-            else if (took_at + 2 < want_rounds && want_rounds > 2)
-                want_rounds--;
+                want_rounds = std::min<uint32_t>(want_rounds * 2, 512);
+            if (took_len > 16 * a.tail_max && scale > 1)
+                scale /= 2; // the single-workgroup tail got far too much: smaller windows
+            else
+                want_rounds = std::max<uint32_t>(2, std::min<uint32_t>(want_rounds, took_at + 2));
             if (frac < 0.05)
                 scale = std::min<uint64_t>(scale * 4, 1u << 16);
             else if (frac < 0.15)
@@ -664,12 +666,17 @@ int stage_a_run(gp_job* job)
         if (rc != GP_OK)
             return rc;
         const uint64_t lim = lim0 * scale;
+        // never queue more waiting operations than the grid-wide rounds can bring down to a
+        // short list: about 3 M per window, judged by the waiting fraction seen last
+        const uint64_t wmax = std::min<uint64_t>(
+            job->window,
+            std::max<uint64_t>(kTile, (uint64_t)(3.0e6 / ((double)p.n_k * std::max(last_frac, 0.02)))));
         uint64_t w1 = w0;
         while (bcur + 1 < job->n_batches && batch_pos[bcur + 1] <= w0)
             bcur++;
-        for (uint32_t bi = bcur; w1 < job->read_positions && w1 - w0 < job->window; bi++) {
+        for (uint32_t bi = bcur; w1 < job->read_positions && w1 - w0 < wmax; bi++) {
             const uint64_t b_end = batch_pos[bi + 1];
-            const uint64_t take = std::min({ b_end - w1, lim, job->window - (w1 - w0) });
+            const uint64_t take = std::min({ b_end - w1, lim, wmax - (w1 - w0) });
             w1 += take;
             if (w1 < b_end)
                 break;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # sweep stage A window load (GP_STAGE_A_LOAD_DIV) on both bench workloads
-for d in 1 2 3 4 6 8; do
+for d in 1 3 6 10; do
   for wl in config2 goldenpath; do
     GP_STAGE_A_LOAD_DIV=$d python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-aux --workload $wl 2>/dev/null | python3 -c "
 import sys,json
