@@ -323,7 +323,7 @@ int gp_job_create(gp_ctx* ctx, const gp_params* params, const gp_batch_set* set,
 
     // ---- filters
     const uint64_t streams = (uint64_t)set->n_batches * params->n_k;
-    if ((rc = j->d_cbf.alloc(streams * params->cbf_bytes)) != GP_OK ||
+    if ((rc = j->d_cbf.alloc(streams * ((params->cbf_bytes + 15) / 16 * 16) + 64)) != GP_OK ||
         (rc = j->d_bf.alloc(streams * (params->bf_bytes / 4))) != GP_OK)
         return fail(rc);
     if ((rc = stage_a_prepare(j)) != GP_OK)

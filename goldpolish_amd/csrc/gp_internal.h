@@ -115,6 +115,7 @@ struct gp_job {
     gp::DevBuf<unsigned long long> d_resv; // reservation slots (hashed), (tag << 32) | position
     uint32_t resv_bits = 0;
     gp::DevBuf<uint4> d_pending[4];       // [set][list] of {hash lo, hash hi, pos, meta},{idx x4}
+    gp::DevBuf<uint32_t> d_sat, d_batch_thr_max; // saturation flags per (batch, k); max threshold per batch
     gp::DevBuf<uint32_t> d_counts;        // [kMaxRounds+2] pending count per round
     gp::DevBuf<unsigned long long> d_stats; // device-side gp_counters
     uint64_t window = 0;

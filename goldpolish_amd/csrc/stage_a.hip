@@ -68,6 +68,8 @@ struct AArgs {
     unsigned long long* resv_out;  // table this launch reserves in
     uint64_t tag_cur;    // 40-bit tag the incoming list reserved with
     uint64_t tag_next;   // tag for reservations made by this launch (always smaller: newer wins)
+    uint32_t* sat;       // per (batch, k): bit 0 = every counter >= max thr-1, bit 1 = filter all ones
+    const uint32_t* batch_thr_max; // per batch: largest kmer_threshold of its contigs
     uint32_t tail_from;  // first round the tail kernel may take over (see cbf_tail)
     uint32_t tail_max;   // lists up to this long are left to the tail kernel
     uint32_t resv_bits;
@@ -238,6 +240,19 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
             const uint64_t base = fh + rh;
             uint32_t idx[kMaxHash];
             n_ops++;
+            // a saturated filter pair answers for itself: every counter is already high enough
+            // for any k-mer to go in, and every bit it could set is set (cbf_check_sat)
+            const uint32_t sat = a.sat[stream];
+            if (sat == 3u)
+                continue;
+            if (sat & 1u) {
+                uint64_t hv[kMaxHash];
+                hv[0] = base;
+                for (uint32_t i = 1; i < a.hash_num; i++)
+                    hv[i] = ext_hash(base, k, i);
+                bf_insert(a, stream, hv);
+                continue;
+            }
             if (try_settle(a, stream, thr, k, base, idx))
                 continue;
             n_ordered++;
@@ -255,6 +270,77 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
     __syncthreads();
     if (threadIdx.x < 3 && s_stats[threadIdx.x])
         atomicAdd(&a.stats[threadIdx.x], s_stats[threadIdx.x]);
+}
+
+// Has a (batch, k) filter pair stopped changing?  Counters only matter through "is the
+// minimum >= thr-1", so once every counter is >= thr-1 (for the largest threshold any contig
+// of the batch uses) every later operation settles; once every bit of the Bloom filter is
+// set, inserting is a no-op.  One workgroup per stream of the window; flags only ever go
+// from 0 to 1, so a first pass that reads them late loses nothing but time.
+__global__ __launch_bounds__(1024) void cbf_check_sat(AArgs a, uint32_t stream0)
+{
+    __shared__ uint32_t bad_c, bad_b;
+    const uint32_t stream = stream0 + blockIdx.x;
+    uint32_t cur = a.sat[stream];
+    if (cur == 3u)
+        return;
+    if (threadIdx.x == 0)
+        bad_c = bad_b = 0;
+    __syncthreads();
+    const uint32_t batch = stream / a.n_k, ki = stream % a.n_k;
+    const uint32_t need = a.batch_thr_max[batch] - 2 + ki - 1; // thr - 1
+    if (!(cur & 1u)) {
+        const uint8_t* cb = a.cbf + (uint64_t)stream * a.cbf_stride;
+        uint32_t bad = 0;
+        if (a.nib) {
+            const uint64_t nbytes = a.cbf_bytes / 2; // whole bytes; an odd last counter below
+            const uint64_t n16 = nbytes / 16;
+            const uint4* p4 = reinterpret_cast<const uint4*>(cb);
+            for (uint64_t i = threadIdx.x; i < n16 && !bad; i += blockDim.x) {
+                const uint4 v = p4[i];
+                const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+                for (int q = 0; q < 4; q++)
+                    for (int r = 0; r < 8; r++)
+                        bad |= ((w[q] >> (4 * r)) & 15u) < need;
+            }
+            for (uint64_t i = n16 * 16 + threadIdx.x; i < nbytes; i += blockDim.x)
+                bad |= ((cb[i] & 15u) < need) | ((uint32_t)(cb[i] >> 4) < need);
+            if (threadIdx.x == 0 && (a.cbf_bytes & 1))
+                bad |= (cb[nbytes] & 15u) < need;
+        } else {
+            const uint64_t n16 = a.cbf_bytes / 16;
+            const uint4* p4 = reinterpret_cast<const uint4*>(cb);
+            for (uint64_t i = threadIdx.x; i < n16 && !bad; i += blockDim.x) {
+                const uint4 v = p4[i];
+                const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+                for (int q = 0; q < 4; q++)
+                    for (int r = 0; r < 4; r++)
+                        bad |= ((w[q] >> (8 * r)) & 255u) < need;
+            }
+            for (uint64_t i = n16 * 16 + threadIdx.x; i < a.cbf_bytes; i += blockDim.x)
+                bad |= cb[i] < need;
+        }
+        if (bad)
+            atomicOr(&bad_c, 1u);
+    }
+    if (!(cur & 2u)) {
+        const uint32_t* w = a.bf + (uint64_t)stream * a.bf_words;
+        uint32_t bad = 0;
+        for (uint32_t i = threadIdx.x; i < a.bf_words && !bad; i += blockDim.x)
+            bad |= w[i] != 0xFFFFFFFFu;
+        if (bad)
+            atomicOr(&bad_b, 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t now = cur;
+        if (!(cur & 1u) && !bad_c)
+            now |= 1u;
+        if (!(cur & 2u) && !bad_b)
+            now |= 2u;
+        if (now != cur)
+            a.sat[stream] = now;
+    }
 }
 
 // loads that must see what other waves of the SAME launch wrote (tail kernel): agent-scope
@@ -507,6 +593,18 @@ int stage_a_prepare(gp_job* job)
         return rc;
     if ((rc = job->d_stats.alloc(16)) != GP_OK)
         return rc;
+    if ((rc = job->d_sat.alloc((uint64_t)job->n_batches * p.n_k)) != GP_OK ||
+        (rc = job->d_batch_thr_max.alloc(job->n_batches)) != GP_OK)
+        return rc;
+    {
+        std::vector<uint32_t> tm(job->n_batches, 4);
+        for (uint32_t bi = 0; bi < job->n_batches; bi++)
+            for (uint32_t c = job->h_batch_contig_begin[bi]; c < job->h_batch_contig_begin[bi + 1]; c++)
+                tm[bi] = std::max(tm[bi], job->h_contig_thr[c]);
+        if (job->n_batches)
+            GP_HIP(hipMemcpy(job->d_batch_thr_max.p, tm.data(), tm.size() * sizeof(uint32_t),
+                             hipMemcpyHostToDevice));
+    }
     GP_HIP(hipHostMalloc((void**)&job->h_count_pinned, 256));
     for (uint32_t i = 0; i < kRing; i++)
         GP_HIP(hipEventCreateWithFlags(&job->a_ev[i], hipEventDisableTiming));
@@ -563,7 +661,7 @@ int stage_a_run(gp_job* job)
         // first pass (49 -> 24 GB, FETCH_SIZE) at equal run time (first pass -6 %, rounds
         // +6 % because increments become atomics).  GP_STAGE_A_NIBBLE=0 switches it off.
         a.nib = (max_thr <= 15 && env_u64("GP_STAGE_A_NIBBLE", 1)) ? 1u : 0u;
-        a.cbf_stride = a.nib ? ((p.cbf_bytes + 1) / 2 + 3) / 4 * 4 : p.cbf_bytes;
+        a.cbf_stride = ((a.nib ? (p.cbf_bytes + 1) / 2 : p.cbf_bytes) + 15) / 16 * 16;
     }
     a.bf_words = (uint32_t)(p.bf_bytes / 4);
     a.cbf_mod = make_fastmod(p.cbf_bytes);
@@ -577,6 +675,8 @@ int stage_a_run(gp_job* job)
     }
     a.resv_bits = job->resv_bits;
     a.stats = job->d_stats.p;
+    a.sat = job->d_sat.p;
+    a.batch_thr_max = job->d_batch_thr_max.p;
 
     job->t_first_pass.reset();
     job->t_round.reset();
@@ -587,6 +687,7 @@ int stage_a_run(gp_job* job)
                           std::min<uint64_t>(job->d_cbf.n, (uint64_t)job->n_batches * p.n_k * a.cbf_stride + 8), s));
     GP_HIP(hipMemsetAsync(job->d_bf.p, 0, job->d_bf.n * sizeof(uint32_t), s));
     GP_HIP(hipMemsetAsync(job->d_stats.p, 0, 16 * sizeof(unsigned long long), s));
+    GP_HIP(hipMemsetAsync(job->d_sat.p, 0, job->d_sat.n * sizeof(uint32_t), s));
     GP_HIP(hipMemsetAsync(job->d_counts.p, 0, 2 * (kMaxRounds + 2) * sizeof(uint32_t), s));
     GP_HIP(hipMemsetAsync(job->d_resv.p, 0xFF, job->d_resv.n * sizeof(unsigned long long), s));
     // stream `s` runs the first passes, stream `s2` the rounds and tails
@@ -741,6 +842,18 @@ int stage_a_run(gp_job* job)
         GP_HIP(hipGetLastError());
         if ((rc = job->t_round.end(s2)) != GP_OK)
             return rc;
+        if (last_frac < 0.05) {
+            // which (batch, k) pairs did this window touch?
+            uint32_t b_last = bcur;
+            while (b_last + 1 < job->n_batches && batch_pos[b_last + 1] < w1)
+                b_last++;
+            const uint32_t n_streams = (b_last - bcur + 1) * p.n_k;
+            if (n_streams <= 64) {
+                hipLaunchKernelGGL(cbf_check_sat, dim3(n_streams), dim3(1024), 0, s2, a,
+                                   bcur * p.n_k);
+                GP_HIP(hipGetLastError());
+            }
+        }
         GP_HIP(hipEventRecord(job->a_ev_tail[set], s2));
         {
             // feedback for the windows to come, read back without stalling anything
