@@ -88,8 +88,8 @@ __device__ inline uint32_t resv_slot(const AArgs& a, uint32_t stream, uint32_t i
 }
 
 // Counters never pass their stream's threshold, and GoldPolish's thresholds are <= 14, so
-// two counters share a byte: the 10 MiB per filter become 5 MiB, most of which lives in an
-// XCD's 4 MiB L2.  Thresholds above 15 (or GP_STAGE_A_NIBBLE=0) use one byte per counter.
+// two counters can share a byte (GP_STAGE_A_NIBBLE=1): the 10 MiB per filter become 5 MiB,
+// most of which lives in an XCD's 4 MiB L2.  Default and thresholds above 15: one byte each.
 template <bool FRESH>
 __device__ inline uint32_t ctr_load(const AArgs& a, const uint8_t* cb, uint32_t idx)
 {
@@ -657,10 +657,10 @@ int stage_a_run(gp_job* job)
         uint32_t max_thr = 0;
         for (uint32_t c = 0; c < job->n_contigs; c++)
             max_thr = std::max(max_thr, job->h_contig_thr[c] - 2 + p.n_k - 1);
-        // Measured on MI355X (config 2): packing halves the HBM-side fetch traffic of the
-        // first pass (49 -> 24 GB, FETCH_SIZE) at equal run time (first pass -6 %, rounds
-        // +6 % because increments become atomics).  GP_STAGE_A_NIBBLE=0 switches it off.
-        a.nib = (max_thr <= 15 && env_u64("GP_STAGE_A_NIBBLE", 1)) ? 1u : 0u;
+        // Measured on MI355X: packing halves the fetch traffic of the counter loads but
+        // turns every increment into an atomic; end to end it is 1.5 % (config 2) to 4 %
+        // (25 kbp contigs) slower, so it is opt-in: GP_STAGE_A_NIBBLE=1.
+        a.nib = (max_thr <= 15 && env_u64("GP_STAGE_A_NIBBLE", 0)) ? 1u : 0u;
         a.cbf_stride = ((a.nib ? (p.cbf_bytes + 1) / 2 : p.cbf_bytes) + 15) / 16 * 16;
     }
     a.bf_words = (uint32_t)(p.bf_bytes / 4);

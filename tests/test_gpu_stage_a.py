@@ -71,12 +71,11 @@ def test_small_filters_heavy_collisions_and_saturation(gp, oracle):
 
 
 def test_byte_counter_fallback_and_wide_thresholds(gp, oracle, monkeypatch):
-    """4-bit packed counters are the default; GP_STAGE_A_NIBBLE=0 and thresholds > 15 use bytes"""
+    """optional 4-bit packed counters (GP_STAGE_A_NIBBLE=1); thresholds > 15 always use bytes"""
     core, ctx = gp
     w = synth.make_workload([12000, 7000], 25, seed=15)
-    monkeypatch.setenv("GP_STAGE_A_NIBBLE", "0")
+    monkeypatch.setenv("GP_STAGE_A_NIBBLE", "1")
     run_and_compare(core, ctx, oracle, w, core.default_params(k_values=[32, 24]))
-    monkeypatch.delenv("GP_STAGE_A_NIBBLE")
     # 8 k values and kmer_threshold 13: thresholds 11..18 do not fit a nibble
     w.kmer_threshold[:] = 13
     p = core.default_params(k_values=[32, 30, 28, 26, 24, 22, 20, 18], cbf_bytes=200_000,
@@ -87,7 +86,7 @@ def test_byte_counter_fallback_and_wide_thresholds(gp, oracle, monkeypatch):
     g = synth.random_genome(3000, rng).tobytes()
     w2 = _custom_workload([g], [[g] * 40], [13])
     run_and_compare(core, ctx, oracle, w2, core.default_params())
-    monkeypatch.setenv("GP_STAGE_A_NIBBLE", "0")
+    monkeypatch.delenv("GP_STAGE_A_NIBBLE")
     run_and_compare(core, ctx, oracle, w2, core.default_params())
 
 
