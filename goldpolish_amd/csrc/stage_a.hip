@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 
 namespace gp {
@@ -202,10 +203,32 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
         uint32_t seg = lo;
         uint64_t seg_end = a.seg_start[seg + 1];
 
+        // all of this lane's positions in one saturated filter pair: nothing to hash or
+        // look up, only the operation count is kept (k-mers without a non-ACGT byte)
+        const bool saturated = pos0 + kPerThread <= seg_end &&
+                               a.sat[a.seg_batch[seg] * a.n_k + ki] == 3u;
+        if (saturated) {
+            int lb = -1;
+            for (uint32_t i = 0; i + 1 < k; i++)
+                if (codes[t0 + i] >= 4)
+                    lb = (int)i;
+            for (int j = 0; j < kPerThread; j++) {
+                const uint64_t pos = pos0 + j;
+                if (pos >= a.win_end)
+                    break;
+                if (codes[t0 + j + k - 1] >= 4)
+                    lb = j + (int)k - 1;
+                n_positions++;
+                if (lb >= j || pos + k > a.n_pos)
+                    continue;
+                n_ops++;
+            }
+        }
+
         // hash of the first window; bad bytes contribute 0 so rolling stays exact
         uint64_t fh = 0, rh = 0;
         int last_bad = -1;
-        for (uint32_t i = 0; i < k; i++) {
+        for (uint32_t i = 0; i < k && !saturated; i++) {
             uint32_t cf = codes[t0 + i];
             uint32_t cr = codes[t0 + k - 1 - i];
             fh = srol1(fh) ^ (cf < 4 ? seed_of_code(cf) : 0ULL);
@@ -213,7 +236,7 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
             if (cf >= 4)
                 last_bad = (int)i;
         }
-        for (int j = 0; j < kPerThread; j++) {
+        for (int j = 0; j < kPerThread && !saturated; j++) {
             const uint64_t pos = pos0 + j;
             if (pos >= a.win_end)
                 break;
@@ -446,6 +469,9 @@ struct TailArgs {
     uint32_t max_rounds;  // bug trap
     uint32_t* err;
     uint32_t* info;       // [0] round at which the tail took over, [1] list length then
+    volatile uint32_t* host_ring; // mapped host memory: 4 words per slot {seq, waiting, took_at, took_len}
+    uint32_t ring_slot, ring_seq;
+    uint32_t n_counts;    // counters to zero for the next user of this buffer set
     unsigned long long* stats; // [3] rounds run by the tail
 };
 
@@ -501,8 +527,23 @@ __global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
             break;
         }
     }
-    if (threadIdx.x == 0 && done_rounds)
-        atomicAdd(&t.stats[3], (unsigned long long)done_rounds);
+    if (threadIdx.x == 0) {
+        if (done_rounds)
+            atomicAdd(&t.stats[3], (unsigned long long)done_rounds);
+        // feedback for the host (how much waited, where the tail took over), written straight
+        // into mapped host memory; the sequence number goes last
+        volatile uint32_t* slot = t.host_ring + 4 * t.ring_slot;
+        slot[1] = a.counts[0];
+        slot[2] = t.info[0];
+        slot[3] = t.info[1];
+        __threadfence_system();
+        slot[0] = t.ring_seq;
+        __threadfence_system();
+    }
+    __syncthreads();
+    // leave the counter array clean for the window that uses this buffer set next
+    for (uint32_t i = threadIdx.x; i < t.n_counts; i += blockDim.x)
+        a.counts[i] = 0;
 }
 
 // ------------------------------------------------------------------ host side
@@ -721,7 +762,10 @@ int stage_a_run(gp_job* job)
     t.max_rounds = (uint32_t)tail_span - 16;
     t.err = job->d_counts.p + kMaxRounds + 1; // last word of set 0's counter array is a flag
     t.stats = job->d_stats.p;
+    t.host_ring = job->h_count_pinned;
+    std::memset((void*)job->h_count_pinned, 0, 256);
     uint64_t wi = 0; // window index; its parity picks the buffer set
+    const auto t_host0 = std::chrono::steady_clock::now();
     uint64_t scale = 1, gen = 1;
     uint32_t bcur = 0;
     double last_frac = 1.0; // waiting fraction of the most recent window we know about
@@ -729,29 +773,34 @@ int stage_a_run(gp_job* job)
     // feedback ring: waiting count of a window, read back without stalling the stream
     uint32_t ring_head = 0, ring_tail = 0, ring_slot = 0; // [tail, head) outstanding
     uint64_t ring_units[kRing];
+    volatile uint32_t* hring = job->h_count_pinned;
     auto drain = [&](bool block) -> int {
         while (ring_tail != ring_head) {
             const uint32_t i = ring_tail % kRing;
+            const uint32_t want_seq = ring_tail + 1;
             if (block) {
-                GP_HIP(hipEventSynchronize(job->a_ev[i]));
-            } else {
-                hipError_t q = hipEventQuery(job->a_ev[i]);
-                if (q == hipErrorNotReady)
-                    break;
-                if (q != hipSuccess)
-                    return hip_fail(q, "hipEventQuery", __FILE__, __LINE__);
+                // only when the host is a full ring ahead of the device
+                uint64_t spins = 0;
+                while (hring[4 * i] != want_seq) {
+                    if (++spins > (1ull << 34)) {
+                        set_error("stage A: device stopped reporting window feedback");
+                        return GP_ERR_STATE;
+                    }
+                }
+            } else if (hring[4 * i] != want_seq) {
+                break;
             }
-            const double frac = (double)job->h_count_pinned[4 * i] / (double)ring_units[i];
+            const double frac = (double)hring[4 * i + 1] / (double)ring_units[i];
             last_frac = frac;
             // did the grid-wide rounds hand the tail a short list, and how early?
-            const uint32_t took_at = job->h_count_pinned[4 * i + 1];
-            const uint32_t took_len = job->h_count_pinned[4 * i + 2];
+            const uint32_t took_at = hring[4 * i + 2];
+            const uint32_t took_len = hring[4 * i + 3];
             if (took_len > a.tail_max)
                 want_rounds = std::min<uint32_t>(want_rounds * 2, 512);
-            if (took_len > 16 * a.tail_max && scale > 1)
-                scale /= 2; // the single-workgroup tail got far too much: smaller windows
             else
                 want_rounds = std::max<uint32_t>(2, std::min<uint32_t>(want_rounds, took_at + 2));
+            if (took_len > 16 * a.tail_max && scale > 1)
+                scale /= 2; // the single-workgroup tail got far too much: smaller windows
             if (frac < 0.05)
                 scale = std::min<uint64_t>(scale * 4, 1u << 16);
             else if (frac < 0.15)
@@ -794,7 +843,6 @@ int stage_a_run(gp_job* job)
         // this set's buffers were last used by window wi-2: wait for its tail
         if (wi >= 2)
             GP_HIP(hipStreamWaitEvent(s, job->a_ev_tail[set], 0));
-        GP_HIP(hipMemsetAsync(counts, 0, (want_rounds + 2) * sizeof(uint32_t), s));
         const uint64_t g0 = gen;
         a.win_start = w0;
         a.win_end = w1;
@@ -824,7 +872,10 @@ int stage_a_run(gp_job* job)
         GP_HIP(hipStreamWaitEvent(s2, job->a_ev_fp[set], 0));
         const uint32_t rounds_now = std::min<uint32_t>(want_rounds, kMaxRounds - 8);
         t.n_rounds = rounds_now;
-        if ((rc = job->t_round.begin(s2, rounds_now + 1)) != GP_OK)
+        t.n_counts = rounds_now + 2;
+        t.ring_slot = ring_slot;
+        t.ring_seq = ring_head + 1;
+        if (wi == 0 && (rc = job->t_round.begin(s2, 1)) != GP_OK) // one span over all rounds
             return rc;
         for (uint32_t round = 0; round < rounds_now; round++) {
             a.round = round;
@@ -840,8 +891,6 @@ int stage_a_run(gp_job* job)
         t.tag_first = tag_max - g0;
         hipLaunchKernelGGL(cbf_tail, dim3(1), dim3(kTailThreads), 0, s2, a, t);
         GP_HIP(hipGetLastError());
-        if ((rc = job->t_round.end(s2)) != GP_OK)
-            return rc;
         if (last_frac < 0.05) {
             // which (batch, k) pairs did this window touch?
             uint32_t b_last = bcur;
@@ -855,25 +904,25 @@ int stage_a_run(gp_job* job)
             }
         }
         GP_HIP(hipEventRecord(job->a_ev_tail[set], s2));
-        {
-            // feedback for the windows to come, read back without stalling anything
-            const uint32_t i = ring_slot;
-            GP_HIP(hipMemcpyAsync(job->h_count_pinned + 4 * i, counts, sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, s2));
-            GP_HIP(hipMemcpyAsync(job->h_count_pinned + 4 * i + 1, t.info, 2 * sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, s2));
-            GP_HIP(hipEventRecord(job->a_ev[i], s2));
-            ring_head++;
-        }
+        ring_head++;
         wi++;
         job->counters.a_rounds += rounds_now + 1;
         gen = g0 + rounds_now + tail_span + 1;
         w0 = w1;
     }
-    {
-        int rc = drain(true);
+    if (wi > 0) {
+        int rc = job->t_round.end(s2);
         if (rc != GP_OK)
             return rc;
+    }
+    if (env_u64("GP_STAGE_A_DEBUG", 0)) {
+        const double host_ms = std::chrono::duration<double, std::milli>(
+                                   std::chrono::steady_clock::now() - t_host0).count();
+        GP_HIP(hipStreamSynchronize(s2));
+        const double all_ms = std::chrono::duration<double, std::milli>(
+                                  std::chrono::steady_clock::now() - t_host0).count();
+        fprintf(stderr, "[stage A] %llu windows: host enqueue %.2f ms, device done after %.2f ms\n",
+                (unsigned long long)wi, host_ms, all_ms);
     }
     // the rest of the pipeline (stream `s`) continues behind the last tail
     GP_HIP(hipEventRecord(job->a_ev_init, s2));
