@@ -221,6 +221,7 @@ def main():
             "bound": "hbm", "kernel": "cbf_first_pass", "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_GBps": (round(traffic / avg_s / 1e9, 1) if traffic and fp["launches"] else None),
             "alg_bytes_per_launch": int(bytes_per_launch),
             "avg_launch_ms": round(fp["ms"] / max(fp["launches"], 1), 4),
             "largest_by_time": dom,
