@@ -13,22 +13,28 @@
 //
 //   * "position in the concatenated read buffer" IS the serial order, so an
 //     operation's identity is (k index, position).
-//   * Counters never exceed thr and never decrease.  An operation that sees
-//     all of its counters >= thr-1 -- at ANY time, even ahead of its turn --
-//     must end with those counters == thr and with its k-mer inserted, whatever
-//     happens before it; it completes immediately (first_pass / round kernels,
-//     "settled" path).
-//   * Every other operation takes a deterministic reservation: it writes its
-//     position with atomicMin into a hashed slot for each of its counters; in
-//     the next launch the operations that hold all their slots are exactly
-//     those with no earlier unfinished operation on any of their counters, so
-//     they apply the serial update; the rest retry.  Two tables alternate so
-//     commit(r) and reserve(r+1) share one launch.
+//   * Counters never exceed thr and never decrease, and a minimum of thr-1 or thr
+//     both mean "insert".  An operation that sees all of its counters >= thr-1
+//     -- at ANY time, even ahead of its turn, even from a stale read -- inserts
+//     its k-mer and writes nothing ("settled", try_settle).
+//   * Every other operation takes a deterministic reservation: atomicMin of
+//     (round tag, position) into a hashed slot for each of its counters; in the
+//     next launch the operations that hold all their slots are exactly those
+//     with no earlier unfinished operation on any of their counters, so they
+//     apply the serial update; the rest retry (round_op).  Tags shrink per
+//     launch (newer beats stale), two tables alternate.
+//   * A window (bounded waiting operations per counter) = cbf_first_pass, a few
+//     grid-wide cbf_round launches, then cbf_tail: one workgroup that loops over
+//     the short remaining list with L1-bypassing loads.  No launch waits for the
+//     host; the first pass of the next window runs beside it on a second stream;
+//     feedback (how much waited) returns through mapped host memory.
+//   * cbf_check_sat marks (batch, k) pairs whose counters and filter can no
+//     longer change; their k-mers then cost nothing.
 //
 // Memory behaviour: the sequence is streamed once per k through LDS (coalesced
 // 1 B/base); the counter / bit accesses are 1-byte random accesses into 10 MiB
-// (counters) and 512 KiB (bits) per (batch, k) -- HBM/Infinity-Cache
-// transaction-bound, no reuse to tile for.  Integer / bitwise work only.
+// (counters) and 512 KiB (bits) per (batch, k) -- random-transaction and
+// atomic bound, no reuse to tile for.  Integer / bitwise work only.
 #include "gp_internal.h"
 
 #include <algorithm>
