@@ -116,6 +116,7 @@ struct gp_job {
     uint32_t resv_bits = 0;
     gp::DevBuf<uint4> d_pending[4];       // [set][list] of {hash lo, hash hi, pos, meta},{idx x4}
     gp::DevBuf<uint32_t> d_sat, d_batch_thr_max; // saturation flags per (batch, k); max threshold per batch
+    gp::DevBuf<uint64_t> d_batch_pos;     // [n_batches+1] first read position of each batch
     gp::DevBuf<uint32_t> d_counts;        // [kMaxRounds+2] pending count per round
     gp::DevBuf<unsigned long long> d_stats; // device-side gp_counters
     uint64_t window = 0;

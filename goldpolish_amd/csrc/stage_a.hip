@@ -84,7 +84,11 @@ struct AArgs {
     uint4* list_out;
     uint32_t* counts;    // counts[r] = length of the list round r consumes
     uint32_t round;
-    uint64_t win_start, win_end;
+    // a window = the same slice [off, off + slice) of every batch of a group (batch-relative
+    // positions), one or more 1024-position tiles per batch
+    const uint64_t* batch_pos; // [n_batches+1] first read position of each batch
+    uint32_t grp_first, grp_n, tiles_per_batch;
+    uint64_t off, slice;
     unsigned long long* stats; // [0] positions [1] ops [2] ordered ops
 };
 
@@ -182,7 +186,12 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
     const uint32_t ki = blockIdx.y;
     const KConsts& kc = a.kc[ki];
     const uint32_t k = kc.k;
-    const uint64_t tile0 = a.win_start + (uint64_t)blockIdx.x * kTile;
+    const uint32_t gb = a.grp_first + blockIdx.x / a.tiles_per_batch;
+    const uint64_t b_start = a.batch_pos[gb], b_end = a.batch_pos[gb + 1];
+    const uint64_t tile0 = b_start + a.off + (uint64_t)(blockIdx.x % a.tiles_per_batch) * kTile;
+    const uint64_t tile_end = min(min(b_end, b_start + a.off + a.slice), tile0 + (uint64_t)kTile);
+    if (tile0 >= tile_end)
+        return; // this batch has no reads left at this offset
 
     if (threadIdx.x < 3)
         s_stats[threadIdx.x] = 0;
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
     const int t0 = threadIdx.x * kPerThread;
     const uint64_t pos0 = tile0 + t0;
     uint32_t n_ops = 0, n_ordered = 0, n_positions = 0;
-    if (pos0 < a.win_end) {
+    if (pos0 < tile_end) {
         // segment (= contig's read block) that holds pos0
         uint32_t lo = 0, hi = a.n_seg;
         while (hi - lo > 1) {
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
                     lb = (int)i;
             for (int j = 0; j < kPerThread; j++) {
                 const uint64_t pos = pos0 + j;
-                if (pos >= a.win_end)
+                if (pos >= tile_end)
                     break;
                 if (codes[t0 + j + k - 1] >= 4)
                     lb = j + (int)k - 1;
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
         }
         for (int j = 0; j < kPerThread && !saturated; j++) {
             const uint64_t pos = pos0 + j;
-            if (pos >= a.win_end)
+            if (pos >= tile_end)
                 break;
             if (j > 0) {
                 uint32_t out = codes[t0 + j - 1], in = codes[t0 + j + k - 1];
@@ -285,7 +294,8 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
             if (try_settle(a, stream, thr, k, base, idx))
                 continue;
             n_ordered++;
-            const uint32_t rel = (uint32_t)(pos - a.win_start);
+            // order key: tiles of a batch are consecutive blocks in increasing position order
+            const uint32_t rel = blockIdx.x * (uint32_t)kTile + (uint32_t)(pos - tile0);
             reserve(a, stream, idx, rel);
             uint32_t at = wave_append(&a.counts[0]);
             a.list_out[2 * at] = make_uint4((uint32_t)base, (uint32_t)(base >> 32), rel,
@@ -640,6 +650,8 @@ int stage_a_prepare(gp_job* job)
         return rc;
     if ((rc = job->d_stats.alloc(16)) != GP_OK)
         return rc;
+    if ((rc = job->d_batch_pos.alloc((uint64_t)job->n_batches + 1)) != GP_OK)
+        return rc;
     if ((rc = job->d_sat.alloc((uint64_t)job->n_batches * p.n_k)) != GP_OK ||
         (rc = job->d_batch_thr_max.alloc(job->n_batches)) != GP_OK)
         return rc;
@@ -757,6 +769,10 @@ int stage_a_run(gp_job* job)
     for (uint32_t bi = 0; bi < job->n_batches; bi++)
         batch_pos[bi] = job->h_seg_start[job->h_batch_contig_begin[bi]];
     batch_pos[job->n_batches] = job->read_positions;
+    GP_HIP(hipMemcpyAsync(job->d_batch_pos.p, batch_pos.data(), batch_pos.size() * sizeof(uint64_t),
+                          hipMemcpyHostToDevice, s));
+    GP_HIP(hipStreamSynchronize(s)); // batch_pos is a local
+    a.batch_pos = job->d_batch_pos.p;
     const uint64_t load_div = std::max<uint64_t>(1, env_u64("GP_STAGE_A_LOAD_DIV", 6));
     const uint64_t lim0 = std::max<uint64_t>(kTile, p.cbf_bytes / (load_div * p.hash_num));
     const uint32_t n_rounds = (uint32_t)std::min<uint64_t>(env_u64("GP_STAGE_A_ROUNDS", 6), kMaxRounds);
@@ -773,7 +789,6 @@ int stage_a_run(gp_job* job)
     uint64_t wi = 0; // window index; its parity picks the buffer set
     const auto t_host0 = std::chrono::steady_clock::now();
     uint64_t scale = 1, gen = 1;
-    uint32_t bcur = 0;
     double last_frac = 1.0; // waiting fraction of the most recent window we know about
     uint32_t want_rounds = n_rounds; // grid-wide rounds per window, steered by the same feedback
     // feedback ring: waiting count of a window, read back without stalling the stream
@@ -817,28 +832,49 @@ int stage_a_run(gp_job* job)
         }
         return GP_OK;
     };
-    for (uint64_t w0 = 0; w0 < job->read_positions;) {
+    // Batches are taken in groups; every window covers the same slice [off, off + slice) of
+    // every batch of the group.  Many small batches therefore advance in lockstep: each filter
+    // sees only a sliver of its reads per window (no chains of waiting operations to speak
+    // of), yet a window still holds enough operations to fill the chip.  A group of one batch
+    // degenerates to consecutive slices of that batch (the long-contig case).
+    const uint32_t group_max = (uint32_t)std::max<uint64_t>(1, env_u64("GP_STAGE_A_GROUP", 2048));
+    for (uint32_t g_first = 0; g_first < job->n_batches;) {
+        uint32_t g_n = std::min<uint32_t>(group_max, job->n_batches - g_first);
+        g_n = (uint32_t)std::min<uint64_t>(g_n, std::max<uint64_t>(1, job->window / kTile));
+        uint64_t longest = 0;
+        for (uint32_t bi = g_first; bi < g_first + g_n; bi++)
+            longest = std::max(longest, batch_pos[bi + 1] - batch_pos[bi]);
+        scale = 1;
+        last_frac = 1.0;
+      for (uint64_t off = 0; off < longest;) {
         int rc = drain(ring_head - ring_tail >= kRing);
         if (rc != GP_OK)
             return rc;
-        const uint64_t lim = lim0 * scale;
-        // never queue more waiting operations than the grid-wide rounds can bring down to a
-        // short list: about 3 M per window, judged by the waiting fraction seen last
+        // per-batch slice: bounded by the per-filter load (lim), by the total number of
+        // operations expected to wait (about 3 M per window), and by the buffers
         const uint64_t wmax = std::min<uint64_t>(
             job->window,
             std::max<uint64_t>(kTile, (uint64_t)(3.0e6 / ((double)p.n_k * std::max(last_frac, 0.02)))));
-        uint64_t w1 = w0;
-        while (bcur + 1 < job->n_batches && batch_pos[bcur + 1] <= w0)
-            bcur++;
-        for (uint32_t bi = bcur; w1 < job->read_positions && w1 - w0 < wmax; bi++) {
-            const uint64_t b_end = batch_pos[bi + 1];
-            const uint64_t take = std::min({ b_end - w1, lim, wmax - (w1 - w0) });
-            w1 += take;
-            if (w1 < b_end)
-                break;
+        uint64_t slice = std::min<uint64_t>(lim0 * scale, std::max<uint64_t>(kTile, wmax / g_n));
+        slice = std::max<uint64_t>(kTile, slice / kTile * kTile);
+        slice = std::min<uint64_t>(slice, (longest - off + kTile - 1) / kTile * kTile);
+        const uint32_t tiles_per_batch = (uint32_t)(slice / kTile);
+        if ((uint64_t)tiles_per_batch * g_n * kTile > job->window || (uint64_t)tiles_per_batch * g_n >= (1u << 14)) {
+            set_error("stage A: window does not fit the work buffers");
+            return GP_ERR_STATE;
         }
-        if (w1 == w0) // empty batches at the cursor
-            w1 = std::min(job->read_positions, w0 + 1);
+        uint64_t w_positions = 0; // positions this window really covers
+        for (uint32_t bi = g_first; bi < g_first + g_n; bi++) {
+            const uint64_t len = batch_pos[bi + 1] - batch_pos[bi];
+            if (len > off)
+                w_positions += std::min<uint64_t>(slice, len - off);
+        }
+        if (w_positions == 0) {
+            off += slice;
+            continue;
+        }
+        const uint32_t bcur = g_first;
+        const uint64_t w0 = 0, w1 = w_positions; // only their difference is used below
         const uint32_t set = (uint32_t)(wi & 1);
         uint32_t* counts = job->d_counts.p + set * (kMaxRounds + 2);
         t.list[0] = job->d_pending[2 * set].p;
@@ -850,8 +886,11 @@ int stage_a_run(gp_job* job)
         if (wi >= 2)
             GP_HIP(hipStreamWaitEvent(s, job->a_ev_tail[set], 0));
         const uint64_t g0 = gen;
-        a.win_start = w0;
-        a.win_end = w1;
+        a.grp_first = g_first;
+        a.grp_n = g_n;
+        a.tiles_per_batch = tiles_per_batch;
+        a.off = off;
+        a.slice = slice;
         a.counts = counts;
         a.resv = nullptr;
         a.resv_out = t.resv[0];
@@ -860,7 +899,7 @@ int stage_a_run(gp_job* job)
         a.list_in = nullptr;
         a.list_out = t.list[0];
         a.round = 0;
-        dim3 grid((unsigned)((w1 - w0 + kTile - 1) / kTile), p.n_k);
+        dim3 grid(tiles_per_batch * g_n, p.n_k);
         if ((rc = job->t_first_pass.begin(s, (w1 - w0) * p.n_k)) != GP_OK)
             return rc;
         hipLaunchKernelGGL(cbf_first_pass, grid, dim3(kBlock), 0, s, a);
@@ -898,11 +937,8 @@ int stage_a_run(gp_job* job)
         hipLaunchKernelGGL(cbf_tail, dim3(1), dim3(kTailThreads), 0, s2, a, t);
         GP_HIP(hipGetLastError());
         if (last_frac < 0.05) {
-            // which (batch, k) pairs did this window touch?
-            uint32_t b_last = bcur;
-            while (b_last + 1 < job->n_batches && batch_pos[b_last + 1] < w1)
-                b_last++;
-            const uint32_t n_streams = (b_last - bcur + 1) * p.n_k;
+            // the (batch, k) pairs this window touched
+            const uint32_t n_streams = g_n * p.n_k;
             if (n_streams <= 64) {
                 hipLaunchKernelGGL(cbf_check_sat, dim3(n_streams), dim3(1024), 0, s2, a,
                                    bcur * p.n_k);
@@ -914,7 +950,9 @@ int stage_a_run(gp_job* job)
         wi++;
         job->counters.a_rounds += rounds_now + 1;
         gen = g0 + rounds_now + tail_span + 1;
-        w0 = w1;
+        off += slice;
+      }
+        g_first += g_n;
     }
     if (wi > 0) {
         int rc = job->t_round.end(s2);
