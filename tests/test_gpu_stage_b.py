@@ -130,6 +130,23 @@ def test_edge_case_contigs(gp, oracle):
     _cascade_check(core, ctx, oracle, w, p, full)
 
 
+def test_noisy_filters_stress_the_edit_list(gp, oracle):
+    """random half-full filters make ntEdit chain insertions, deletions and substitutions at
+    neighbouring positions: long runs of inserted bases, the insertion cap and the
+    repeat-insertion guard (ntedit.cpp:1030-1102), edits on inserted bases, node splitting"""
+    core, ctx = gp
+    rng = np.random.default_rng(11)
+    for dens in (0.5, 0.6, 0.7, 0.85, 0.9):
+        contigs = [synth.random_genome(n, rng).tobytes() for n in (3000, 1500, 2200, 900)]
+        w = _custom_workload(contigs, [[] for _ in contigs], [5] * len(contigs))
+        p = core.default_params(k_values=[32, 24, 20], bf_bytes=4096)
+        filters = [[np.packbits(rng.random(4096 * 8) < dens, bitorder="little")
+                    for _ in range(p.n_k)] for _ in contigs]
+        counters, final = _cascade_check(core, ctx, oracle, w, p, filters)
+        assert counters["b_edits"] > 50
+        assert any(len(f) > len(c) + 50 for f, c in zip(final, contigs) if f is not None)
+
+
 MASK_CASES = [
     # hand-derived from scripts/goldpolish-mask:44-72 with k=4 unless stated
     (b"ACGTACGTACGT", 4, b"ACGTACGTACGT"),
