@@ -59,41 +59,42 @@ def pmc_traffic(kernel):
     return int(per_launch), f"profiles/{files[-1].name}"
 
 
-def gather_to_rank0(seqs, rank, world, backend):
-    """Variable-length gather of the polished contigs on rank 0 (no other collective)."""
+def gather_to_rank0(lens, payload, rank, world):
+    """Variable-length gather of the polished records on rank 0 (the path's only exchange).
+    `lens` (int64) and `payload` (uint8) are tensors on the backend's device: HBM under
+    nccl/RCCL, host memory under gloo.  Rank 0 returns [(lens, payload)] per rank."""
     import torch
     import torch.distributed as dist
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    flat = np.frombuffer(b"".join(s for s in seqs if s is not None), dtype=np.uint8)
-    lens = torch.tensor([len(s) if s is not None else 0 for s in seqs], dtype=torch.int64, device=dev)
-    meta = torch.tensor([flat.size, lens.numel()], dtype=torch.int64, device=dev)
+    meta = torch.tensor([payload.numel(), lens.numel()], dtype=torch.int64, device=lens.device)
     metas = [torch.zeros_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta)
-    payload = torch.from_numpy(flat.copy()).to(dev)
     if rank == 0:
-        out = [seqs]
-        reqs, bufs = [], []
+        out = [(lens, payload)]
+        reqs = []
         for r in range(1, world):
             nb, nl = int(metas[r][0]), int(metas[r][1])
-            b = torch.empty(nb, dtype=torch.uint8, device=dev)
-            l = torch.empty(nl, dtype=torch.int64, device=dev)
+            b = torch.empty(nb, dtype=torch.uint8, device=lens.device)
+            l = torch.empty(nl, dtype=torch.int64, device=lens.device)
             reqs += [dist.irecv(l, src=r), dist.irecv(b, src=r)]
-            bufs.append((l, b))
+            out.append((l, b))
         for q in reqs:
             q.wait()
-        for l, b in bufs:
-            l = l.cpu().numpy()
-            b = b.cpu().numpy().tobytes()
-            at, part = 0, []
-            for n in l:
-                part.append(b[at:at + int(n)])
-                at += int(n)
-            out.append(part)
         return out
     reqs = [dist.isend(lens, dst=0), dist.isend(payload, dst=0)]
     for q in reqs:
         q.wait()
     return None
+
+
+def split_records(lens, payload):
+    """(lens, payload) tensors -> list of bytes, one per record (b"" for dropped ones)."""
+    l = lens.cpu().numpy()
+    b = payload.cpu().numpy().tobytes()
+    at, out = 0, []
+    for n in l:
+        out.append(b[at:at + int(n)])
+        at += int(n)
+    return out
 
 
 def cpu_baseline(seed):
@@ -107,8 +108,8 @@ def cpu_baseline(seed):
     if not so.exists():
         subprocess.check_call(["make", "-C", str(ROOT / "oracle"), "libgpo.so"])
     O = oracle_lib.Oracle(str(so))
-    sample_bp = 1_000_000
-    w = synth.make_workload([sample_bp], 30, seed=seed + 1000)
+    sample_bp = 10_000_000      # the whole configs[1] contig: about 20 s of one host core
+    w = synth.make_workload([sample_bp], 30, seed=seed)
     params = O.batch_params(k_values=(32,))
     t = time.perf_counter()
     O.polish_batch(w.names, [w.contig(0)], [w.reads_of(0)], [int(w.kmer_threshold[0])], params)
@@ -153,7 +154,12 @@ def main():
         def step():
             job.polish(sync=True)
             if world > 1:
-                gather_to_rank0(job.sequences(), rank, world, "nccl")
+                # device-to-device: pack on the GPU, send from HBM over xGMI
+                lens, _ = job.lengths()
+                lens_t = torch.from_numpy(lens.astype(np.int64)).cuda()
+                payload = torch.empty(max(int(lens.sum()), 1), dtype=torch.uint8, device="cuda")
+                job.sequences_into_device(payload.data_ptr(), payload.numel())
+                gather_to_rank0(lens_t, payload[:int(lens.sum())], rank, world)
 
         for _ in range(warmup):
             step()

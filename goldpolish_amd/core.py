@@ -25,7 +25,7 @@ SYMBOLS = [
     "gp_ctx_stream", "gp_kmer_threshold", "gp_rank_reads", "gp_job_create", "gp_job_destroy",
     "gp_job_polish", "gp_job_build_filters", "gp_job_ntedit_pass", "gp_job_ntedit_guard",
     "gp_job_mask", "gp_job_sealer", "gp_job_upper", "gp_job_sync", "gp_job_get_filter",
-    "gp_job_set_filters", "gp_job_get_lengths", "gp_job_get_sequences", "gp_job_get_counters",
+    "gp_job_set_filters", "gp_job_get_lengths", "gp_job_get_sequences", "gp_job_get_sequences_device", "gp_job_get_counters",
     "gp_job_kernel_time",
 ]
 
@@ -99,6 +99,7 @@ def load_library(path=None):
     L.gp_job_set_filters.argtypes = [C.c_void_p, u8p]
     L.gp_job_get_lengths.argtypes = [C.c_void_p, u64p, u8p, u64p]
     L.gp_job_get_sequences.argtypes = [C.c_void_p, u8p, C.c_uint64]
+    L.gp_job_get_sequences_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.gp_job_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
     L.gp_job_kernel_time.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), u64p, u64p]
     return L
@@ -271,6 +272,19 @@ class Job:
             out.append(None if dropped[i] else buf[at:at + n].tobytes())
             at += n
         return out
+
+    def lengths(self):
+        """(lengths[n_contigs] uint64 with 0 for dropped records, dropped[n_contigs] uint8)"""
+        lens = np.zeros(self.n_contigs, dtype=np.uint64)
+        dropped = np.zeros(self.n_contigs, dtype=np.uint8)
+        total = C.c_uint64(0)
+        _check(lib().gp_job_get_lengths(self._h, lens.ctypes.data_as(u64p),
+                                        dropped.ctypes.data_as(u8p), C.byref(total)))
+        return lens, dropped
+
+    def sequences_into_device(self, device_ptr: int, nbytes: int):
+        """Packs the surviving records at a device pointer on this job's GPU (no host hop)."""
+        _check(lib().gp_job_get_sequences_device(self._h, C.c_void_p(device_ptr), nbytes))
 
     def counters(self) -> dict:
         c = Counters()

@@ -495,6 +495,14 @@ int gp_job_get_sequences(gp_job* job, uint8_t* buf, uint64_t buf_bytes)
     return stage_sequences(job, buf, buf_bytes);
 }
 
+int gp_job_get_sequences_device(gp_job* job, void* device_buf, uint64_t buf_bytes)
+{
+    if (!job || !device_buf)
+        return GP_ERR_INVALID_ARG;
+    GP_HIP(hipSetDevice(job->ctx->device));
+    return stage_sequences_device(job, device_buf, buf_bytes);
+}
+
 int gp_job_get_counters(gp_job* job, gp_counters* out)
 {
     if (!job || !out)

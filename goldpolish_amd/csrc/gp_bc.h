@@ -18,6 +18,8 @@ struct StageBC {
     DevBuf<uint32_t> len[2];
     DevBuf<uint64_t> off;     // [n_contigs+1] slot offsets (bytes)
     DevBuf<uint8_t> dropped;  // [n_contigs]
+    DevBuf<uint64_t> pack_off; // [n_contigs + 1] output offsets of the export
+    DevBuf<uint8_t> pack_buf;  // staging for the host export
     DevBuf<Node> nodes;
     DevBuf<uint64_t> node_off; // [n_contigs+1]
     DevBuf<uint32_t> contig_batch, name_len, in_len;

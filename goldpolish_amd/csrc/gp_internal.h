@@ -147,4 +147,5 @@ int stage_c_run(gp_job* job);
 int stage_upper(gp_job* job);
 int stage_lengths(gp_job* job, uint64_t* lengths, uint8_t* dropped, uint64_t* total);
 int stage_sequences(gp_job* job, uint8_t* buf, uint64_t buf_bytes);
+int stage_sequences_device(gp_job* job, void* d_buf, uint64_t buf_bytes);
 } // namespace gp

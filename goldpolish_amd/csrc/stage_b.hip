@@ -2216,28 +2216,74 @@ int stage_lengths(gp_job* job, uint64_t* lengths, uint8_t* dropped, uint64_t* to
     return GP_OK;
 }
 
-int stage_sequences(gp_job* job, uint8_t* buf, uint64_t buf_bytes)
+// Concatenates the surviving records (input order, no separators) at `dst`, a device pointer.
+__global__ void pack_kernel(uint8_t* __restrict__ dst, const uint8_t* __restrict__ seq,
+                            const uint64_t* __restrict__ off, const uint64_t* __restrict__ out_off)
+{
+    const uint32_t cid = blockIdx.y;
+    const uint64_t n = out_off[cid + 1] - out_off[cid];
+    const uint8_t* s = seq + off[cid];
+    uint8_t* d = dst + out_off[cid];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x)
+        d[i] = s[i];
+}
+
+static int pack_to_device(gp_job* job, uint8_t* d_dst, uint64_t dst_bytes, const char* who)
 {
     StageBC* b = job->bc;
     const uint32_t n = job->n_contigs;
     std::vector<uint64_t> lens(n ? n : 1);
-    std::vector<uint8_t> dr(n ? n : 1);
     uint64_t total = 0;
-    int rc = stage_lengths(job, lens.data(), dr.data(), &total);
+    int rc = stage_lengths(job, lens.data(), nullptr, &total);
+    if (rc != GP_OK)
+        return rc;
+    if (total > dst_bytes) {
+        set_error(std::string(who) + ": buffer too small");
+        return GP_ERR_INVALID_ARG;
+    }
+    if (!n || !total)
+        return GP_OK;
+    std::vector<uint64_t> out_off(n + 1, 0);
+    for (uint32_t c = 0; c < n; c++)
+        out_off[c + 1] = out_off[c] + lens[c];
+    if (b->pack_off.n < n + 1 && (rc = b->pack_off.alloc(n + 1)) != GP_OK)
+        return rc;
+    hipStream_t s = job->ctx->stream;
+    GP_HIP(hipMemcpyAsync(b->pack_off.p, out_off.data(), (n + 1) * sizeof(uint64_t),
+                          hipMemcpyHostToDevice, s));
+    const uint32_t gx = n >= 1024 ? 4 : (n >= 64 ? 64 : 1024);
+    hipLaunchKernelGGL(pack_kernel, dim3(gx, n), dim3(256), 0, s, d_dst,
+                       (const uint8_t*)b->seq[b->cur].p, (const uint64_t*)b->off.p,
+                       (const uint64_t*)b->pack_off.p);
+    GP_HIP(hipGetLastError());
+    GP_HIP(hipStreamSynchronize(s));
+    return GP_OK;
+}
+
+int stage_sequences_device(gp_job* job, void* d_buf, uint64_t buf_bytes)
+{
+    return pack_to_device(job, (uint8_t*)d_buf, buf_bytes, "gp_job_get_sequences_device");
+}
+
+int stage_sequences(gp_job* job, uint8_t* buf, uint64_t buf_bytes)
+{
+    StageBC* b = job->bc;
+    uint64_t total = 0;
+    int rc = stage_lengths(job, nullptr, nullptr, &total);
     if (rc != GP_OK)
         return rc;
     if (total > buf_bytes) {
         set_error("gp_job_get_sequences: buffer too small");
         return GP_ERR_INVALID_ARG;
     }
-    uint64_t at = 0;
-    for (uint32_t c = 0; c < n; c++) {
-        if (lens[c]) {
-            GP_HIP(hipMemcpy(buf + at, b->seq[b->cur].p + b->h_off[c], lens[c],
-                             hipMemcpyDeviceToHost));
-            at += lens[c];
-        }
-    }
+    if (!total)
+        return GP_OK;
+    if (b->pack_buf.n < total && (rc = b->pack_buf.alloc(total)) != GP_OK)
+        return rc;
+    if ((rc = pack_to_device(job, b->pack_buf.p, total, "gp_job_get_sequences")) != GP_OK)
+        return rc;
+    GP_HIP(hipMemcpy(buf, b->pack_buf.p, total, hipMemcpyDeviceToHost));
     return GP_OK;
 }
 

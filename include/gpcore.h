@@ -161,6 +161,9 @@ int gp_job_set_filters(gp_job* job, const uint8_t* filters);
  * concatenated in contig order; call with buf == NULL to get total bytes. */
 int gp_job_get_lengths(gp_job* job, uint64_t* lengths, uint8_t* dropped, uint64_t* total);
 int gp_job_get_sequences(gp_job* job, uint8_t* buf, uint64_t buf_bytes);
+/* Same bytes, written to a DEVICE pointer on the job's GPU (e.g. a buffer that goes
+ * straight into an RCCL send): no host hop. */
+int gp_job_get_sequences_device(gp_job* job, void* device_buf, uint64_t buf_bytes);
 int gp_job_get_counters(gp_job* job, gp_counters* out);
 /* Average device time (ms) of the dominant stage-A kernel's launches since the
  * last gp_job_build_filters, measured with HIP events on the context stream,

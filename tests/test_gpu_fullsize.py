@@ -109,3 +109,25 @@ def test_batches_do_not_influence_each_other(gp):
         with core.Job.from_workload(ctx, p, one) as job:
             job.polish()
             assert job.sequences()[0] == together[c], c
+
+
+def test_device_export_matches_host_export(gp):
+    """gp_job_get_sequences_device packs the same bytes into an HBM buffer (the RCCL send
+    buffer of the multi-GPU gather) as gp_job_get_sequences returns on the host."""
+    import torch
+    core, ctx = gp
+    w = synth.make_workload([30_000, 90, 12_000, 150, 45_000], 25, seed=77)   # 90 bp is dropped
+    p = core.default_params(k_values=[32, 24])
+    with core.Job.from_workload(ctx, p, w) as job:
+        job.polish()
+        host = job.sequences()
+        lens, dropped = job.lengths()
+        assert dropped.tolist() == [0, 1, 0, 0, 0] and lens[1] == 0
+        total = int(lens.sum())
+        buf = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+        job.sequences_into_device(buf.data_ptr(), total)
+        got = buf.cpu().numpy()
+        assert got[:total].tobytes() == b"".join(s for s in host if s is not None)
+        assert not got[total:].any()
+        with pytest.raises(core.GpError):
+            job.sequences_into_device(buf.data_ptr(), total - 1)

@@ -31,13 +31,16 @@ import bench
 rank, world = int(sys.argv[1]), int(sys.argv[2])
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[4], RANK=str(rank), WORLD_SIZE=str(world))
 dist.init_process_group("gloo", rank=rank, world_size=world)
-mine = [bytes([65 + rank]) * (10 + 7 * rank), None, b"ACGT" * (3 + rank)]
-out = bench.gather_to_rank0(mine, rank, world, "gloo")
+import numpy as np, torch
+mine = [bytes([65 + rank]) * (10 + 7 * rank), b"", b"ACGT" * (3 + rank)]   # middle record dropped
+lens = torch.tensor([len(x) for x in mine], dtype=torch.int64)
+payload = torch.from_numpy(np.frombuffer(b"".join(mine), dtype=np.uint8).copy())
+out = bench.gather_to_rank0(lens, payload, rank, world)
 if rank == 0:
     assert len(out) == world
     for r in range(world):
         exp = [bytes([65 + r]) * (10 + 7 * r), b"", b"ACGT" * (3 + r)]
-        got = [x if x is not None else b"" for x in out[r]]
+        got = bench.split_records(*out[r])
         assert got == exp, (r, got, exp)
     print("GATHER_OK")
 else:
