@@ -7,7 +7,9 @@ is missing, or no GPU is present when a context is created, it raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import pathlib
+import sys
 
 import numpy as np
 
@@ -25,8 +27,8 @@ SYMBOLS = [
     "gp_ctx_stream", "gp_kmer_threshold", "gp_rank_reads", "gp_job_create", "gp_job_destroy",
     "gp_job_polish", "gp_job_build_filters", "gp_job_ntedit_pass", "gp_job_ntedit_guard",
     "gp_job_mask", "gp_job_sealer", "gp_job_upper", "gp_job_sync", "gp_job_get_filter",
-    "gp_job_set_filters", "gp_job_get_lengths", "gp_job_get_sequences", "gp_job_get_sequences_device", "gp_job_get_counters",
-    "gp_job_kernel_time",
+    "gp_job_set_filters", "gp_job_get_lengths", "gp_job_get_sequences",
+    "gp_job_get_sequences_device", "gp_job_get_counters", "gp_job_kernel_time",
 ]
 
 
@@ -68,12 +70,36 @@ class Counters(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels carry their own libamdhip64 (SONAME libamdhip64.so.7, the one
+    libgpcore asks for).  Two HIP/HSA runtimes in one process do not both see the GPU, so when
+    a torch wheel is installed its copy is mapped first and libgpcore binds to it whichever
+    of the two is imported first; the torch tensors of the multi-GPU gather and libgpcore's
+    kernels then share one runtime and one address space.  GP_HIP_RUNTIME=system skips this."""
+    if os.environ.get("GP_HIP_RUNTIME") == "system" or "torch" in sys.modules:
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.origin:
+        return
+    cand = pathlib.Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if cand.exists():
+        try:
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library(path=None):
     path = pathlib.Path(path) if path else LIB_PATH
     if not path.exists():
         raise FileNotFoundError(
             f"{path} is missing: build it with `make -C goldpolish_amd/csrc` "
             "(or __graft_entry__.build()); libgpcore has no CPU fallback")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(str(path))
     L.gp_last_error.restype = C.c_char_p
     L.gp_version.restype = C.c_int

@@ -52,6 +52,7 @@ constexpr int kHalo = 64;          // k <= 64
 constexpr uint32_t kMaxRounds = 4094;
 constexpr int kRoundBlocks = 2048;
 constexpr uint32_t kRing = 16;
+constexpr uint32_t kCountStride = 32; // one 128-B line per round counter: appends of different rounds never share a line
 
 struct AArgs {
     const uint8_t* reads;
@@ -79,7 +80,8 @@ struct AArgs {
     const uint32_t* batch_thr_max; // per batch: largest kmer_threshold of its contigs
     uint32_t tail_from;  // first round the tail kernel may take over (see cbf_tail)
     uint32_t tail_max;   // lists up to this long are left to the tail kernel
-    uint32_t resv_bits;
+    uint32_t resv_bits;  // slots in use this window (<= the allocation), see stage_a_run
+    uint32_t all_wait;   // 1: nearly every operation waits anyway; the first pass skips the counter look-up
     uint4* list_in;
     uint4* list_out;
     uint32_t* counts;    // counts[r] = length of the list round r consumes
@@ -178,11 +180,46 @@ __device__ inline void reserve(const AArgs& a, uint32_t stream, const uint32_t* 
         atomicMin(&a.resv_out[resv_slot(a, stream, idx[i])], w);
 }
 
+
+// A workgroup appends `n_mine` items per lane with ONE global atomic.  Every lane of the
+// workgroup must call it (n_mine may be 0).  Returns the index of the lane's first item.
+// (Per-wave appends to one word serialise at about 90 per microsecond chip-wide; with four
+// lists of a window in flight that was a third of a window's time.)
+template <int THREADS>
+__device__ inline uint32_t block_append(uint32_t* counter, uint32_t n_mine, uint32_t* s_wave /*[THREADS/64 + 1]*/)
+{
+    constexpr int kWaves = THREADS / 64;
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    uint32_t incl = n_mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(incl, d);
+        if (lane >= d)
+            incl += o;
+    }
+    if (lane == 63)
+        s_wave[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < kWaves; w++) {
+            uint32_t c = s_wave[w];
+            s_wave[w] = tot;
+            tot += c;
+        }
+        s_wave[kWaves] = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    const uint32_t at = s_wave[kWaves] + s_wave[wave] + incl - n_mine;
+    __syncthreads(); // s_wave may be reused by the caller's next call
+    return at;
+}
+
 // ---- first pass over a window: hash, settle what can be settled, reserve the rest
 __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
 {
     __shared__ uint8_t codes[kTile + kHalo];
     __shared__ unsigned long long s_stats[3];
+    __shared__ uint32_t s_wave[kBlock / 64 + 1];
     const uint32_t ki = blockIdx.y;
     const KConsts& kc = a.kc[ki];
     const uint32_t k = kc.k;
@@ -205,6 +242,10 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
     const int t0 = threadIdx.x * kPerThread;
     const uint64_t pos0 = tile0 + t0;
     uint32_t n_ops = 0, n_ordered = 0, n_positions = 0;
+    // what the lane's positions turned into: 0 nothing left to do, 1 counters looked up, 2 filter only
+    uint32_t op_state[kPerThread] = {}, op_seg[kPerThread] = {}, op_min[kPerThread] = {};
+    uint32_t op_idx[kPerThread][4] = {};
+    uint64_t op_base[kPerThread] = {};
     if (pos0 < tile_end) {
         // segment (= contig's read block) that holds pos0
         uint32_t lo = 0, hi = a.n_seg;
@@ -251,10 +292,13 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
             if (cf >= 4)
                 last_bad = (int)i;
         }
-        for (int j = 0; j < kPerThread && !saturated; j++) {
+        // pass 1: hashes and counter loads of all of the lane's positions (the loads of the
+        // four positions are independent, so they are in flight together)
+#pragma unroll
+        for (int j = 0; j < kPerThread; j++) {
             const uint64_t pos = pos0 + j;
-            if (pos >= tile_end)
-                break;
+            if (saturated || pos >= tile_end)
+                continue;
             if (j > 0) {
                 uint32_t out = codes[t0 + j - 1], in = codes[t0 + j + k - 1];
                 uint64_t s_in = in < 4 ? seed_of_code(in) : 0ULL;
@@ -274,33 +318,68 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
                 seg_end = a.seg_start[seg + 1];
             }
             const uint32_t stream = a.seg_batch[seg] * a.n_k + ki;
-            const uint32_t thr = a.seg_thr[seg] - 2 + ki;
-            const uint64_t base = fh + rh;
-            uint32_t idx[kMaxHash];
             n_ops++;
             // a saturated filter pair answers for itself: every counter is already high enough
             // for any k-mer to go in, and every bit it could set is set (cbf_check_sat)
             const uint32_t sat = a.sat[stream];
             if (sat == 3u)
                 continue;
-            if (sat & 1u) {
-                uint64_t hv[kMaxHash];
-                hv[0] = base;
-                for (uint32_t i = 1; i < a.hash_num; i++)
-                    hv[i] = ext_hash(base, k, i);
-                bf_insert(a, stream, hv);
-                continue;
+            op_base[j] = fh + rh;
+            op_seg[j] = seg;
+            op_state[j] = (sat & 1u) ? 2u : 1u; // 2: counters saturated, only the filter is left
+            if (op_state[j] == 1u) {
+                const uint8_t* cb = a.cbf + (uint64_t)stream * a.cbf_stride;
+                uint32_t m = a.all_wait ? 0u : 255u;
+                for (uint32_t h = 0; h < a.hash_num; h++) {
+                    const uint64_t hv = h ? ext_hash(op_base[j], k, h) : op_base[j];
+                    const uint32_t ix = (uint32_t)fastmod(hv, a.cbf_mod);
+                    if (h < 4)
+                        op_idx[j][h] = ix;
+                    if (!a.all_wait)
+                        m = min(m, ctr_load<false>(a, cb, ix));
+                }
+                op_min[j] = m;
             }
-            if (try_settle(a, stream, thr, k, base, idx))
+        }
+        // pass 2: settle what can be settled (see try_settle); count what has to wait
+#pragma unroll
+        for (int j = 0; j < kPerThread; j++) {
+            if (!op_state[j])
                 continue;
-            n_ordered++;
+            const uint32_t seg_j = op_seg[j];
+            const uint32_t stream = a.seg_batch[seg_j] * a.n_k + ki;
+            const uint32_t thr = a.seg_thr[seg_j] - 2 + ki;
+            if (op_state[j] == 2u || op_min[j] + 1 >= thr) {
+                uint64_t hv[kMaxHash];
+                hv[0] = op_base[j];
+                for (uint32_t i = 1; i < a.hash_num; i++)
+                    hv[i] = ext_hash(op_base[j], k, i);
+                bf_insert(a, stream, hv);
+                op_state[j] = 0;
+            } else {
+                n_ordered++;
+            }
+        }
+    }
+    // pass 3: one list append per workgroup, then reservations + records
+    {
+        uint32_t at = block_append<kBlock>(&a.counts[0], n_ordered, s_wave);
+#pragma unroll
+        for (int j = 0; j < kPerThread; j++) {
+            if (!op_state[j])
+                continue;
+            const uint32_t seg_j = op_seg[j];
+            const uint32_t stream = a.seg_batch[seg_j] * a.n_k + ki;
             // order key: tiles of a batch are consecutive blocks in increasing position order
-            const uint32_t rel = blockIdx.x * (uint32_t)kTile + (uint32_t)(pos - tile0);
+            const uint32_t rel = blockIdx.x * (uint32_t)kTile + (uint32_t)(t0 + j);
+            uint32_t idx[kMaxHash];
+            for (uint32_t h = 0; h < a.hash_num; h++)
+                idx[h] = h < 4 ? op_idx[j][h] : (uint32_t)fastmod(ext_hash(op_base[j], k, h), a.cbf_mod);
             reserve(a, stream, idx, rel);
-            uint32_t at = wave_append(&a.counts[0]);
-            a.list_out[2 * at] = make_uint4((uint32_t)base, (uint32_t)(base >> 32), rel,
-                                            (seg << 3) | ki);
-            a.list_out[2 * at + 1] = make_uint4(idx[0], idx[1], idx[2], idx[3]);
+            a.list_out[2 * at] = make_uint4((uint32_t)op_base[j], (uint32_t)(op_base[j] >> 32), rel,
+                                            (seg_j << 3) | ki);
+            a.list_out[2 * at + 1] = make_uint4(op_idx[j][0], op_idx[j][1], op_idx[j][2], op_idx[j][3]);
+            at++;
         }
     }
     atomicAdd(&s_stats[0], (unsigned long long)n_positions);
@@ -456,15 +535,21 @@ __device__ inline bool round_op(const AArgs& a, const uint4 rec, const uint4 rix
 // ---- one reservation round over a long list: every CU
 __global__ __launch_bounds__(256) void cbf_round(AArgs a)
 {
-    const uint32_t n_in = a.counts[a.round];
+    __shared__ uint32_t s_wave[256 / 64 + 1];
+    const uint32_t n_in = a.counts[a.round * kCountStride];
     if (a.round >= a.tail_from && n_in <= a.tail_max)
         return; // short list: cbf_tail finishes it without further launches
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in;
-         i += gridDim.x * blockDim.x) {
-        const uint4 rec = a.list_in[2 * i];
-        const uint4 rix = a.list_in[2 * i + 1];
-        if (round_op<false>(a, rec, rix, a.resv, a.resv_out, a.tag_cur, a.tag_next)) {
-            uint32_t at = wave_append(&a.counts[a.round + 1]);
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n_in; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + threadIdx.x;
+        uint4 rec = {}, rix = {};
+        bool waits = false;
+        if (i < n_in) {
+            rec = a.list_in[2 * i];
+            rix = a.list_in[2 * i + 1];
+            waits = round_op<false>(a, rec, rix, a.resv, a.resv_out, a.tag_cur, a.tag_next);
+        }
+        const uint32_t at = block_append<256>(&a.counts[(a.round + 1) * kCountStride], waits ? 1u : 0u, s_wave);
+        if (waits) {
             a.list_out[2 * at] = rec;
             a.list_out[2 * at + 1] = rix;
         }
@@ -496,9 +581,9 @@ __global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
     __shared__ uint32_t s_n, s_out;
     if (threadIdx.x == 0) {
         uint32_t r = 0;
-        while (r < t.n_rounds && !(r >= a.tail_from && a.counts[r] <= a.tail_max))
+        while (r < t.n_rounds && !(r >= a.tail_from && a.counts[r * kCountStride] <= a.tail_max))
             r++;
-        s_n = a.counts[r];
+        s_n = a.counts[r * kCountStride];
         s_out = r; // reused below as "current round" until the loop starts
         t.info[0] = r;
         t.info[1] = s_n;
@@ -559,7 +644,7 @@ __global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
     __syncthreads();
     // leave the counter array clean for the window that uses this buffer set next
     for (uint32_t i = threadIdx.x; i < t.n_counts; i += blockDim.x)
-        a.counts[i] = 0;
+        a.counts[i * kCountStride] = 0;
 }
 
 // ------------------------------------------------------------------ host side
@@ -646,7 +731,7 @@ int stage_a_prepare(gp_job* job)
     job->resv_bits = bits;
     if ((rc = job->d_resv.alloc(4ull << bits)) != GP_OK) // two tables per set
         return rc;
-    if ((rc = job->d_counts.alloc(2 * (kMaxRounds + 2))) != GP_OK)
+    if ((rc = job->d_counts.alloc(2ull * (kMaxRounds + 2) * kCountStride)) != GP_OK)
         return rc;
     if ((rc = job->d_stats.alloc(16)) != GP_OK)
         return rc;
@@ -747,10 +832,10 @@ int stage_a_run(gp_job* job)
     GP_HIP(hipMemsetAsync(job->d_bf.p, 0, job->d_bf.n * sizeof(uint32_t), s));
     GP_HIP(hipMemsetAsync(job->d_stats.p, 0, 16 * sizeof(unsigned long long), s));
     GP_HIP(hipMemsetAsync(job->d_sat.p, 0, job->d_sat.n * sizeof(uint32_t), s));
-    GP_HIP(hipMemsetAsync(job->d_counts.p, 0, 2 * (kMaxRounds + 2) * sizeof(uint32_t), s));
+    GP_HIP(hipMemsetAsync(job->d_counts.p, 0, job->d_counts.n * sizeof(uint32_t), s));
     GP_HIP(hipMemsetAsync(job->d_resv.p, 0xFF, job->d_resv.n * sizeof(unsigned long long), s));
     // stream `s` runs the first passes, stream `s2` the rounds and tails
-    hipStream_t s2 = job->a_stream2;
+    hipStream_t s2 = env_u64("GP_STAGE_A_SERIAL", 0) ? s : job->a_stream2; // debugging aid: one stream
     GP_HIP(hipEventRecord(job->a_ev_init, s));
     GP_HIP(hipStreamWaitEvent(s2, job->a_ev_init, 0));
 
@@ -782,7 +867,7 @@ int stage_a_run(gp_job* job)
     TailArgs t{};
     t.n_rounds = n_rounds;
     t.max_rounds = (uint32_t)tail_span - 16;
-    t.err = job->d_counts.p + kMaxRounds + 1; // last word of set 0's counter array is a flag
+    t.err = job->d_counts.p + (uint64_t)(kMaxRounds + 1) * kCountStride; // last line of set 0's counter array is a flag
     t.stats = job->d_stats.p;
     t.host_ring = job->h_count_pinned;
     std::memset((void*)job->h_count_pinned, 0, 256);
@@ -794,6 +879,8 @@ int stage_a_run(gp_job* job)
     // feedback ring: waiting count of a window, read back without stalling the stream
     uint32_t ring_head = 0, ring_tail = 0, ring_slot = 0; // [tail, head) outstanding
     uint64_t ring_units[kRing];
+    bool ring_looked[kRing]; // did that window's first pass look the counters up (frac is real)?
+    uint32_t since_look = 0;
     volatile uint32_t* hring = job->h_count_pinned;
     auto drain = [&](bool block) -> int {
         while (ring_tail != ring_head) {
@@ -811,7 +898,8 @@ int stage_a_run(gp_job* job)
             } else if (hring[4 * i] != want_seq) {
                 break;
             }
-            const double frac = (double)hring[4 * i + 1] / (double)ring_units[i];
+            // a window that skipped the look-up reports everything as waiting: keep the estimate
+            const double frac = ring_looked[i] ? (double)hring[4 * i + 1] / (double)ring_units[i] : last_frac;
             last_frac = frac;
             // did the grid-wide rounds hand the tail a short list, and how early?
             const uint32_t took_at = hring[4 * i + 2];
@@ -838,6 +926,8 @@ int stage_a_run(gp_job* job)
     // of), yet a window still holds enough operations to fill the chip.  A group of one batch
     // degenerates to consecutive slices of that batch (the long-contig case).
     const uint32_t group_max = (uint32_t)std::max<uint64_t>(1, env_u64("GP_STAGE_A_GROUP", 2048));
+    const double slot_mul = (double)env_u64("GP_STAGE_A_SLOTS_PER_RESV", 8);
+    const bool allow_skip = env_u64("GP_STAGE_A_SKIP_LOOKUP", 1) != 0;
     for (uint32_t g_first = 0; g_first < job->n_batches;) {
         uint32_t g_n = std::min<uint32_t>(group_max, job->n_batches - g_first);
         g_n = (uint32_t)std::min<uint64_t>(g_n, std::max<uint64_t>(1, job->window / kTile));
@@ -876,16 +966,31 @@ int stage_a_run(gp_job* job)
         const uint32_t bcur = g_first;
         const uint64_t w0 = 0, w1 = w_positions; // only their difference is used below
         const uint32_t set = (uint32_t)(wi & 1);
-        uint32_t* counts = job->d_counts.p + set * (kMaxRounds + 2);
+        uint32_t* counts = job->d_counts.p + (uint64_t)set * (kMaxRounds + 2) * kCountStride;
         t.list[0] = job->d_pending[2 * set].p;
         t.list[1] = job->d_pending[2 * set + 1].p;
         t.resv[0] = job->d_resv.p + ((uint64_t)(2 * set) << job->resv_bits);
         t.resv[1] = job->d_resv.p + ((uint64_t)(2 * set + 1) << job->resv_bits);
-        t.info = counts + kMaxRounds - 2;
+        t.info = counts + (uint64_t)kMaxRounds * kCountStride; // a line no round ever counts in
         // this set's buffers were last used by window wi-2: wait for its tail
         if (wi >= 2)
             GP_HIP(hipStreamWaitEvent(s, job->a_ev_tail[set], 0));
         const uint64_t g0 = gen;
+        {
+            // Slots in use: about eight per expected reservation, within the allocation.  A
+            // smaller table keeps the atomics at their full rate (27 G/s up to 2^24 slots,
+            // 22 G/s at 2^26, measured); stale entries of other windows carry larger tags and
+            // lose to any new reservation, so the mapping may change from window to window.
+            const double expect = (double)w_positions * p.n_k * std::min(1.0, last_frac * 1.5) * p.hash_num;
+            uint32_t bits = std::min<uint32_t>(18, job->resv_bits); // never beyond the allocation
+            while (bits < job->resv_bits && (double)(1ull << bits) < slot_mul * expect)
+                bits++;
+            a.resv_bits = bits;
+            // while nearly everything waits the look-up is wasted work; every eighth window
+            // still does it so that the estimate follows the filter filling up
+            a.all_wait = (allow_skip && last_frac > 0.9 && since_look < 7) ? 1u : 0u;
+            since_look = a.all_wait ? since_look + 1 : 0;
+        }
         a.grp_first = g_first;
         a.grp_n = g_n;
         a.tiles_per_batch = tiles_per_batch;
@@ -910,6 +1015,7 @@ int stage_a_run(gp_job* job)
         {
             const uint32_t i = ring_head % kRing;
             ring_units[i] = (w1 - w0) * p.n_k;
+            ring_looked[i] = !a.all_wait;
             ring_slot = i;
         }
         // Rounds and tail on the second stream: they need this window's first pass and, by
@@ -974,7 +1080,7 @@ int stage_a_run(gp_job* job)
     unsigned long long st[4];
     uint32_t tail_err = 0;
     GP_HIP(hipMemcpyAsync(st, job->d_stats.p, sizeof st, hipMemcpyDeviceToHost, s));
-    GP_HIP(hipMemcpyAsync(&tail_err, job->d_counts.p + kMaxRounds + 1, sizeof tail_err,
+    GP_HIP(hipMemcpyAsync(&tail_err, job->d_counts.p + (uint64_t)(kMaxRounds + 1) * kCountStride, sizeof tail_err,
                           hipMemcpyDeviceToHost, s));
     GP_HIP(hipStreamSynchronize(s));
     job->counters.a_positions = st[0];
