@@ -114,15 +114,15 @@ struct gp_job {
     // ---- stage A work buffers
     gp::DevBuf<unsigned long long> d_resv; // reservation slots (hashed), (tag << 32) | position
     uint32_t resv_bits = 0;
-    gp::DevBuf<uint4> d_pending[4];       // [set][list] of {hash lo, hash hi, pos, meta},{idx x4}
+    gp::DevBuf<uint4> d_pending[2];       // two lists of {hash lo, hash hi, pos, meta},{idx x4}; steps alternate
     gp::DevBuf<uint32_t> d_sat, d_batch_thr_max; // saturation flags per (batch, k); max threshold per batch
     gp::DevBuf<uint64_t> d_batch_pos;     // [n_batches+1] first read position of each batch
-    gp::DevBuf<uint32_t> d_counts;        // [kMaxRounds+2] pending count per round
+    gp::DevBuf<uint32_t> d_counts;        // ring of per-step list lengths, one 128-B line each
     gp::DevBuf<unsigned long long> d_stats; // device-side gp_counters
     uint64_t window = 0;
     uint32_t* h_count_pinned = nullptr;
-    hipEvent_t a_ev[16] = {};
-    hipEvent_t a_ev_fp[2] = {}, a_ev_tail[2] = {}, a_ev_init = nullptr;
+    hipEvent_t a_ev[16] = {}, a_ev_b[16] = {}; // per-step joins of the two stage-A streams
+    hipEvent_t a_ev_init = nullptr;
     hipStream_t a_stream2 = nullptr;
 
     // ---- stage B/C state (see stage_b.hip / stage_c.hip)

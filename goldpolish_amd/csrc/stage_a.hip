@@ -18,16 +18,20 @@
 //     -- at ANY time, even ahead of its turn, even from a stale read -- inserts
 //     its k-mer and writes nothing ("settled", try_settle).
 //   * Every other operation takes a deterministic reservation: atomicMin of
-//     (round tag, position) into a hashed slot for each of its counters; in the
-//     next launch the operations that hold all their slots are exactly those
+//     (step tag, position) into a hashed slot for each of its counters; in the
+//     next step the operations that hold all their slots are exactly those
 //     with no earlier unfinished operation on any of their counters, so they
 //     apply the serial update; the rest retry (round_op).  Tags shrink per
-//     launch (newer beats stale), two tables alternate.
-//   * A window (bounded waiting operations per counter) = cbf_first_pass, a few
-//     grid-wide cbf_round launches, then cbf_tail: one workgroup that loops over
-//     the short remaining list with L1-bypassing loads.  No launch waits for the
-//     host; the first pass of the next window runs beside it on a second stream;
-//     feedback (how much waited) returns through mapped host memory.
+//     step (newer beats stale), two tables alternate.
+//   * The work is a stream of steps.  Step s = cbf_round over the waiting list
+//     (everything that has not had its turn yet) beside cbf_first_pass over the
+//     next slice of read positions, which appends its waiting operations to the
+//     list step s+1 consumes.  The list is never drained between slices, so
+//     there is no per-slice tail of small latency-bound launches; only at the end
+//     of a group of batches a few more rounds and cbf_tail (one workgroup looping
+//     with L1-bypassing loads) finish what is left.  No launch waits for the
+//     host; feedback (list length, waiting fraction) returns through mapped host
+//     memory and steers the slice size.
 //   * cbf_check_sat marks (batch, k) pairs whose counters and filter can no
 //     longer change; their k-mers then cost nothing.
 //
@@ -49,10 +53,12 @@ constexpr int kTile = 1024;        // positions per workgroup
 constexpr int kPerThread = 4;      // consecutive positions per lane
 constexpr int kBlock = kTile / kPerThread;
 constexpr int kHalo = 64;          // k <= 64
-constexpr uint32_t kMaxRounds = 4094;
 constexpr int kRoundBlocks = 2048;
-constexpr uint32_t kRing = 16;
-constexpr uint32_t kCountStride = 32; // one 128-B line per round counter: appends of different rounds never share a line
+constexpr uint32_t kRing = 16;         // feedback slots in mapped host memory
+constexpr uint32_t kAhead = 8;         // steps the host may be ahead of the latest report
+constexpr uint32_t kSteps = 16;        // ring of per-step list counters
+constexpr uint32_t kDrainRounds = 12;  // grid-wide rounds launched before the tail (< kSteps - 2)
+constexpr uint32_t kCountStride = 32;  // one 128-B line per step: word 0 = list length, word 1 = waiting operations the first pass added
 
 struct AArgs {
     const uint8_t* reads;
@@ -70,22 +76,27 @@ struct AArgs {
     uint32_t bf_words;
     FastMod cbf_mod, bf_mod;
     KConsts kc[GP_MAX_K_VALUES];
-    // reservation slots, (round tag << 32) | window position; two tables alternate so that
+    // reservation slots, (step tag << 32) | position key; two tables alternate so that
     // the reservations a launch makes never disturb the ones it is still checking
     unsigned long long* resv;      // table the incoming list reserved in
     unsigned long long* resv_out;  // table this launch reserves in
-    uint64_t tag_cur;    // 40-bit tag the incoming list reserved with
+    uint64_t tag_cur;    // 32-bit tag the incoming list reserved with
     uint64_t tag_next;   // tag for reservations made by this launch (always smaller: newer wins)
     uint32_t* sat;       // per (batch, k): bit 0 = every counter >= max thr-1, bit 1 = filter all ones
     const uint32_t* batch_thr_max; // per batch: largest kmer_threshold of its contigs
-    uint32_t tail_from;  // first round the tail kernel may take over (see cbf_tail)
-    uint32_t tail_max;   // lists up to this long are left to the tail kernel
-    uint32_t resv_bits;  // slots in use this window (<= the allocation), see stage_a_run
+    uint32_t tail_max;   // while draining: lists up to this long are left to the tail kernel
+    uint32_t bits_in;    // log2 slots of the table being checked (what the previous step reserved with)
+    uint32_t bits_out;   // log2 slots this step reserves with (<= the allocation), see stage_a_run
     uint32_t all_wait;   // 1: nearly every operation waits anyway; the first pass skips the counter look-up
+    uint32_t drain;      // 1: end of a group, cbf_tail follows (no feedback, counters left for it)
+    uint32_t pos_base;   // slice number << 24: orders operations of different slices
     uint4* list_in;
     uint4* list_out;
-    uint32_t* counts;    // counts[r] = length of the list round r consumes
-    uint32_t round;
+    uint32_t* count_in;   // counter line of the list this step consumes
+    uint32_t* count_out;  // ... of the list it produces (cbf_round and cbf_first_pass both append)
+    uint32_t* count_zero; // the line the previous step consumed, cleared for reuse (or null)
+    volatile uint32_t* host_ring; // mapped host memory: 4 words per slot {seq, list length, fresh waiting, -}
+    uint32_t ring_slot, ring_seq;
     // a window = the same slice [off, off + slice) of every batch of a group (batch-relative
     // positions), one or more 1024-position tiles per batch
     const uint64_t* batch_pos; // [n_batches+1] first read position of each batch
@@ -94,10 +105,10 @@ struct AArgs {
     unsigned long long* stats; // [0] positions [1] ops [2] ordered ops
 };
 
-__device__ inline uint32_t resv_slot(const AArgs& a, uint32_t stream, uint32_t idx)
+__device__ inline uint32_t resv_slot(const AArgs& a, uint32_t bits, uint32_t stream, uint32_t idx)
 {
     uint64_t key = (uint64_t)stream * a.cbf_bytes + idx;
-    return (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> (64 - a.resv_bits));
+    return (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> (64 - bits));
 }
 
 // Counters never pass their stream's threshold, and GoldPolish's thresholds are <= 14, so
@@ -169,7 +180,7 @@ __device__ inline bool try_settle(const AArgs& a, uint32_t stream, uint32_t thr,
 // and the earlier position second; stale entries of older rounds never need clearing.
 __device__ inline unsigned long long resv_word(uint64_t tag, uint32_t pos)
 {
-    return ((unsigned long long)tag << 24) | pos; // window positions are < 2^24
+    return ((unsigned long long)tag << 32) | pos;
 }
 
 __device__ inline void reserve(const AArgs& a, uint32_t stream, const uint32_t* idx,
@@ -177,7 +188,7 @@ __device__ inline void reserve(const AArgs& a, uint32_t stream, const uint32_t* 
 {
     const unsigned long long w = resv_word(a.tag_next, pos);
     for (uint32_t i = 0; i < a.hash_num; i++)
-        atomicMin(&a.resv_out[resv_slot(a, stream, idx[i])], w);
+        atomicMin(&a.resv_out[resv_slot(a, a.bits_out, stream, idx[i])], w);
 }
 
 
@@ -186,7 +197,8 @@ __device__ inline void reserve(const AArgs& a, uint32_t stream, const uint32_t* 
 // (Per-wave appends to one word serialise at about 90 per microsecond chip-wide; with four
 // lists of a window in flight that was a third of a window's time.)
 template <int THREADS>
-__device__ inline uint32_t block_append(uint32_t* counter, uint32_t n_mine, uint32_t* s_wave /*[THREADS/64 + 1]*/)
+__device__ inline uint32_t block_append(uint32_t* counter, uint32_t n_mine, uint32_t* s_wave /*[THREADS/64 + 1]*/,
+                                        uint32_t* also = nullptr)
 {
     constexpr int kWaves = THREADS / 64;
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
@@ -207,6 +219,8 @@ __device__ inline uint32_t block_append(uint32_t* counter, uint32_t n_mine, uint
             tot += c;
         }
         s_wave[kWaves] = tot ? atomicAdd(counter, tot) : 0u;
+        if (tot && also)
+            atomicAdd(also, tot);
     }
     __syncthreads();
     const uint32_t at = s_wave[kWaves] + s_wave[wave] + incl - n_mine;
@@ -363,7 +377,7 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
     }
     // pass 3: one list append per workgroup, then reservations + records
     {
-        uint32_t at = block_append<kBlock>(&a.counts[0], n_ordered, s_wave);
+        uint32_t at = block_append<kBlock>(a.count_out, n_ordered, s_wave, a.count_out + 1);
 #pragma unroll
         for (int j = 0; j < kPerThread; j++) {
             if (!op_state[j])
@@ -371,7 +385,7 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
             const uint32_t seg_j = op_seg[j];
             const uint32_t stream = a.seg_batch[seg_j] * a.n_k + ki;
             // order key: tiles of a batch are consecutive blocks in increasing position order
-            const uint32_t rel = blockIdx.x * (uint32_t)kTile + (uint32_t)(t0 + j);
+            const uint32_t rel = a.pos_base | (blockIdx.x * (uint32_t)kTile + (uint32_t)(t0 + j));
             uint32_t idx[kMaxHash];
             for (uint32_t h = 0; h < a.hash_num; h++)
                 idx[h] = h < 4 ? op_idx[j][h] : (uint32_t)fastmod(ext_hash(op_base[j], k, h), a.cbf_mod);
@@ -476,7 +490,7 @@ __device__ inline T ld(const T* p)
 template <bool FRESH>
 __device__ inline bool round_op(const AArgs& a, const uint4 rec, const uint4 rix,
                                 const unsigned long long* resv_in, unsigned long long* resv_out,
-                                uint64_t tag_cur, uint64_t tag_next)
+                                uint64_t tag_cur, uint64_t tag_next, uint32_t bits_in)
 {
     const uint64_t base = ((uint64_t)rec.y << 32) | rec.x;
     const uint32_t pos = rec.z;
@@ -492,7 +506,7 @@ __device__ inline bool round_op(const AArgs& a, const uint4 rec, const uint4 rix
     const unsigned long long want = resv_word(tag_cur, pos);
     bool mine = true;
     for (uint32_t h = 0; h < a.hash_num; h++)
-        mine &= (ld<FRESH>(&resv_in[resv_slot(a, stream, idx[h])]) == want);
+        mine &= (ld<FRESH>(&resv_in[resv_slot(a, bits_in, stream, idx[h])]) == want);
 
     uint8_t* cb = a.cbf + (uint64_t)stream * a.cbf_stride;
     uint32_t c[kMaxHash], m = 255;
@@ -519,7 +533,7 @@ __device__ inline bool round_op(const AArgs& a, const uint4 rec, const uint4 rix
     } else {
         const unsigned long long w = resv_word(tag_next, pos);
         for (uint32_t h = 0; h < a.hash_num; h++)
-            atomicMin(&resv_out[resv_slot(a, stream, idx[h])], w);
+            atomicMin(&resv_out[resv_slot(a, a.bits_out, stream, idx[h])], w);
         return true;
     }
     if (insert) {
@@ -536,9 +550,22 @@ __device__ inline bool round_op(const AArgs& a, const uint4 rec, const uint4 rix
 __global__ __launch_bounds__(256) void cbf_round(AArgs a)
 {
     __shared__ uint32_t s_wave[256 / 64 + 1];
-    const uint32_t n_in = a.counts[a.round * kCountStride];
-    if (a.round >= a.tail_from && n_in <= a.tail_max)
-        return; // short list: cbf_tail finishes it without further launches
+    const uint32_t n_in = a.count_in[0];
+    if (a.drain) {
+        if (n_in <= a.tail_max)
+            return; // short list: cbf_tail finishes it without further launches
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // feedback for the host, straight into mapped host memory; the sequence number last
+        volatile uint32_t* slot = a.host_ring + 4 * a.ring_slot;
+        slot[1] = n_in;
+        slot[2] = a.count_in[1];
+        __threadfence_system();
+        slot[0] = a.ring_seq;
+        if (a.count_zero) {
+            a.count_zero[0] = 0;
+            a.count_zero[1] = 0;
+        }
+    }
     for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n_in; i0 += gridDim.x * blockDim.x) {
         const uint32_t i = i0 + threadIdx.x;
         uint4 rec = {}, rix = {};
@@ -546,9 +573,9 @@ __global__ __launch_bounds__(256) void cbf_round(AArgs a)
         if (i < n_in) {
             rec = a.list_in[2 * i];
             rix = a.list_in[2 * i + 1];
-            waits = round_op<false>(a, rec, rix, a.resv, a.resv_out, a.tag_cur, a.tag_next);
+            waits = round_op<false>(a, rec, rix, a.resv, a.resv_out, a.tag_cur, a.tag_next, a.bits_in);
         }
-        const uint32_t at = block_append<256>(&a.counts[(a.round + 1) * kCountStride], waits ? 1u : 0u, s_wave);
+        const uint32_t at = block_append<256>(a.count_out, waits ? 1u : 0u, s_wave);
         if (waits) {
             a.list_out[2 * at] = rec;
             a.list_out[2 * at + 1] = rix;
@@ -556,49 +583,47 @@ __global__ __launch_bounds__(256) void cbf_round(AArgs a)
     }
 }
 
-// ---- the tail of a window: one workgroup keeps running rounds on the list the grid-wide
-// rounds left (the first list no longer than tail_max, or whatever is left after the last
-// of them) until nothing waits.  Rounds are separated by workgroup barriers; every load of
-// data another wave may have written in an earlier round bypasses L1.
+// ---- the tail of a group: one workgroup keeps running rounds on the list the grid-wide
+// drain rounds left (the first list no longer than tail_max, or whatever is left after the
+// last of them) until nothing waits.  Rounds are separated by workgroup barriers; every load
+// of data another wave may have written in an earlier round bypasses L1.
 constexpr int kTailThreads = 1024;
 
 struct TailArgs {
-    uint4* list[2];
+    uint4* list[2];               // indexed by step parity
     unsigned long long* resv[2];
-    uint64_t tag_first;   // tag of round 0 of this window; round r uses tag_first - r
-    uint32_t n_rounds;    // grid-wide rounds that were launched
+    uint32_t* counts;     // the ring of counter lines
+    uint64_t tag_max;     // step s checks reservations made with tag_max - s
+    uint64_t step0;       // first drain step
+    uint32_t n_rounds;    // grid-wide drain rounds that were launched
     uint32_t max_rounds;  // bug trap
     uint32_t* err;
-    uint32_t* info;       // [0] round at which the tail took over, [1] list length then
-    volatile uint32_t* host_ring; // mapped host memory: 4 words per slot {seq, waiting, took_at, took_len}
-    uint32_t ring_slot, ring_seq;
-    uint32_t n_counts;    // counters to zero for the next user of this buffer set
     unsigned long long* stats; // [3] rounds run by the tail
 };
 
 __global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
 {
     __shared__ uint32_t s_n, s_out;
+    __shared__ uint64_t s_step;
     if (threadIdx.x == 0) {
         uint32_t r = 0;
-        while (r < t.n_rounds && !(r >= a.tail_from && a.counts[r * kCountStride] <= a.tail_max))
+        while (r < t.n_rounds && t.counts[((t.step0 + r) % kSteps) * kCountStride] > a.tail_max)
             r++;
-        s_n = a.counts[r * kCountStride];
-        s_out = r; // reused below as "current round" until the loop starts
-        t.info[0] = r;
-        t.info[1] = s_n;
+        s_n = t.counts[((t.step0 + r) % kSteps) * kCountStride];
+        s_step = t.step0 + r;
     }
     __syncthreads();
-    uint32_t n = s_n, round = s_out;
+    uint32_t n = s_n;
+    uint64_t step = s_step;
     __syncthreads();
     uint32_t done_rounds = 0;
     while (n > 0) {
         if (threadIdx.x == 0)
             s_out = 0;
         __syncthreads();
-        const uint4* in = t.list[round & 1];
-        uint4* out = t.list[(round + 1) & 1];
-        const uint64_t tag_cur = t.tag_first - round, tag_next = tag_cur - 1;
+        const uint4* in = t.list[step & 1];
+        uint4* out = t.list[(step + 1) & 1];
+        const uint64_t tag_cur = t.tag_max - step, tag_next = tag_cur - 1;
         for (uint32_t i = threadIdx.x; i < n; i += kTailThreads) {
             uint4 rec, rix;
             {
@@ -609,8 +634,9 @@ __global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
                 rec = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
                 rix = make_uint4((uint32_t)w2, (uint32_t)(w2 >> 32), (uint32_t)w3, (uint32_t)(w3 >> 32));
             }
-            if (round_op<true>(a, rec, rix, t.resv[round & 1], t.resv[(round + 1) & 1], tag_cur,
-                               tag_next)) {
+            // the drain keeps the slot count fixed: bits_in == bits_out for every tail round
+            if (round_op<true>(a, rec, rix, t.resv[step & 1], t.resv[(step + 1) & 1], tag_cur,
+                               tag_next, a.bits_out)) {
                 uint32_t at = atomicAdd(&s_out, 1u);
                 out[2 * at] = rec;
                 out[2 * at + 1] = rix;
@@ -619,7 +645,7 @@ __global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
         __threadfence();
         __syncthreads();
         n = s_out;
-        round++;
+        step++;
         done_rounds++;
         __syncthreads();
         if (done_rounds > t.max_rounds) {
@@ -628,23 +654,11 @@ __global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
             break;
         }
     }
-    if (threadIdx.x == 0) {
-        if (done_rounds)
-            atomicAdd(&t.stats[3], (unsigned long long)done_rounds);
-        // feedback for the host (how much waited, where the tail took over), written straight
-        // into mapped host memory; the sequence number goes last
-        volatile uint32_t* slot = t.host_ring + 4 * t.ring_slot;
-        slot[1] = a.counts[0];
-        slot[2] = t.info[0];
-        slot[3] = t.info[1];
-        __threadfence_system();
-        slot[0] = t.ring_seq;
-        __threadfence_system();
-    }
-    __syncthreads();
-    // leave the counter array clean for the window that uses this buffer set next
-    for (uint32_t i = threadIdx.x; i < t.n_counts; i += blockDim.x)
-        a.counts[i * kCountStride] = 0;
+    if (threadIdx.x == 0 && done_rounds)
+        atomicAdd(&t.stats[3], (unsigned long long)done_rounds);
+    // nothing waits any more: every counter line is free again
+    for (uint32_t i = threadIdx.x; i < kSteps * kCountStride; i += blockDim.x)
+        t.counts[i] = 0;
 }
 
 // ------------------------------------------------------------------ host side
@@ -706,8 +720,8 @@ static uint64_t env_u64(const char* name, uint64_t dflt)
 int stage_a_prepare(gp_job* job)
 {
     const gp_params& p = job->prm;
-    // window: how many read positions are hashed per launch.  The pending lists
-    // are sized for the worst case (every k-mer of every k must wait).
+    // window: the most read positions one first-pass launch may cover.  The waiting lists
+    // are sized for the worst case (every k-mer of every k of a window waits).
     uint64_t w = env_u64("GP_STAGE_A_WINDOW", 8ull << 20);
     w = std::max<uint64_t>(w, kTile);
     w = std::min<uint64_t>(w, std::max<uint64_t>(job->read_positions, kTile));
@@ -719,19 +733,18 @@ int stage_a_prepare(gp_job* job)
         return GP_ERR_INVALID_ARG;
     }
     int rc;
-    // two sets (windows alternate between them so that the first pass of window w+1 can
-    // run beside the rounds of window w), two lists per set, two uint4 per record
-    for (int i = 0; i < 4; i++)
+    // two lists (steps alternate), two uint4 per record
+    for (int i = 0; i < 2; i++)
         if ((rc = job->d_pending[i].alloc(2 * max_pending)) != GP_OK)
             return rc;
-    // reservation slots: two per possible waiting counter touch, power of two, <= 1 GiB
+    // reservation slots: two per possible waiting counter touch, power of two, <= 512 MiB a table
     uint32_t bits = 16;
     while ((1ull << bits) < max_pending * p.hash_num * 2 && bits < 26)
         bits++;
     job->resv_bits = bits;
-    if ((rc = job->d_resv.alloc(4ull << bits)) != GP_OK) // two tables per set
+    if ((rc = job->d_resv.alloc(2ull << bits)) != GP_OK) // two tables
         return rc;
-    if ((rc = job->d_counts.alloc(2ull * (kMaxRounds + 2) * kCountStride)) != GP_OK)
+    if ((rc = job->d_counts.alloc((uint64_t)(kSteps + 1) * kCountStride)) != GP_OK) // + a line for the error flag
         return rc;
     if ((rc = job->d_stats.alloc(16)) != GP_OK)
         return rc;
@@ -749,12 +762,10 @@ int stage_a_prepare(gp_job* job)
             GP_HIP(hipMemcpy(job->d_batch_thr_max.p, tm.data(), tm.size() * sizeof(uint32_t),
                              hipMemcpyHostToDevice));
     }
-    GP_HIP(hipHostMalloc((void**)&job->h_count_pinned, 256));
-    for (uint32_t i = 0; i < kRing; i++)
+    GP_HIP(hipHostMalloc((void**)&job->h_count_pinned, 4 * kRing * sizeof(uint32_t)));
+    for (uint32_t i = 0; i < kRing; i++) {
         GP_HIP(hipEventCreateWithFlags(&job->a_ev[i], hipEventDisableTiming));
-    for (int i = 0; i < 2; i++) {
-        GP_HIP(hipEventCreateWithFlags(&job->a_ev_fp[i], hipEventDisableTiming));
-        GP_HIP(hipEventCreateWithFlags(&job->a_ev_tail[i], hipEventDisableTiming));
+        GP_HIP(hipEventCreateWithFlags(&job->a_ev_b[i], hipEventDisableTiming));
     }
     GP_HIP(hipEventCreateWithFlags(&job->a_ev_init, hipEventDisableTiming));
     GP_HIP(hipStreamCreateWithFlags(&job->a_stream2, hipStreamNonBlocking));
@@ -766,14 +777,11 @@ void stage_a_release(gp_job* job)
     if (job->h_count_pinned)
         (void)hipHostFree(job->h_count_pinned);
     job->h_count_pinned = nullptr;
-    for (uint32_t i = 0; i < kRing; i++)
+    for (uint32_t i = 0; i < kRing; i++) {
         if (job->a_ev[i])
             (void)hipEventDestroy(job->a_ev[i]);
-    for (int i = 0; i < 2; i++) {
-        if (job->a_ev_fp[i])
-            (void)hipEventDestroy(job->a_ev_fp[i]);
-        if (job->a_ev_tail[i])
-            (void)hipEventDestroy(job->a_ev_tail[i]);
+        if (job->a_ev_b[i])
+            (void)hipEventDestroy(job->a_ev_b[i]);
     }
     if (job->a_ev_init)
         (void)hipEventDestroy(job->a_ev_init);
@@ -817,10 +825,12 @@ int stage_a_run(gp_job* job)
             a.kc[i].in_rev[c] = sroln(seed_of_code(c ^ 2), p.k[i]);
         }
     }
-    a.resv_bits = job->resv_bits;
+    a.bits_in = a.bits_out = std::min<uint32_t>(18, job->resv_bits);
     a.stats = job->d_stats.p;
     a.sat = job->d_sat.p;
     a.batch_thr_max = job->d_batch_thr_max.p;
+    a.host_ring = job->h_count_pinned;
+    a.tail_max = (uint32_t)env_u64("GP_STAGE_A_TAIL", 4096);
 
     job->t_first_pass.reset();
     job->t_round.reset();
@@ -835,7 +845,7 @@ int stage_a_run(gp_job* job)
     GP_HIP(hipMemsetAsync(job->d_counts.p, 0, job->d_counts.n * sizeof(uint32_t), s));
     GP_HIP(hipMemsetAsync(job->d_resv.p, 0xFF, job->d_resv.n * sizeof(unsigned long long), s));
     // stream `s` runs the first passes, stream `s2` the rounds and tails
-    hipStream_t s2 = env_u64("GP_STAGE_A_SERIAL", 0) ? s : job->a_stream2; // debugging aid: one stream
+    hipStream_t s2 = job->a_stream2;
     GP_HIP(hipEventRecord(job->a_ev_init, s));
     GP_HIP(hipStreamWaitEvent(s2, job->a_ev_init, 0));
 
@@ -844,12 +854,6 @@ int stage_a_run(gp_job* job)
         return GP_OK;
     }
 
-    // Window = the slice of read positions hashed per first-pass launch.  What makes the
-    // reservation rounds expensive is many waiting operations per counter, so a window
-    // takes at most `lim` positions of any one batch (hash_num * lim touches over
-    // cbf_bytes counters: a load of 1/4 at scale 1) but as many whole batches as fit.
-    // Once a filter is saturated nearly everything settles in the first pass; the
-    // window then grows again (feedback on the waiting fraction of the last window).
     std::vector<uint64_t> batch_pos(job->n_batches + 1);
     for (uint32_t bi = 0; bi < job->n_batches; bi++)
         batch_pos[bi] = job->h_seg_start[job->h_batch_contig_begin[bi]];
@@ -858,76 +862,119 @@ int stage_a_run(gp_job* job)
                           hipMemcpyHostToDevice, s));
     GP_HIP(hipStreamSynchronize(s)); // batch_pos is a local
     a.batch_pos = job->d_batch_pos.p;
+
+    // Slice = the read positions of one batch a step's first pass hashes.  What makes the
+    // rounds expensive is many waiting operations per counter, so a slice takes at most
+    // `lim` positions of any one batch (hash_num * lim touches over cbf_bytes counters) but
+    // as many whole batches as fit.  Once a filter is saturated nearly everything settles
+    // in the first pass; the slice then grows (feedback on the waiting fraction).
     const uint64_t load_div = std::max<uint64_t>(1, env_u64("GP_STAGE_A_LOAD_DIV", 6));
     const uint64_t lim0 = std::max<uint64_t>(kTile, p.cbf_bytes / (load_div * p.hash_num));
-    const uint32_t n_rounds = (uint32_t)std::min<uint64_t>(env_u64("GP_STAGE_A_ROUNDS", 6), kMaxRounds);
-    const uint64_t tag_max = (1ull << 40) - 1, tail_span = 1ull << 22;
-    a.tail_from = 2;
-    a.tail_max = (uint32_t)env_u64("GP_STAGE_A_TAIL", 4096);
+    const double wait_cap = (double)env_u64("GP_STAGE_A_WAITCAP", 3000000); // operations expected to wait, per step
+    const double slot_mul = (double)env_u64("GP_STAGE_A_SLOTS_PER_RESV", 8);
+    const bool allow_skip = env_u64("GP_STAGE_A_SKIP_LOOKUP", 1) != 0;
+    const uint32_t group_max = (uint32_t)std::max<uint64_t>(1, env_u64("GP_STAGE_A_GROUP", 2048));
+    const uint64_t max_pending = job->window * p.n_k; // list capacity, operations
+    const uint64_t tag_max = 0xFFFFFFFFull, tail_span = 1ull << 22;
+
+    uint32_t* const counts = job->d_counts.p;
+    uint32_t* const err_flag = counts + (uint64_t)kSteps * kCountStride;
+    uint4* const lists[2] = { job->d_pending[0].p, job->d_pending[1].p };
+    unsigned long long* const tables[2] = { job->d_resv.p, job->d_resv.p + (1ull << job->resv_bits) };
     TailArgs t{};
-    t.n_rounds = n_rounds;
+    t.list[0] = lists[0];
+    t.list[1] = lists[1];
+    t.resv[0] = tables[0];
+    t.resv[1] = tables[1];
+    t.counts = counts;
+    t.tag_max = tag_max;
+    t.n_rounds = kDrainRounds;
     t.max_rounds = (uint32_t)tail_span - 16;
-    t.err = job->d_counts.p + (uint64_t)(kMaxRounds + 1) * kCountStride; // last line of set 0's counter array is a flag
+    t.err = err_flag;
     t.stats = job->d_stats.p;
-    t.host_ring = job->h_count_pinned;
-    std::memset((void*)job->h_count_pinned, 0, 256);
-    uint64_t wi = 0; // window index; its parity picks the buffer set
-    const auto t_host0 = std::chrono::steady_clock::now();
-    uint64_t scale = 1, gen = 1;
-    double last_frac = 1.0; // waiting fraction of the most recent window we know about
-    uint32_t want_rounds = n_rounds; // grid-wide rounds per window, steered by the same feedback
-    // feedback ring: waiting count of a window, read back without stalling the stream
-    uint32_t ring_head = 0, ring_tail = 0, ring_slot = 0; // [tail, head) outstanding
-    uint64_t ring_units[kRing];
-    bool ring_looked[kRing]; // did that window's first pass look the counters up (frac is real)?
-    uint32_t since_look = 0;
+
+    // feedback ring: what a step's cbf_round saw, read back without stalling the streams
     volatile uint32_t* hring = job->h_count_pinned;
-    auto drain = [&](bool block) -> int {
+    std::memset((void*)job->h_count_pinned, 0, 4 * kRing * sizeof(uint32_t));
+    struct StepNote {
+        uint64_t prev_units; // operations the previous step's first pass looked at
+        bool prev_looked;    // ... and whether it looked the counters up (its waiting count is real)
+        bool hashed;         // this step ran a first pass beside its round
+    } notes[kRing];
+    // Rounds per first pass: two.  About half of a waiting list holds all its slots in a
+    // round (true conflicts on a long contig's one filter; slot collisions when hundreds of
+    // small filters share the table), so hashing a new slice every step lets the list grow
+    // until chains per counter are long; one round-only step between slices keeps it short
+    // (measured: 47 ms instead of 63 per 10 Mbp contig, 790 instead of 1670 on 400 x 25 kbp).
+    // Fixed rather than steered: feedback arrives several steps late, too late to stop growth.
+    const uint32_t ahead = (uint32_t)std::min<uint64_t>(kRing, std::max<uint64_t>(1, env_u64("GP_STAGE_A_AHEAD", kAhead)));
+    const uint32_t cadence = (uint32_t)std::max<uint64_t>(1, env_u64("GP_STAGE_A_CADENCE", 2));
+    uint32_t rounds_since_fp = 0;
+    uint32_t ring_head = 0, ring_tail = 0; // [tail, head) outstanding
+    uint64_t known_in = 0;   // list length in the latest report
+    uint64_t unacked = 0;    // operations of first passes whose outcome no report covers yet
+    double last_frac = 1.0;  // waiting fraction of the most recent first pass we know about
+    uint64_t scale = 1;
+    uint32_t since_look = 0;
+    auto drain_feedback = [&](bool block) -> int {
         while (ring_tail != ring_head) {
             const uint32_t i = ring_tail % kRing;
             const uint32_t want_seq = ring_tail + 1;
             if (block) {
-                // only when the host is a full ring ahead of the device
                 uint64_t spins = 0;
                 while (hring[4 * i] != want_seq) {
                     if (++spins > (1ull << 34)) {
-                        set_error("stage A: device stopped reporting window feedback");
+                        set_error("stage A: device stopped reporting step feedback");
                         return GP_ERR_STATE;
                     }
                 }
+                block = false; // one report is enough to make progress
             } else if (hring[4 * i] != want_seq) {
                 break;
             }
-            // a window that skipped the look-up reports everything as waiting: keep the estimate
-            const double frac = ring_looked[i] ? (double)hring[4 * i + 1] / (double)ring_units[i] : last_frac;
-            last_frac = frac;
-            // did the grid-wide rounds hand the tail a short list, and how early?
-            const uint32_t took_at = hring[4 * i + 2];
-            const uint32_t took_len = hring[4 * i + 3];
-            if (took_len > a.tail_max)
-                want_rounds = std::min<uint32_t>(want_rounds * 2, 512);
-            else
-                want_rounds = std::max<uint32_t>(2, std::min<uint32_t>(want_rounds, took_at + 2));
-            if (took_len > 16 * a.tail_max && scale > 1)
-                scale /= 2; // the single-workgroup tail got far too much: smaller windows
-            if (frac < 0.05)
-                scale = std::min<uint64_t>(scale * 4, 1u << 16);
-            else if (frac < 0.15)
-                scale = std::min<uint64_t>(scale * 2, 1u << 16);
-            else if (frac > 0.6 && scale > 1)
-                scale /= 2;
+            known_in = hring[4 * i + 1];
+            unacked -= std::min(unacked, notes[i].prev_units);
+            if (notes[i].prev_looked && notes[i].prev_units) {
+                const double frac = (double)hring[4 * i + 2] / (double)notes[i].prev_units;
+                last_frac = frac;
+                if (frac < 0.05)
+                    scale = std::min<uint64_t>(scale * 4, 1u << 16);
+                else if (frac < 0.15)
+                    scale = std::min<uint64_t>(scale * 2, 1u << 16);
+                else if (frac > 0.6 && scale > 1)
+                    scale /= 2;
+            }
             ring_tail++;
         }
         return GP_OK;
     };
-    // Batches are taken in groups; every window covers the same slice [off, off + slice) of
+
+    uint64_t step = 0;            // global step number: list/table parity and tag
+    uint64_t n_first_pass = 0;
+    bool span_open = false;
+    uint64_t prev_units = 0;
+    bool prev_looked = false;
+    const auto t_host0 = std::chrono::steady_clock::now();
+    const bool debug = env_u64("GP_STAGE_A_DEBUG", 0) != 0;
+
+    // one step's cbf_round on s2 (a.drain selects the group-end flavour)
+    auto launch_round = [&](uint32_t blocks) {
+        a.tag_cur = tag_max - step;
+        a.tag_next = a.tag_cur - 1;
+        a.resv = tables[step & 1];
+        a.resv_out = tables[(step + 1) & 1];
+        a.list_in = lists[step & 1];
+        a.list_out = lists[(step + 1) & 1];
+        a.count_in = counts + (step % kSteps) * kCountStride;
+        a.count_out = counts + ((step + 1) % kSteps) * kCountStride;
+        a.count_zero = step ? counts + ((step - 1) % kSteps) * kCountStride : nullptr;
+        hipLaunchKernelGGL(cbf_round, dim3(blocks), dim3(256), 0, s2, a);
+    };
+
+    // Batches are taken in groups; every slice covers the same range [off, off + slice) of
     // every batch of the group.  Many small batches therefore advance in lockstep: each filter
-    // sees only a sliver of its reads per window (no chains of waiting operations to speak
-    // of), yet a window still holds enough operations to fill the chip.  A group of one batch
-    // degenerates to consecutive slices of that batch (the long-contig case).
-    const uint32_t group_max = (uint32_t)std::max<uint64_t>(1, env_u64("GP_STAGE_A_GROUP", 2048));
-    const double slot_mul = (double)env_u64("GP_STAGE_A_SLOTS_PER_RESV", 8);
-    const bool allow_skip = env_u64("GP_STAGE_A_SKIP_LOOKUP", 1) != 0;
+    // sees only a sliver of its reads per step, yet a step still holds enough operations to
+    // fill the chip.  A group of one batch degenerates to consecutive slices of that batch.
     for (uint32_t g_first = 0; g_first < job->n_batches;) {
         uint32_t g_n = std::min<uint32_t>(group_max, job->n_batches - g_first);
         g_n = (uint32_t)std::min<uint64_t>(g_n, std::max<uint64_t>(1, job->window / kTile));
@@ -936,143 +983,180 @@ int stage_a_run(gp_job* job)
             longest = std::max(longest, batch_pos[bi + 1] - batch_pos[bi]);
         scale = 1;
         last_frac = 1.0;
-      for (uint64_t off = 0; off < longest;) {
-        int rc = drain(ring_head - ring_tail >= kRing);
-        if (rc != GP_OK)
-            return rc;
-        // per-batch slice: bounded by the per-filter load (lim), by the total number of
-        // operations expected to wait (about 3 M per window), and by the buffers
-        const uint64_t wmax = std::min<uint64_t>(
-            job->window,
-            std::max<uint64_t>(kTile, (uint64_t)(3.0e6 / ((double)p.n_k * std::max(last_frac, 0.02)))));
-        uint64_t slice = std::min<uint64_t>(lim0 * scale, std::max<uint64_t>(kTile, wmax / g_n));
-        slice = std::max<uint64_t>(kTile, slice / kTile * kTile);
-        slice = std::min<uint64_t>(slice, (longest - off + kTile - 1) / kTile * kTile);
-        const uint32_t tiles_per_batch = (uint32_t)(slice / kTile);
-        if ((uint64_t)tiles_per_batch * g_n * kTile > job->window || (uint64_t)tiles_per_batch * g_n >= (1u << 14)) {
-            set_error("stage A: window does not fit the work buffers");
-            return GP_ERR_STATE;
-        }
-        uint64_t w_positions = 0; // positions this window really covers
-        for (uint32_t bi = g_first; bi < g_first + g_n; bi++) {
-            const uint64_t len = batch_pos[bi + 1] - batch_pos[bi];
-            if (len > off)
-                w_positions += std::min<uint64_t>(slice, len - off);
-        }
-        if (w_positions == 0) {
-            off += slice;
-            continue;
-        }
-        const uint32_t bcur = g_first;
-        const uint64_t w0 = 0, w1 = w_positions; // only their difference is used below
-        const uint32_t set = (uint32_t)(wi & 1);
-        uint32_t* counts = job->d_counts.p + (uint64_t)set * (kMaxRounds + 2) * kCountStride;
-        t.list[0] = job->d_pending[2 * set].p;
-        t.list[1] = job->d_pending[2 * set + 1].p;
-        t.resv[0] = job->d_resv.p + ((uint64_t)(2 * set) << job->resv_bits);
-        t.resv[1] = job->d_resv.p + ((uint64_t)(2 * set + 1) << job->resv_bits);
-        t.info = counts + (uint64_t)kMaxRounds * kCountStride; // a line no round ever counts in
-        // this set's buffers were last used by window wi-2: wait for its tail
-        if (wi >= 2)
-            GP_HIP(hipStreamWaitEvent(s, job->a_ev_tail[set], 0));
-        const uint64_t g0 = gen;
-        {
-            // Slots in use: about eight per expected reservation, within the allocation.  A
-            // smaller table keeps the atomics at their full rate (27 G/s up to 2^24 slots,
-            // 22 G/s at 2^26, measured); stale entries of other windows carry larger tags and
-            // lose to any new reservation, so the mapping may change from window to window.
-            const double expect = (double)w_positions * p.n_k * std::min(1.0, last_frac * 1.5) * p.hash_num;
-            uint32_t bits = std::min<uint32_t>(18, job->resv_bits); // never beyond the allocation
-            while (bits < job->resv_bits && (double)(1ull << bits) < slot_mul * expect)
-                bits++;
-            a.resv_bits = bits;
-            // while nearly everything waits the look-up is wasted work; every eighth window
-            // still does it so that the estimate follows the filter filling up
-            a.all_wait = (allow_skip && last_frac > 0.9 && since_look < 7) ? 1u : 0u;
-            since_look = a.all_wait ? since_look + 1 : 0;
-        }
-        a.grp_first = g_first;
-        a.grp_n = g_n;
-        a.tiles_per_batch = tiles_per_batch;
-        a.off = off;
-        a.slice = slice;
-        a.counts = counts;
-        a.resv = nullptr;
-        a.resv_out = t.resv[0];
-        a.tag_cur = 0;
-        a.tag_next = tag_max - g0;
-        a.list_in = nullptr;
-        a.list_out = t.list[0];
-        a.round = 0;
-        dim3 grid(tiles_per_batch * g_n, p.n_k);
-        if ((rc = job->t_first_pass.begin(s, (w1 - w0) * p.n_k)) != GP_OK)
-            return rc;
-        hipLaunchKernelGGL(cbf_first_pass, grid, dim3(kBlock), 0, s, a);
-        GP_HIP(hipGetLastError());
-        if ((rc = job->t_first_pass.end(s)) != GP_OK)
-            return rc;
-        GP_HIP(hipEventRecord(job->a_ev_fp[set], s));
-        {
-            const uint32_t i = ring_head % kRing;
-            ring_units[i] = (w1 - w0) * p.n_k;
-            ring_looked[i] = !a.all_wait;
-            ring_slot = i;
-        }
-        // Rounds and tail on the second stream: they need this window's first pass and, by
-        // stream order, the previous window's tail.  Nothing here waits for the device.
-        GP_HIP(hipStreamWaitEvent(s2, job->a_ev_fp[set], 0));
-        const uint32_t rounds_now = std::min<uint32_t>(want_rounds, kMaxRounds - 8);
-        t.n_rounds = rounds_now;
-        t.n_counts = rounds_now + 2;
-        t.ring_slot = ring_slot;
-        t.ring_seq = ring_head + 1;
-        if (wi == 0 && (rc = job->t_round.begin(s2, 1)) != GP_OK) // one span over all rounds
-            return rc;
-        for (uint32_t round = 0; round < rounds_now; round++) {
-            a.round = round;
-            a.tag_cur = tag_max - (g0 + round);
-            a.tag_next = a.tag_cur - 1;
-            a.resv = t.resv[round & 1];
-            a.resv_out = t.resv[(round + 1) & 1];
-            a.list_in = t.list[round & 1];
-            a.list_out = t.list[(round + 1) & 1];
-            const unsigned blocks = last_frac < 0.01 ? 256u : (unsigned)kRoundBlocks;
-            hipLaunchKernelGGL(cbf_round, dim3(blocks), dim3(256), 0, s2, a);
-        }
-        t.tag_first = tag_max - g0;
-        hipLaunchKernelGGL(cbf_tail, dim3(1), dim3(kTailThreads), 0, s2, a, t);
-        GP_HIP(hipGetLastError());
-        if (last_frac < 0.05) {
-            // the (batch, k) pairs this window touched
-            const uint32_t n_streams = g_n * p.n_k;
-            if (n_streams <= 64) {
-                hipLaunchKernelGGL(cbf_check_sat, dim3(n_streams), dim3(1024), 0, s2, a,
-                                   bcur * p.n_k);
+        uint32_t slice_seq = 0;
+        uint64_t off = 0;
+        while (off < longest) {
+            int rc = drain_feedback(ring_head - ring_tail >= ahead);
+            if (rc != GP_OK)
+                return rc;
+            // ---- this step's slice
+            const uint64_t wmax = std::min<uint64_t>(
+                job->window,
+                std::max<uint64_t>(kTile, (uint64_t)(wait_cap / ((double)p.n_k * std::max(last_frac, 0.02)))));
+            uint64_t slice = std::min<uint64_t>(lim0 * scale, std::max<uint64_t>(kTile, wmax / g_n));
+            slice = std::max<uint64_t>(kTile, slice / kTile * kTile);
+            slice = std::min<uint64_t>(slice, (longest - off + kTile - 1) / kTile * kTile);
+            uint32_t tiles_per_batch = (uint32_t)(slice / kTile);
+            if ((uint64_t)tiles_per_batch * g_n * kTile > job->window || (uint64_t)tiles_per_batch * g_n >= (1u << 14)) {
+                set_error("stage A: slice does not fit the work buffers");
+                return GP_ERR_STATE;
+            }
+            uint64_t w_positions = 0; // positions this slice really covers
+            for (uint32_t bi = g_first; bi < g_first + g_n; bi++) {
+                const uint64_t len = batch_pos[bi + 1] - batch_pos[bi];
+                if (len > off)
+                    w_positions += std::min<uint64_t>(slice, len - off);
+            }
+            uint64_t units = w_positions * p.n_k;
+            // The list must never overflow: what may be waiting at most (latest report + every
+            // first pass since) plus this slice has to fit.  Too much waiting also means long
+            // chains per counter: then this step only runs a round.
+            bool hash_now = units > 0;
+            if (hash_now && known_in + unacked + units > max_pending) {
+                if ((rc = drain_feedback(ring_tail != ring_head)) != GP_OK)
+                    return rc;
+                if (known_in + unacked + units > max_pending)
+                    hash_now = false;
+            }
+            if (hash_now && (double)known_in > 4.0 * wait_cap)
+                hash_now = false;
+            if (hash_now && rounds_since_fp + 1 < cadence)
+                hash_now = false;
+            if (!hash_now && units == 0) {
+                off += slice; // no batch of the group reaches this far
+                continue;
+            }
+
+            {
+                // Slots in use: about eight per expected reservation, within the allocation.  A
+                // smaller table keeps the atomics at their full rate (27 G/s up to 2^24 slots,
+                // 22 G/s at 2^26, measured); stale entries of other steps carry larger tags and
+                // lose to any new reservation, so the mapping may change from step to step.
+                const double expect = ((double)known_in + (double)unacked * std::min(1.0, last_frac * 1.5) +
+                                       (hash_now ? (double)units * std::min(1.0, last_frac * 1.5) : 0.0)) * p.hash_num;
+                // The count only moves when it has to (too full) or is far too large: a change
+                // costs the waiting operations one round, because they are checked against the
+                // table they reserved in with the old count.
+                uint32_t bits = std::min<uint32_t>(18, job->resv_bits); // never beyond the allocation
+                while (bits < job->resv_bits && (double)(1ull << bits) < slot_mul * expect)
+                    bits++;
+                a.bits_in = a.bits_out;
+                if (bits > a.bits_out || bits + 2 <= a.bits_out)
+                    a.bits_out = bits;
+                // while nearly everything waits the look-up is wasted work; every eighth first
+                // pass still does it so that the estimate follows the filter filling up
+                a.all_wait = (allow_skip && last_frac > 0.9 && since_look < 7) ? 1u : 0u;
+            }
+            a.grp_first = g_first;
+            a.grp_n = g_n;
+            a.tiles_per_batch = tiles_per_batch;
+            a.off = off;
+            a.slice = slice;
+            a.drain = 0;
+            a.pos_base = slice_seq << 24;
+            a.ring_slot = ring_head % kRing;
+            a.ring_seq = ring_head + 1;
+            notes[ring_head % kRing] = { prev_units, prev_looked, hash_now };
+
+            if (debug && (job->counters.a_rounds < 40 || job->counters.a_rounds % 25 == 0))
+                fprintf(stderr, "[stage A] step %llu: slice %llu units %llu hash %d known_in %llu unacked %llu frac %.3f "
+                                "scale %llu bits %u skip_lookup %u ahead %u\n",
+                        (unsigned long long)job->counters.a_rounds, (unsigned long long)slice,
+                        (unsigned long long)units, (int)hash_now, (unsigned long long)known_in,
+                        (unsigned long long)unacked, last_frac, (unsigned long long)scale, a.bits_out, a.all_wait,
+                        ring_head - ring_tail);
+            if (!span_open) {
+                if ((rc = job->t_round.begin(s2, 1)) != GP_OK) // one span over all rounds
+                    return rc;
+                span_open = true;
+            }
+            launch_round(last_frac < 0.01 && known_in + unacked < 65536 ? 256u : (unsigned)kRoundBlocks);
+            GP_HIP(hipGetLastError());
+            if (hash_now) {
+                if ((rc = job->t_first_pass.begin(s, units)) != GP_OK)
+                    return rc;
+                hipLaunchKernelGGL(cbf_first_pass, dim3(tiles_per_batch * g_n, p.n_k), dim3(kBlock), 0, s, a);
                 GP_HIP(hipGetLastError());
+                if ((rc = job->t_first_pass.end(s)) != GP_OK)
+                    return rc;
+                n_first_pass++;
+                rounds_since_fp = 0;
+                since_look = a.all_wait ? since_look + 1 : 0;
+                unacked += units;
+                prev_units = units;
+                prev_looked = !a.all_wait;
+                if (last_frac < 0.05 && g_n * p.n_k <= 64) {
+                    // have the (batch, k) pairs this slice touched stopped changing?
+                    hipLaunchKernelGGL(cbf_check_sat, dim3(g_n * p.n_k), dim3(1024), 0, s, a, g_first * p.n_k);
+                    GP_HIP(hipGetLastError());
+                }
+                off += slice;
+                slice_seq++;
+            } else {
+                prev_units = 0;
+                prev_looked = false;
+                rounds_since_fp++;
+            }
+            // the next step starts when both halves of this one are done
+            const uint32_t e = (uint32_t)(step % kRing);
+            GP_HIP(hipEventRecord(job->a_ev[e], s2));
+            GP_HIP(hipEventRecord(job->a_ev_b[e], s));
+            GP_HIP(hipStreamWaitEvent(s, job->a_ev[e], 0));
+            GP_HIP(hipStreamWaitEvent(s2, job->a_ev_b[e], 0));
+            ring_head++;
+            step++;
+            job->counters.a_rounds++;
+
+            // ---- end of the group, or the slice numbers are used up: finish what waits
+            if (off >= longest || slice_seq == 255) {
+                a.drain = 1;
+                a.bits_in = a.bits_out; // fixed from here to the end of the tail
+                t.step0 = step;
+                for (uint32_t r = 0; r < kDrainRounds; r++) {
+                    launch_round(kRoundBlocks);
+                    step++;
+                }
+                hipLaunchKernelGGL(cbf_tail, dim3(1), dim3(kTailThreads), 0, s2, a, t);
+                GP_HIP(hipGetLastError());
+                job->counters.a_rounds += kDrainRounds;
+                step += tail_span + 1; // the tail's rounds use the tags in between
+                const uint32_t e2 = (uint32_t)(step % kRing);
+                GP_HIP(hipEventRecord(job->a_ev[e2], s2));
+                GP_HIP(hipStreamWaitEvent(s, job->a_ev[e2], 0));
+                slice_seq = 0;
+                // collect the reports of the steps before the drain (a late one would be counted
+                // against the next group's first passes); nothing waits on the device any more
+                while (ring_tail != ring_head)
+                    if ((rc = drain_feedback(true)) != GP_OK)
+                        return rc;
+                known_in = 0;
+                unacked = 0;
+                prev_units = 0;
+                prev_looked = false;
+                if (step + 2 * tail_span >= tag_max) {
+                    // tags used up (thousands of groups): start over with clean tables
+                    GP_HIP(hipStreamSynchronize(s2));
+                    GP_HIP(hipMemsetAsync(job->d_resv.p, 0xFF, job->d_resv.n * sizeof(unsigned long long), s2));
+                    GP_HIP(hipStreamSynchronize(s2));
+                    step = 0;
+                }
             }
         }
-        GP_HIP(hipEventRecord(job->a_ev_tail[set], s2));
-        ring_head++;
-        wi++;
-        job->counters.a_rounds += rounds_now + 1;
-        gen = g0 + rounds_now + tail_span + 1;
-        off += slice;
-      }
         g_first += g_n;
     }
-    if (wi > 0) {
+    if (span_open) {
         int rc = job->t_round.end(s2);
         if (rc != GP_OK)
             return rc;
     }
-    if (env_u64("GP_STAGE_A_DEBUG", 0)) {
+    if (debug) {
         const double host_ms = std::chrono::duration<double, std::milli>(
                                    std::chrono::steady_clock::now() - t_host0).count();
         GP_HIP(hipStreamSynchronize(s2));
         const double all_ms = std::chrono::duration<double, std::milli>(
                                   std::chrono::steady_clock::now() - t_host0).count();
-        fprintf(stderr, "[stage A] %llu windows: host enqueue %.2f ms, device done after %.2f ms\n",
-                (unsigned long long)wi, host_ms, all_ms);
+        fprintf(stderr, "[stage A] %llu first passes: host enqueue %.2f ms, device done after %.2f ms\n",
+                (unsigned long long)n_first_pass, host_ms, all_ms);
     }
     // the rest of the pipeline (stream `s`) continues behind the last tail
     GP_HIP(hipEventRecord(job->a_ev_init, s2));
@@ -1080,8 +1164,7 @@ int stage_a_run(gp_job* job)
     unsigned long long st[4];
     uint32_t tail_err = 0;
     GP_HIP(hipMemcpyAsync(st, job->d_stats.p, sizeof st, hipMemcpyDeviceToHost, s));
-    GP_HIP(hipMemcpyAsync(&tail_err, job->d_counts.p + (uint64_t)(kMaxRounds + 1) * kCountStride, sizeof tail_err,
-                          hipMemcpyDeviceToHost, s));
+    GP_HIP(hipMemcpyAsync(&tail_err, err_flag, sizeof tail_err, hipMemcpyDeviceToHost, s));
     GP_HIP(hipStreamSynchronize(s));
     job->counters.a_positions = st[0];
     job->counters.a_ops = st[1];
