@@ -182,7 +182,7 @@ def main():
                "n_contigs": w.n_contigs}
         if want_roofline:
             kt = {}
-            for name in ("cbf_first_pass", "cbf_round", "ntedit_walk", "mask", "sealer_bfs", "upper"):
+            for name in ("cbf_first_pass", "cbf_round", "cbf_local", "ntedit_scan", "ntedit_walk", "mask", "sealer_bfs", "upper"):
                 ms, n, units = job.kernel_time(name)
                 kt[name] = {"ms": ms, "launches": n, "units": units}
             res["kernels"] = kt

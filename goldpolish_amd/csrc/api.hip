@@ -346,6 +346,7 @@ void gp_job_destroy(gp_job* job)
     stage_bc_release(job);
     job->t_first_pass.destroy();
     job->t_round.destroy();
+    job->t_local.destroy();
     job->t_scan.destroy();
     job->t_walk.destroy();
     job->t_bfs.destroy();
@@ -521,6 +522,8 @@ int gp_job_kernel_time(gp_job* job, const char* kernel, double* total_ms, uint64
         t = &job->t_first_pass;
     else if (!std::strcmp(kernel, "cbf_round"))
         t = &job->t_round;
+    else if (!std::strcmp(kernel, "cbf_local"))
+        t = &job->t_local;
     else if (!std::strcmp(kernel, "ntedit_scan"))
         t = &job->t_scan;
     else if (!std::strcmp(kernel, "ntedit_walk"))

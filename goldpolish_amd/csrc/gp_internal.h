@@ -117,6 +117,7 @@ struct gp_job {
     gp::DevBuf<uint4> d_pending[2];       // two lists of {hash lo, hash hi, pos, meta},{idx x4}; steps alternate
     gp::DevBuf<uint32_t> d_sat, d_batch_thr_max; // saturation flags per (batch, k); max threshold per batch
     gp::DevBuf<uint64_t> d_batch_pos;     // [n_batches+1] first read position of each batch
+    gp::DevBuf<uint32_t> d_batch_order;   // [n_batches] batches as stage A takes them
     gp::DevBuf<uint32_t> d_counts;        // ring of per-step list lengths, one 128-B line each
     gp::DevBuf<unsigned long long> d_stats; // device-side gp_counters
     uint64_t window = 0;
@@ -128,7 +129,7 @@ struct gp_job {
     // ---- stage B/C state (see stage_b.hip / stage_c.hip)
     gp::StageBC* bc = nullptr;
 
-    gp::KernelTimer t_first_pass, t_round, t_scan, t_walk, t_bfs, t_mask, t_upper, t_reset;
+    gp::KernelTimer t_first_pass, t_round, t_local, t_scan, t_walk, t_bfs, t_mask, t_upper, t_reset;
     gp_counters counters{};
     bool filters_ready = false;
 };

@@ -100,6 +100,7 @@ struct AArgs {
     // a window = the same slice [off, off + slice) of every batch of a group (batch-relative
     // positions), one or more 1024-position tiles per batch
     const uint64_t* batch_pos; // [n_batches+1] first read position of each batch
+    const uint32_t* batch_order; // batches in the order the groups take them (long ones first, then the cbf_local ones)
     uint32_t grp_first, grp_n, tiles_per_batch;
     uint64_t off, slice;
     unsigned long long* stats; // [0] positions [1] ops [2] ordered ops
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
     const uint32_t ki = blockIdx.y;
     const KConsts& kc = a.kc[ki];
     const uint32_t k = kc.k;
-    const uint32_t gb = a.grp_first + blockIdx.x / a.tiles_per_batch;
+    const uint32_t gb = a.batch_order[a.grp_first + blockIdx.x / a.tiles_per_batch];
     const uint64_t b_start = a.batch_pos[gb], b_end = a.batch_pos[gb + 1];
     const uint64_t tile0 = b_start + a.off + (uint64_t)(blockIdx.x % a.tiles_per_batch) * kTile;
     const uint64_t tile_end = min(min(b_end, b_start + a.off + a.slice), tile0 + (uint64_t)kTile);
@@ -409,10 +410,10 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
 // of the batch uses) every later operation settles; once every bit of the Bloom filter is
 // set, inserting is a no-op.  One workgroup per stream of the window; flags only ever go
 // from 0 to 1, so a first pass that reads them late loses nothing but time.
-__global__ __launch_bounds__(1024) void cbf_check_sat(AArgs a, uint32_t stream0)
+__global__ __launch_bounds__(1024) void cbf_check_sat(AArgs a)
 {
     __shared__ uint32_t bad_c, bad_b;
-    const uint32_t stream = stream0 + blockIdx.x;
+    const uint32_t stream = a.batch_order[a.grp_first + blockIdx.x / a.n_k] * a.n_k + blockIdx.x % a.n_k;
     uint32_t cur = a.sat[stream];
     if (cur == 3u)
         return;
@@ -661,6 +662,222 @@ __global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
         t.counts[i] = 0;
 }
 
+
+// ---- many small filters: one workgroup per (batch, k) pair replays its operations alone.
+// Nobody else touches the pair's counters, so the whole ordering problem stays inside the
+// workgroup: a tile of 1024 consecutive positions is hashed, what is settled goes straight
+// into the filter, and the rest is ordered through an LDS hash table keyed by the counter
+// index itself (exact: only operations that really share a counter wait for each other),
+// with workgroup barriers instead of launches between the rounds and without a single
+// global atomic on the way (device-scope atomics run at 27 G/s chip-wide whatever their
+// target).  Tiles follow each other in position order, which IS the serial order.  What
+// another wave of the workgroup wrote before a workgroup barrier is visible after it (the
+// waves share the CU's L1); no device-scope fence is needed, and none is wanted: an
+// agent-scope release writes the XCD's L2 back.  A round-0 winner has no earlier waiting
+// operation of its tile on any of its counters, so the values loaded for the settle test
+// are still the current ones: in a sparse filter an operation costs its four counter
+// loads and the stores, nothing else.  The kernel is bound by those random line fetches.
+constexpr int kLocalSlots = 8192;      // >= 2 x the counter touches of a tile (hash_num <= 4)
+constexpr uint32_t kLocalEmpty = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(kBlock) void cbf_local(AArgs a, uint32_t first, uint32_t n_local)
+{
+    __shared__ uint8_t codes[kTile + kHalo];
+    __shared__ uint32_t keys[kLocalSlots]; // counter index held by the slot
+    __shared__ uint32_t vals[kLocalSlots]; // earliest waiting operation of the tile on that counter
+    __shared__ unsigned long long s_stats[4];
+    const uint32_t b = a.batch_order[first + blockIdx.x / a.n_k];
+    const uint32_t ki = blockIdx.x % a.n_k;
+    const KConsts& kc = a.kc[ki];
+    const uint32_t k = kc.k;
+    const uint32_t stream = b * a.n_k + ki;
+    uint8_t* cb = a.cbf + (uint64_t)stream * a.cbf_stride;
+    const uint64_t b_start = a.batch_pos[b], b_end = a.batch_pos[b + 1];
+
+    if (threadIdx.x < 4)
+        s_stats[threadIdx.x] = 0;
+    uint32_t n_ops = 0, n_ordered = 0, n_positions = 0, n_rounds = 0;
+    const int t0 = threadIdx.x * kPerThread;
+
+    for (uint64_t tile0 = b_start; tile0 < b_end; tile0 += kTile) {
+        const uint64_t tile_end = min(b_end, tile0 + (uint64_t)kTile);
+        __syncthreads(); // everyone is done with the previous tile's codes
+        for (int i = threadIdx.x; i < kTile + kHalo; i += kBlock) {
+            uint64_t p = tile0 + i;
+            uint8_t c = p < a.n_pos ? a.reads[p] : (uint8_t)'\n';
+            codes[i] = base_code(c);
+        }
+        __syncthreads();
+
+        uint32_t op_state[kPerThread] = {}, op_thr[kPerThread] = {}, op_c[kPerThread] = {};
+        uint32_t op_idx[kPerThread][4] = {};
+        uint64_t op_base[kPerThread] = {};
+        const uint64_t pos0 = tile0 + t0;
+        if (pos0 < tile_end) {
+            uint32_t lo = 0, hi = a.n_seg;
+            while (hi - lo > 1) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (a.seg_start[mid] <= pos0)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            uint32_t seg = lo;
+            uint64_t seg_end = a.seg_start[seg + 1];
+            uint64_t fh = 0, rh = 0;
+            int last_bad = -1;
+            for (uint32_t i = 0; i < k; i++) {
+                uint32_t cf = codes[t0 + i];
+                uint32_t cr = codes[t0 + k - 1 - i];
+                fh = srol1(fh) ^ (cf < 4 ? seed_of_code(cf) : 0ULL);
+                rh = srol1(rh) ^ (cr < 4 ? seed_of_code(cr ^ 2) : 0ULL);
+                if (cf >= 4)
+                    last_bad = (int)i;
+            }
+#pragma unroll
+            for (int j = 0; j < kPerThread; j++) {
+                const uint64_t pos = pos0 + j;
+                if (pos >= tile_end)
+                    continue;
+                if (j > 0) {
+                    uint32_t out = codes[t0 + j - 1], in = codes[t0 + j + k - 1];
+                    uint64_t s_in = in < 4 ? seed_of_code(in) : 0ULL;
+                    uint64_t s_outk = out < 4 ? kc.out_fwd[out] : 0ULL;
+                    uint64_t r_ink = in < 4 ? kc.in_rev[in] : 0ULL;
+                    uint64_t r_out = out < 4 ? seed_of_code(out ^ 2) : 0ULL;
+                    fh = srol1(fh) ^ s_in ^ s_outk;
+                    rh = sror1(rh ^ r_ink ^ r_out);
+                    if (in >= 4)
+                        last_bad = j + (int)k - 1;
+                }
+                n_positions++;
+                if (last_bad >= j || pos + k > a.n_pos)
+                    continue;
+                while (pos >= seg_end) {
+                    seg++;
+                    seg_end = a.seg_start[seg + 1];
+                }
+                n_ops++;
+                op_base[j] = fh + rh;
+                op_thr[j] = a.seg_thr[seg] - 2 + ki;
+                op_state[j] = 1;
+                uint32_t pack = 0;
+                for (uint32_t h = 0; h < 4; h++) { // hash_num <= 4 on this path (stage_a_run)
+                    if (h >= a.hash_num)
+                        break;
+                    const uint64_t hv = h ? ext_hash(op_base[j], k, h) : op_base[j];
+                    op_idx[j][h] = (uint32_t)fastmod(hv, a.cbf_mod);
+                    pack |= ctr_load<false>(a, cb, op_idx[j][h]) << (8 * h);
+                }
+                op_c[j] = pack;
+            }
+        }
+
+        // rounds: every waiting operation enters its counters into the table; who is the
+        // earliest on all of them has no earlier waiting operation on any of its counters and
+        // applies the serial update.  Round 0 works on the values loaded above.
+        for (uint32_t round = 0;; round++) {
+            uint32_t mine_left = 0;
+#pragma unroll
+            for (int j = 0; j < kPerThread; j++) {
+                if (!op_state[j])
+                    continue;
+                if (round == 0 || (round & 7u) == 7u) {
+                    // settled (see try_settle): goes in, nothing to write.  Waiting operations
+                    // look again every eighth round: a run of one k-mer (a homopolymer) would
+                    // otherwise take a round per copy long after its counters are high enough.
+                    uint32_t m = 255;
+                    for (uint32_t h = 0; h < a.hash_num; h++) {
+                        const uint32_t c = round == 0 ? (op_c[j] >> (8 * h)) & 255u
+                                                      : ctr_load<false>(a, cb, op_idx[j][h]);
+                        m = min(m, c);
+                    }
+                    if (m + 1 >= op_thr[j]) {
+                        uint64_t hv[kMaxHash];
+                        hv[0] = op_base[j];
+                        for (uint32_t i = 1; i < a.hash_num; i++)
+                            hv[i] = ext_hash(op_base[j], k, i);
+                        bf_insert(a, stream, hv);
+                        op_state[j] = 0;
+                        continue;
+                    }
+                    n_ordered += round == 0;
+                }
+                mine_left++;
+            }
+            if (!__syncthreads_or((int)mine_left))
+                break;
+            n_rounds += threadIdx.x == 0;
+            for (int i = threadIdx.x; i < kLocalSlots; i += kBlock) {
+                keys[i] = kLocalEmpty;
+                vals[i] = kLocalEmpty;
+            }
+            __syncthreads();
+            uint32_t op_slot[kPerThread][4];
+#pragma unroll
+            for (int j = 0; j < kPerThread; j++) {
+                if (!op_state[j])
+                    continue;
+                for (uint32_t h = 0; h < a.hash_num; h++) {
+                    const uint32_t ix = op_idx[j][h];
+                    uint32_t sl = (ix * 0x9E3779B1u) >> (32 - 13);
+                    for (;;) { // linear probing; the table is at most half full
+                        const uint32_t old = atomicCAS(&keys[sl], kLocalEmpty, ix);
+                        if (old == kLocalEmpty || old == ix)
+                            break;
+                        sl = (sl + 1) & (kLocalSlots - 1);
+                    }
+                    atomicMin(&vals[sl], (uint32_t)(t0 + j));
+                    op_slot[j][h] = sl;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kPerThread; j++) {
+                if (!op_state[j])
+                    continue;
+                bool mine = true;
+                for (uint32_t h = 0; h < a.hash_num; h++)
+                    mine &= vals[op_slot[j][h]] == (uint32_t)(t0 + j);
+                if (!mine)
+                    continue;
+                uint32_t c[4], m = 255;
+                for (uint32_t h = 0; h < a.hash_num; h++) {
+                    c[h] = round == 0 ? (op_c[j] >> (8 * h)) & 255u : ctr_load<false>(a, cb, op_idx[j][h]);
+                    m = min(m, c[h]);
+                }
+                const uint32_t thr = op_thr[j];
+                if (m < thr) {
+                    for (uint32_t h = 0; h < a.hash_num; h++) {
+                        bool first = c[h] == m;
+                        for (uint32_t g = 0; g < h; g++)
+                            first &= op_idx[j][g] != op_idx[j][h]; // a counter hit twice still moves by one
+                        if (first)
+                            ctr_increment(a, cb, op_idx[j][h], m);
+                    }
+                    m++;
+                }
+                if (m >= thr) {
+                    uint64_t hv[kMaxHash];
+                    hv[0] = op_base[j];
+                    for (uint32_t h = 1; h < a.hash_num; h++)
+                        hv[h] = ext_hash(op_base[j], k, h);
+                    bf_insert(a, stream, hv);
+                }
+                op_state[j] = 0;
+            }
+            // the barrier at the top of the loop orders these stores before the next loads
+        }
+    }
+    atomicAdd(&s_stats[0], (unsigned long long)n_positions);
+    atomicAdd(&s_stats[1], (unsigned long long)n_ops);
+    atomicAdd(&s_stats[2], (unsigned long long)n_ordered);
+    atomicAdd(&s_stats[3], (unsigned long long)n_rounds);
+    __syncthreads();
+    if (threadIdx.x < 4 && s_stats[threadIdx.x])
+        atomicAdd(&a.stats[threadIdx.x], s_stats[threadIdx.x]);
+}
+
 // ------------------------------------------------------------------ host side
 int KernelTimer::begin(hipStream_t s, uint64_t n_units)
 {
@@ -748,7 +965,8 @@ int stage_a_prepare(gp_job* job)
         return rc;
     if ((rc = job->d_stats.alloc(16)) != GP_OK)
         return rc;
-    if ((rc = job->d_batch_pos.alloc((uint64_t)job->n_batches + 1)) != GP_OK)
+    if ((rc = job->d_batch_pos.alloc((uint64_t)job->n_batches + 1)) != GP_OK ||
+        (rc = job->d_batch_order.alloc(job->n_batches)) != GP_OK)
         return rc;
     if ((rc = job->d_sat.alloc((uint64_t)job->n_batches * p.n_k)) != GP_OK ||
         (rc = job->d_batch_thr_max.alloc(job->n_batches)) != GP_OK)
@@ -834,6 +1052,7 @@ int stage_a_run(gp_job* job)
 
     job->t_first_pass.reset();
     job->t_round.reset();
+    job->t_local.reset();
     job->counters.a_rounds = 0;
 
     // fresh filters + free reservation tables
@@ -860,8 +1079,51 @@ int stage_a_run(gp_job* job)
     batch_pos[job->n_batches] = job->read_positions;
     GP_HIP(hipMemcpyAsync(job->d_batch_pos.p, batch_pos.data(), batch_pos.size() * sizeof(uint64_t),
                           hipMemcpyHostToDevice, s));
-    GP_HIP(hipStreamSynchronize(s)); // batch_pos is a local
     a.batch_pos = job->d_batch_pos.p;
+    // Which batches replay alone in a workgroup (cbf_local) and which go through the grid-wide
+    // reservation rounds?  A workgroup works a batch off tile after tile, about 15 us per 1024
+    // positions whatever else runs, so that pays when there are enough batches to fill the
+    // chip and none of them is long; a long contig's batch needs the whole chip on its one
+    // filter.  GP_STAGE_A_LOCAL: 0 never, 1 every batch, default by size.
+    std::vector<uint32_t> order;
+    uint32_t n_big = job->n_batches;
+    {
+        const uint64_t local_max = env_u64("GP_STAGE_A_LOCAL_MAX", 3ull << 19); // positions per batch
+        const uint64_t mode = p.hash_num <= 4 ? env_u64("GP_STAGE_A_LOCAL", 2) : 0; // the LDS table holds 4 touches per operation
+        std::vector<uint32_t> small;
+        for (uint32_t bi = 0; bi < job->n_batches; bi++) {
+            const uint64_t len = batch_pos[bi + 1] - batch_pos[bi];
+            if (mode == 1 || (mode == 2 && len <= local_max))
+                small.push_back(bi);
+            else
+                order.push_back(bi);
+        }
+        if (mode == 2 && small.size() * p.n_k < 128) { // too few to fill the chip
+            order.clear();
+            small.clear();
+            for (uint32_t bi = 0; bi < job->n_batches; bi++)
+                order.push_back(bi);
+        }
+        n_big = (uint32_t)order.size();
+        order.insert(order.end(), small.begin(), small.end());
+    }
+    GP_HIP(hipMemcpyAsync(job->d_batch_order.p, order.data(), order.size() * sizeof(uint32_t),
+                          hipMemcpyHostToDevice, s));
+    GP_HIP(hipStreamSynchronize(s)); // batch_pos and order are locals
+    a.batch_order = job->d_batch_order.p;
+    const uint32_t n_local = job->n_batches - n_big;
+    if (n_local) {
+        uint64_t units = 0;
+        for (uint32_t i = n_big; i < job->n_batches; i++)
+            units += (batch_pos[order[i] + 1] - batch_pos[order[i]]) * p.n_k;
+        int rc0 = job->t_local.begin(s, units);
+        if (rc0 != GP_OK)
+            return rc0;
+        hipLaunchKernelGGL(cbf_local, dim3(n_local * p.n_k), dim3(kBlock), 0, s, a, n_big, n_local);
+        GP_HIP(hipGetLastError());
+        if ((rc0 = job->t_local.end(s)) != GP_OK)
+            return rc0;
+    }
 
     // Slice = the read positions of one batch a step's first pass hashes.  What makes the
     // rounds expensive is many waiting operations per counter, so a slice takes at most
@@ -975,12 +1237,12 @@ int stage_a_run(gp_job* job)
     // every batch of the group.  Many small batches therefore advance in lockstep: each filter
     // sees only a sliver of its reads per step, yet a step still holds enough operations to
     // fill the chip.  A group of one batch degenerates to consecutive slices of that batch.
-    for (uint32_t g_first = 0; g_first < job->n_batches;) {
-        uint32_t g_n = std::min<uint32_t>(group_max, job->n_batches - g_first);
+    for (uint32_t g_first = 0; g_first < n_big;) {
+        uint32_t g_n = std::min<uint32_t>(group_max, n_big - g_first);
         g_n = (uint32_t)std::min<uint64_t>(g_n, std::max<uint64_t>(1, job->window / kTile));
         uint64_t longest = 0;
-        for (uint32_t bi = g_first; bi < g_first + g_n; bi++)
-            longest = std::max(longest, batch_pos[bi + 1] - batch_pos[bi]);
+        for (uint32_t gi = g_first; gi < g_first + g_n; gi++)
+            longest = std::max(longest, batch_pos[order[gi] + 1] - batch_pos[order[gi]]);
         scale = 1;
         last_frac = 1.0;
         uint32_t slice_seq = 0;
@@ -1002,8 +1264,8 @@ int stage_a_run(gp_job* job)
                 return GP_ERR_STATE;
             }
             uint64_t w_positions = 0; // positions this slice really covers
-            for (uint32_t bi = g_first; bi < g_first + g_n; bi++) {
-                const uint64_t len = batch_pos[bi + 1] - batch_pos[bi];
+            for (uint32_t gi = g_first; gi < g_first + g_n; gi++) {
+                const uint64_t len = batch_pos[order[gi] + 1] - batch_pos[order[gi]];
                 if (len > off)
                     w_positions += std::min<uint64_t>(slice, len - off);
             }
@@ -1087,7 +1349,7 @@ int stage_a_run(gp_job* job)
                 prev_looked = !a.all_wait;
                 if (last_frac < 0.05 && g_n * p.n_k <= 64) {
                     // have the (batch, k) pairs this slice touched stopped changing?
-                    hipLaunchKernelGGL(cbf_check_sat, dim3(g_n * p.n_k), dim3(1024), 0, s, a, g_first * p.n_k);
+                    hipLaunchKernelGGL(cbf_check_sat, dim3(g_n * p.n_k), dim3(1024), 0, s, a);
                     GP_HIP(hipGetLastError());
                 }
                 off += slice;
@@ -1177,7 +1439,7 @@ int stage_a_run(gp_job* job)
     int rc = job->t_first_pass.collect();
     if (rc != GP_OK)
         return rc;
-    if ((rc = job->t_round.collect()) != GP_OK)
+    if ((rc = job->t_round.collect()) != GP_OK || (rc = job->t_local.collect()) != GP_OK)
         return rc;
     job->filters_ready = true;
     return GP_OK;

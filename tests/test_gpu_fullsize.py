@@ -135,3 +135,35 @@ def test_device_export_matches_host_export(gp):
         assert not got[total:].any()
         with pytest.raises(core.GpError):
             job.sequences_into_device(buf.data_ptr(), total - 1)
+
+
+def test_mixed_job_long_and_many_short_batches(gp, oracle, monkeypatch):
+    """One job holding a long contig's batch (grid-wide reservation rounds) and a few hundred
+    short ones (one workgroup per filter pair, chosen by size): every filter equals the one
+    the forced single-schedule runs give, and a sample of them equals the serial oracle."""
+    core, ctx = gp
+    lens = [2_500_000] + [6000] * 150 + [9000] * 60
+    w = synth.make_workload(lens, 20, seed=91)
+    p = core.default_params(k_values=[32, 24])
+
+    def filters(mode):
+        if mode is None:
+            monkeypatch.delenv("GP_STAGE_A_LOCAL", raising=False)
+        else:
+            monkeypatch.setenv("GP_STAGE_A_LOCAL", mode)
+        with core.Job.from_workload(ctx, p, w) as job:
+            job.build_filters()
+            local_ms, local_launches, _ = job.kernel_time("cbf_local")
+            fp_ms, fp_launches, _ = job.kernel_time("cbf_first_pass")
+            return ([[sha(job.get_filter(b, ki).tobytes()) for ki in range(p.n_k)]
+                     for b in range(job.n_batches)],
+                    [job.get_filter(b, 1) for b in (0, 1, 77, 210)], local_launches, fp_launches)
+
+    auto, sample, n_local, n_fp = filters(None)
+    assert n_local == 1 and n_fp > 0          # both schedules ran
+    grid, _, n_local_g, _ = filters("0")
+    assert n_local_g == 0 and grid == auto
+    for i, b in enumerate((0, 1, 77, 210)):
+        _, bfs = oracle.fill_bfs(w.reads_of(b), [32, 24], int(w.kmer_threshold[b]), p.cbf_bytes,
+                                 p.bf_bytes)
+        assert np.array_equal(sample[i], bfs[1]), b

@@ -11,6 +11,14 @@ from goldpolish_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["grid", "local"], autouse=True)
+def stage_a_path(request, monkeypatch):
+    """every case runs through both stage-A schedules: grid-wide reservation rounds
+    (GP_STAGE_A_LOCAL=0) and one workgroup per (batch, k) pair (GP_STAGE_A_LOCAL=1)"""
+    monkeypatch.setenv("GP_STAGE_A_LOCAL", "0" if request.param == "grid" else "1")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def gp():
     from goldpolish_amd import core
