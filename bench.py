@@ -27,6 +27,7 @@ ROOT = pathlib.Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ATOMIC_CEILING_GPS = 27.0  # scattered device-scope atomics per ns, measured (tools/probes/atomic_probe.hip)
 
 
 def make_workload(kind, seed):
@@ -35,6 +36,8 @@ def make_workload(kind, seed):
         return synth.make_workload([10_000_000], 30, seed=seed), [32]
     if kind == "goldenpath":
         return synth.make_workload([25_000] * 400, 30, seed=seed), [32, 28, 24, 20]
+    if kind == "config3":   # BASELINE.json configs[2]: 100 Mbp assembly, 40x reads, full cascade
+        return synth.make_workload([25_000] * 4000, 40, seed=seed), [32, 28, 24, 20]
     if kind == "tiny":
         return synth.make_workload([200_000], 30, seed=seed), [32]
     raise SystemExit(f"unknown workload {kind}")
@@ -235,6 +238,17 @@ def main():
                 algorithmic_bytes_per_bp(main_res["n_k"], H, main_res["coverage"]) * value * 1e6 / 1e9, 2),
             "kernel_ms_per_run": {n: round(v["ms"], 3) for n, v in k.items()},
         }
+        # what actually bounds the filter build: scattered device-scope atomics, which this
+        # chip retires at 27 G/s whatever their width, scope or target (tools/probes/
+        # atomic_probe.hip, measured; 64 M atomicMin over 2^16..2^24 slots)
+        resv = main_res["counters"].get("a_reservations", 0)
+        span_ms = k["cbf_round"]["ms"]
+        if resv and span_ms:
+            rate = resv / (span_ms / 1e3) / 1e9
+            line["roofline"]["atomics"] = {
+                "reservation_atomics_per_step": resv, "stage_a_ms": round(span_ms, 3),
+                "achieved_G_per_s": round(rate, 2), "measured_ceiling_G_per_s": ATOMIC_CEILING_GPS,
+                "frac": round(rate / ATOMIC_CEILING_GPS, 3)}
         line["counters"] = main_res["counters"]
     if world == 1 and not args.no_aux and args.workload == "config2":
         aux = run("goldenpath", max(1, min(args.steps, 3)), 1, True)

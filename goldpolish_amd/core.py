@@ -64,7 +64,7 @@ class BatchSet(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "a_positions", "a_ops", "a_ordered_ops", "a_rounds", "b_scan_kmers", "b_sites",
-        "b_probes", "b_edits", "c_gaps", "c_closed", "c_vertex_tests")]
+        "b_probes", "b_edits", "c_gaps", "c_closed", "c_vertex_tests", "a_reservations")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

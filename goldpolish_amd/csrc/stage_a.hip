@@ -103,7 +103,7 @@ struct AArgs {
     const uint32_t* batch_order; // batches in the order the groups take them (long ones first, then the cbf_local ones)
     uint32_t grp_first, grp_n, tiles_per_batch;
     uint64_t off, slice;
-    unsigned long long* stats; // [0] positions [1] ops [2] ordered ops
+    unsigned long long* stats; // [0] positions [1] ops [2] ordered ops [3] tail / local rounds [4] reservation atomics
 };
 
 __device__ inline uint32_t resv_slot(const AArgs& a, uint32_t bits, uint32_t stream, uint32_t idx)
@@ -199,7 +199,8 @@ __device__ inline void reserve(const AArgs& a, uint32_t stream, const uint32_t* 
 // lists of a window in flight that was a third of a window's time.)
 template <int THREADS>
 __device__ inline uint32_t block_append(uint32_t* counter, uint32_t n_mine, uint32_t* s_wave /*[THREADS/64 + 1]*/,
-                                        uint32_t* also = nullptr)
+                                        uint32_t* also = nullptr, unsigned long long* resv_stat = nullptr,
+                                        uint32_t resv_each = 0)
 {
     constexpr int kWaves = THREADS / 64;
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
@@ -222,6 +223,8 @@ __device__ inline uint32_t block_append(uint32_t* counter, uint32_t n_mine, uint
         s_wave[kWaves] = tot ? atomicAdd(counter, tot) : 0u;
         if (tot && also)
             atomicAdd(also, tot);
+        if (tot && resv_stat)
+            atomicAdd(resv_stat, (unsigned long long)tot * resv_each);
     }
     __syncthreads();
     const uint32_t at = s_wave[kWaves] + s_wave[wave] + incl - n_mine;
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
     }
     // pass 3: one list append per workgroup, then reservations + records
     {
-        uint32_t at = block_append<kBlock>(a.count_out, n_ordered, s_wave, a.count_out + 1);
+        uint32_t at = block_append<kBlock>(a.count_out, n_ordered, s_wave, a.count_out + 1, a.stats + 4, a.hash_num);
 #pragma unroll
         for (int j = 0; j < kPerThread; j++) {
             if (!op_state[j])
@@ -576,7 +579,7 @@ __global__ __launch_bounds__(256) void cbf_round(AArgs a)
             rix = a.list_in[2 * i + 1];
             waits = round_op<false>(a, rec, rix, a.resv, a.resv_out, a.tag_cur, a.tag_next, a.bits_in);
         }
-        const uint32_t at = block_append<256>(a.count_out, waits ? 1u : 0u, s_wave);
+        const uint32_t at = block_append<256>(a.count_out, waits ? 1u : 0u, s_wave, nullptr, a.stats + 4, a.hash_num);
         if (waits) {
             a.list_out[2 * at] = rec;
             a.list_out[2 * at + 1] = rix;
@@ -665,7 +668,7 @@ __global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
 
 // ---- many small filters: one workgroup per (batch, k) pair replays its operations alone.
 // Nobody else touches the pair's counters, so the whole ordering problem stays inside the
-// workgroup: a tile of 1024 consecutive positions is hashed, what is settled goes straight
+// workgroup: a tile of 512 consecutive positions is hashed, what is settled goes straight
 // into the filter, and the rest is ordered through an LDS hash table keyed by the counter
 // index itself (exact: only operations that really share a counter wait for each other),
 // with workgroup barriers instead of launches between the rounds and without a single
@@ -677,12 +680,16 @@ __global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
 // operation of its tile on any of its counters, so the values loaded for the settle test
 // are still the current ones: in a sparse filter an operation costs its four counter
 // loads and the stores, nothing else.  The kernel is bound by those random line fetches.
-constexpr int kLocalSlots = 8192;      // >= 2 x the counter touches of a tile (hash_num <= 4)
+constexpr int kLTile = 512;            // positions per tile: with the 32 KB table four workgroups share a CU,
+constexpr int kLPer = 2;               // each in another phase (hash / load / order / store); 1024-position
+constexpr int kLBlock = kLTile / kLPer; // tiles with a 64 KB table (two workgroups per CU) ran 5 % slower
+constexpr int kLocalSlotBits = 12;
+constexpr int kLocalSlots = 1 << kLocalSlotBits; // >= 2 x the counter touches of a tile (hash_num <= 4)
 constexpr uint32_t kLocalEmpty = 0xFFFFFFFFu;
 
-__global__ __launch_bounds__(kBlock) void cbf_local(AArgs a, uint32_t first, uint32_t n_local)
+__global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, uint32_t n_local)
 {
-    __shared__ uint8_t codes[kTile + kHalo];
+    __shared__ uint8_t codes[kLTile + kHalo];
     __shared__ uint32_t keys[kLocalSlots]; // counter index held by the slot
     __shared__ uint32_t vals[kLocalSlots]; // earliest waiting operation of the tile on that counter
     __shared__ unsigned long long s_stats[4];
@@ -697,21 +704,21 @@ __global__ __launch_bounds__(kBlock) void cbf_local(AArgs a, uint32_t first, uin
     if (threadIdx.x < 4)
         s_stats[threadIdx.x] = 0;
     uint32_t n_ops = 0, n_ordered = 0, n_positions = 0, n_rounds = 0;
-    const int t0 = threadIdx.x * kPerThread;
+    const int t0 = threadIdx.x * kLPer;
 
-    for (uint64_t tile0 = b_start; tile0 < b_end; tile0 += kTile) {
-        const uint64_t tile_end = min(b_end, tile0 + (uint64_t)kTile);
+    for (uint64_t tile0 = b_start; tile0 < b_end; tile0 += kLTile) {
+        const uint64_t tile_end = min(b_end, tile0 + (uint64_t)kLTile);
         __syncthreads(); // everyone is done with the previous tile's codes
-        for (int i = threadIdx.x; i < kTile + kHalo; i += kBlock) {
+        for (int i = threadIdx.x; i < kLTile + kHalo; i += kLBlock) {
             uint64_t p = tile0 + i;
             uint8_t c = p < a.n_pos ? a.reads[p] : (uint8_t)'\n';
             codes[i] = base_code(c);
         }
         __syncthreads();
 
-        uint32_t op_state[kPerThread] = {}, op_thr[kPerThread] = {}, op_c[kPerThread] = {};
-        uint32_t op_idx[kPerThread][4] = {};
-        uint64_t op_base[kPerThread] = {};
+        uint32_t op_state[kLPer] = {}, op_thr[kLPer] = {}, op_c[kLPer] = {};
+        uint32_t op_idx[kLPer][4] = {};
+        uint64_t op_base[kLPer] = {};
         const uint64_t pos0 = tile0 + t0;
         if (pos0 < tile_end) {
             uint32_t lo = 0, hi = a.n_seg;
@@ -735,7 +742,7 @@ __global__ __launch_bounds__(kBlock) void cbf_local(AArgs a, uint32_t first, uin
                     last_bad = (int)i;
             }
 #pragma unroll
-            for (int j = 0; j < kPerThread; j++) {
+            for (int j = 0; j < kLPer; j++) {
                 const uint64_t pos = pos0 + j;
                 if (pos >= tile_end)
                     continue;
@@ -779,7 +786,7 @@ __global__ __launch_bounds__(kBlock) void cbf_local(AArgs a, uint32_t first, uin
         for (uint32_t round = 0;; round++) {
             uint32_t mine_left = 0;
 #pragma unroll
-            for (int j = 0; j < kPerThread; j++) {
+            for (int j = 0; j < kLPer; j++) {
                 if (!op_state[j])
                     continue;
                 if (round == 0 || (round & 7u) == 7u) {
@@ -808,19 +815,19 @@ __global__ __launch_bounds__(kBlock) void cbf_local(AArgs a, uint32_t first, uin
             if (!__syncthreads_or((int)mine_left))
                 break;
             n_rounds += threadIdx.x == 0;
-            for (int i = threadIdx.x; i < kLocalSlots; i += kBlock) {
+            for (int i = threadIdx.x; i < kLocalSlots; i += kLBlock) {
                 keys[i] = kLocalEmpty;
                 vals[i] = kLocalEmpty;
             }
             __syncthreads();
-            uint32_t op_slot[kPerThread][4];
+            uint32_t op_slot[kLPer][4];
 #pragma unroll
-            for (int j = 0; j < kPerThread; j++) {
+            for (int j = 0; j < kLPer; j++) {
                 if (!op_state[j])
                     continue;
                 for (uint32_t h = 0; h < a.hash_num; h++) {
                     const uint32_t ix = op_idx[j][h];
-                    uint32_t sl = (ix * 0x9E3779B1u) >> (32 - 13);
+                    uint32_t sl = (ix * 0x9E3779B1u) >> (32 - kLocalSlotBits);
                     for (;;) { // linear probing; the table is at most half full
                         const uint32_t old = atomicCAS(&keys[sl], kLocalEmpty, ix);
                         if (old == kLocalEmpty || old == ix)
@@ -833,7 +840,7 @@ __global__ __launch_bounds__(kBlock) void cbf_local(AArgs a, uint32_t first, uin
             }
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < kPerThread; j++) {
+            for (int j = 0; j < kLPer; j++) {
                 if (!op_state[j])
                     continue;
                 bool mine = true;
@@ -1119,7 +1126,7 @@ int stage_a_run(gp_job* job)
         int rc0 = job->t_local.begin(s, units);
         if (rc0 != GP_OK)
             return rc0;
-        hipLaunchKernelGGL(cbf_local, dim3(n_local * p.n_k), dim3(kBlock), 0, s, a, n_big, n_local);
+        hipLaunchKernelGGL(cbf_local, dim3(n_local * p.n_k), dim3(kLBlock), 0, s, a, n_big, n_local);
         GP_HIP(hipGetLastError());
         if ((rc0 = job->t_local.end(s)) != GP_OK)
             return rc0;
@@ -1423,7 +1430,7 @@ int stage_a_run(gp_job* job)
     // the rest of the pipeline (stream `s`) continues behind the last tail
     GP_HIP(hipEventRecord(job->a_ev_init, s2));
     GP_HIP(hipStreamWaitEvent(s, job->a_ev_init, 0));
-    unsigned long long st[4];
+    unsigned long long st[5];
     uint32_t tail_err = 0;
     GP_HIP(hipMemcpyAsync(st, job->d_stats.p, sizeof st, hipMemcpyDeviceToHost, s));
     GP_HIP(hipMemcpyAsync(&tail_err, err_flag, sizeof tail_err, hipMemcpyDeviceToHost, s));
@@ -1432,6 +1439,7 @@ int stage_a_run(gp_job* job)
     job->counters.a_ops = st[1];
     job->counters.a_ordered_ops = st[2];
     job->counters.a_rounds += st[3];
+    job->counters.a_reservations = st[4];
     if (tail_err) {
         set_error("stage A: reservation rounds did not converge");
         return GP_ERR_STATE;

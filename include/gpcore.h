@@ -109,6 +109,7 @@ typedef struct gp_counters {
     uint64_t c_gaps;         /* gaps found */
     uint64_t c_closed;       /* gaps closed */
     uint64_t c_vertex_tests; /* k-mer membership tests during BFS */
+    uint64_t a_reservations; /* device-scope atomics spent on reservations (grid-wide schedule) */
 } gp_counters;
 
 /* ---- library / context ------------------------------------------------- */

@@ -16,21 +16,22 @@ out.mkdir(exist_ok=True)
 for name in ("config2", "goldenpath"):
     for f in glob.glob(str(raw / f"{name}_trace" / "*" / "*kernel_stats.csv")):
         shutil.copy(f, out / f"{rnd}_{name}_kernel_stats.csv")
-traffic = {}
-for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    for f in glob.glob(str(raw / f"config2_{kind}" / "*" / "*counter_collection.csv")):
-        agg = collections.defaultdict(lambda: [0, 0.0])
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != counter:
-                continue
-            k = r["Kernel_Name"].split("(")[0]
-            agg[k][0] += 1
-            agg[k][1] += float(r["Counter_Value"])
-        for k, (n, v) in agg.items():
-            traffic.setdefault(k, {})[counter] = {"launches": n, "sum_KB": round(v, 1),
-                                                  "per_launch_KB": round(v / n, 1)}
-(out / f"{rnd}_config2_pmc_traffic.json").write_text(json.dumps(traffic, indent=1, sort_keys=True))
-b = raw / "config2_bench.json"
-if b.exists():
-    shutil.copy(b, out / f"{rnd}_config2_bench_line.json")
-print("kernels with PMC data:", len(traffic))
+for name in ("config2", "goldenpath"):
+    traffic = {}
+    for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        for f in glob.glob(str(raw / f"{name}_{kind}" / "*" / "*counter_collection.csv")):
+            agg = collections.defaultdict(lambda: [0, 0.0])
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != counter:
+                    continue
+                k = r["Kernel_Name"].split("(")[0]
+                agg[k][0] += 1
+                agg[k][1] += float(r["Counter_Value"])
+            for k, (n, v) in agg.items():
+                traffic.setdefault(k, {})[counter] = {"launches": n, "sum_KB": round(v, 1),
+                                                      "per_launch_KB": round(v / n, 1)}
+    (out / f"{rnd}_{name}_pmc_traffic.json").write_text(json.dumps(traffic, indent=1, sort_keys=True))
+    b = raw / f"{name}_bench.json"
+    if b.exists():
+        shutil.copy(b, out / f"{rnd}_{name}_bench_line.json")
+    print(name, "kernels with PMC data:", len(traffic))
