@@ -756,7 +756,12 @@ __device__ void indel_sweep(const Ctx& c, Shared& S, uint8_t index_char, uint32_
     atomicAdd(&S.st_probes, (unsigned long long)probes);
 }
 
-__global__ __launch_bounds__(kWalkThreads) void ntedit_walk(WalkArgs a)
+// kMinWaves: 1 = as many registers as the compiler likes (136: three workgroups per CU, the
+// fastest single walk); 6 = 80 registers (six per CU; some spills).  With thousands of contigs
+// the walk is throughput-bound on resident workgroups and the tight build is 17 % faster; with a
+// few hundred it is latency-bound and the roomy one is 8 % faster (stage_b_pass picks).
+template <int kMinWaves>
+__global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs a)
 {
     __shared__ Shared S;
     const uint32_t cid = blockIdx.x;
@@ -2075,7 +2080,10 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     // 2. the ordered walk, one workgroup per contig; 3. copy the edited contigs out
     if ((rc = job->t_walk.begin(s, job->h_contig_off[job->n_contigs])) != GP_OK)
         return rc;
-    hipLaunchKernelGGL(ntedit_walk, dim3(job->n_contigs), dim3(kWalkThreads), 0, s, a);
+    if (job->n_contigs > 3 * 256)
+        hipLaunchKernelGGL(ntedit_walk<6>, dim3(job->n_contigs), dim3(kWalkThreads), 0, s, a);
+    else
+        hipLaunchKernelGGL(ntedit_walk<1>, dim3(job->n_contigs), dim3(kWalkThreads), 0, s, a);
     hipLaunchKernelGGL(materialize_kernel, dim3(b->n_tiles), dim3(256), 0, s,
                        (const uint8_t*)a.seq, a.out, a.off, (const uint32_t*)a.len_next,
                        (const uint8_t*)a.dropped, (const Node*)a.nodes, a.node_off,

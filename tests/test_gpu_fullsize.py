@@ -167,3 +167,23 @@ def test_mixed_job_long_and_many_short_batches(gp, oracle, monkeypatch):
         _, bfs = oracle.fill_bfs(w.reads_of(b), [32, 24], int(w.kmer_threshold[b]), p.cbf_bytes,
                                  p.bf_bytes)
         assert np.array_equal(sample[i], bfs[1]), b
+
+
+def test_a_thousand_short_contigs_whole_path(gp, oracle):
+    """More contigs than the chip holds workgroups: stage A's workgroup-local schedule and the
+    register-tight build of the ntEdit walk (chosen above 768 contigs), whole path against the
+    oracle's batch driver, one contig per batch."""
+    core, ctx = gp
+    w = synth.make_workload([1500] * 700 + [3000] * 200 + [800] * 100, 20, seed=123)
+    p = core.default_params()
+    with core.Job.from_workload(ctx, p, w) as job:
+        job.polish()
+        got = job.sequences()
+        c = job.counters()
+        assert job.kernel_time("cbf_local")[1] == 1
+    assert c["b_edits"] > 100 and c["c_gaps"] > 0
+    op = oracle.batch_params()
+    for i in range(w.n_contigs):
+        outs, _, _ = oracle.polish_batch([w.names[i]], [w.contig(i)], [w.reads_of(i)],
+                                         [int(w.kmer_threshold[i])], op)
+        assert got[i] == outs[0], i
