@@ -29,6 +29,9 @@ SYMBOLS = [
     "gp_job_mask", "gp_job_sealer", "gp_job_upper", "gp_job_sync", "gp_job_get_filter",
     "gp_job_set_filters", "gp_job_get_lengths", "gp_job_get_sequences",
     "gp_job_get_sequences_device", "gp_job_get_counters", "gp_job_kernel_time",
+    "gp_seqindex_build", "gp_seqindex_load", "gp_seqindex_save", "gp_seqindex_count",
+    "gp_seqindex_entry", "gp_seqindex_find", "gp_seqindex_read", "gp_seqindex_destroy",
+    "gp_mappings_load", "gp_mappings_get", "gp_mappings_destroy", "gp_job_create_from_files",
 ]
 
 
@@ -128,6 +131,23 @@ def load_library(path=None):
     L.gp_job_get_sequences_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.gp_job_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
     L.gp_job_kernel_time.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), u64p, u64p]
+    vpp = C.POINTER(C.c_void_p)
+    dp = C.POINTER(C.c_double)
+    L.gp_seqindex_build.argtypes = [C.c_char_p, vpp]
+    L.gp_seqindex_load.argtypes = [C.c_char_p, C.c_char_p, vpp]
+    L.gp_seqindex_save.argtypes = [C.c_void_p, C.c_char_p]
+    L.gp_seqindex_count.restype = C.c_uint64
+    L.gp_seqindex_count.argtypes = [C.c_void_p]
+    L.gp_seqindex_entry.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_char_p), u64p, u64p, dp]
+    L.gp_seqindex_find.argtypes = [C.c_void_p, C.c_char_p, u64p, u64p, dp]
+    L.gp_seqindex_read.argtypes = [C.c_void_p, C.c_char_p, u8p, C.c_uint64, u64p]
+    L.gp_seqindex_destroy.argtypes = [C.c_void_p]
+    L.gp_mappings_load.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, vpp]
+    L.gp_mappings_get.argtypes = [C.c_void_p, C.c_char_p, u64p, C.POINTER(C.POINTER(C.c_char_p))]
+    L.gp_mappings_destroy.argtypes = [C.c_void_p]
+    L.gp_job_create_from_files.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_double, C.c_uint32, u32p,
+                                           C.POINTER(C.c_char_p), vpp]
     return L
 
 
@@ -198,6 +218,90 @@ def _arr(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
 
 
+def _bytes(x):
+    return x if isinstance(x, bytes) else str(x).encode()
+
+
+class SeqIndex:
+    """gp_seqindex: byte-offset index of a 2-line FASTA / 4-line FASTQ file (host side)."""
+
+    def __init__(self, seqs_path, index_path=None):
+        self._h = C.c_void_p()
+        if index_path is None:
+            _check(lib().gp_seqindex_build(_bytes(seqs_path), C.byref(self._h)))
+        else:
+            _check(lib().gp_seqindex_load(_bytes(index_path), _bytes(seqs_path), C.byref(self._h)))
+
+    def save(self, index_path):
+        _check(lib().gp_seqindex_save(self._h, _bytes(index_path)))
+
+    def __len__(self):
+        return int(lib().gp_seqindex_count(self._h))
+
+    def entries(self):
+        """[(id, start, length, avg_phred)] in file order"""
+        out = []
+        for i in range(len(self)):
+            sid, st, ln, ph = C.c_char_p(), C.c_uint64(), C.c_uint64(), C.c_double()
+            _check(lib().gp_seqindex_entry(self._h, i, C.byref(sid), C.byref(st), C.byref(ln),
+                                           C.byref(ph)))
+            out.append((sid.value, st.value, ln.value, ph.value))
+        return out
+
+    def find(self, sid):
+        st, ln, ph = C.c_uint64(), C.c_uint64(), C.c_double()
+        rc = lib().gp_seqindex_find(self._h, _bytes(sid), C.byref(st), C.byref(ln), C.byref(ph))
+        if rc == -8:
+            return None
+        _check(rc)
+        return st.value, ln.value, ph.value
+
+    def read(self, sid) -> bytes:
+        n = C.c_uint64()
+        _check(lib().gp_seqindex_read(self._h, _bytes(sid), None, 0, C.byref(n)))
+        buf = np.zeros(max(n.value, 1), dtype=np.uint8)
+        _check(lib().gp_seqindex_read(self._h, _bytes(sid), buf.ctypes.data_as(u8p), buf.size,
+                                      C.byref(n)))
+        return buf[:n.value].tobytes()
+
+    def close(self):
+        if self._h:
+            lib().gp_seqindex_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class Mappings:
+    """gp_mappings: target id -> mapped read ids, from a .sam / .paf / ntLink table."""
+
+    def __init__(self, path, targets: SeqIndex, mx_min=1, mx_max=30, mx_max_mapped_per_10kbp=100.0):
+        self._h = C.c_void_p()
+        _check(lib().gp_mappings_load(_bytes(path), targets._h, mx_min, mx_max,
+                                      float(mx_max_mapped_per_10kbp), C.byref(self._h)))
+
+    def get(self, target_id):
+        n = C.c_uint64()
+        ids = C.POINTER(C.c_char_p)()
+        _check(lib().gp_mappings_get(self._h, _bytes(target_id), C.byref(n), C.byref(ids)))
+        return [ids[i] for i in range(n.value)]
+
+    def close(self):
+        if self._h:
+            lib().gp_mappings_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 class Job:
     """A set of batches resident on the device."""
 
@@ -230,6 +334,25 @@ class Job:
         self.n_batches, self.n_contigs = bs.n_batches, n_contigs
         self._h = C.c_void_p()
         _check(lib().gp_job_create(ctx._h, C.byref(params), C.byref(bs), C.byref(self._h)))
+
+    @classmethod
+    def from_files(cls, ctx, params, targets: SeqIndex, reads: SeqIndex, mappings: Mappings,
+                   batches, max_reads_per_10kbp=40.0):
+        """batches: list of lists of target ids (what scripts/goldpolish puts into one batch.fa)"""
+        self = cls.__new__(cls)
+        self.ctx, self.params = ctx, params
+        ids = [_bytes(t) for b in batches for t in b]
+        begin = np.zeros(len(batches) + 1, dtype=np.uint32)
+        begin[1:] = np.cumsum([len(b) for b in batches])
+        arr = (C.c_char_p * max(len(ids), 1))(*ids)
+        self._keep = dict(begin=begin, ids=arr)
+        self.n_batches, self.n_contigs = len(batches), len(ids)
+        self._h = C.c_void_p()
+        _check(lib().gp_job_create_from_files(ctx._h, C.byref(params), targets._h, reads._h,
+                                              mappings._h, float(max_reads_per_10kbp),
+                                              len(batches), begin.ctypes.data_as(u32p), arr,
+                                              C.byref(self._h)))
+        return self
 
     @classmethod
     def from_workload(cls, ctx, params, w):

@@ -34,11 +34,14 @@ typedef enum gp_status {
     GP_ERR_OOM = -4,           /* device or host allocation failed */
     GP_ERR_THRESHOLD = -5,     /* kmer_threshold < 4 (reference: src/utils.cpp:105-107) */
     GP_ERR_STATE = -6,         /* stage called out of order */
-    GP_ERR_UNSUPPORTED = -7    /* parameter outside what the kernels implement */
+    GP_ERR_UNSUPPORTED = -7,   /* parameter outside what the kernels implement */
+    GP_ERR_NOT_FOUND = -8      /* a sequence id is not in the index */
 } gp_status;
 
 typedef struct gp_ctx gp_ctx; /* one per device */
 typedef struct gp_job gp_job; /* a set of batches resident on the device */
+typedef struct gp_seqindex gp_seqindex; /* byte-offset index of a 2-line FASTA / 4-line FASTQ file */
+typedef struct gp_mappings gp_mappings; /* target id -> mapped read ids */
 
 /* Parameters of the path.  Defaults = what GoldPolish passes:
  *   k list 32,28,24,20                       scripts/goldpolish:189-190
@@ -171,6 +174,43 @@ int gp_job_get_counters(gp_job* job, gp_counters* out);
  * and the number of launches and streamed positions it covered. */
 int gp_job_kernel_time(gp_job* job, const char* kernel, double* total_ms, uint64_t* launches,
                        uint64_t* units);
+
+
+/* ---- the step in front of the path: which reads reach the filter build -----
+ * Host-side (no device work), SURVEY.md 8f-2.
+ *
+ * gp_seqindex = SeqIndex (src/seqindex.cpp:12-137, seqindex.hpp:59-102) and the
+ * `goldpolish-index` tool (src/goldpolish_index.cpp): build from a sequence file
+ * or load a saved index (lines "id<TAB>start<TAB>length<TAB>avg_phred"), save,
+ * look up, fetch the bytes of one sequence. */
+int gp_seqindex_build(const char* seqs_path, gp_seqindex** out);
+int gp_seqindex_load(const char* index_path, const char* seqs_path, gp_seqindex** out);
+int gp_seqindex_save(const gp_seqindex* ix, const char* index_path);
+uint64_t gp_seqindex_count(const gp_seqindex* ix);
+int gp_seqindex_entry(const gp_seqindex* ix, uint64_t i, const char** id, uint64_t* start,
+                      uint64_t* len, double* phred); /* i-th record in file order */
+int gp_seqindex_find(const gp_seqindex* ix, const char* id, uint64_t* start, uint64_t* len,
+                     double* phred);                 /* GP_ERR_NOT_FOUND if absent */
+int gp_seqindex_read(const gp_seqindex* ix, const char* id, uint8_t* buf, uint64_t buf_bytes,
+                     uint64_t* len);                 /* buf == NULL: length only */
+void gp_seqindex_destroy(gp_seqindex* ix);
+/* gp_mappings = AllMappings (src/mappings.cpp:15-345): ".sam" -> SAM, ".paf" -> PAF,
+ * anything else -> ntLink "read target minimizers" table, filtered per target by
+ * the common-minimizer threshold found in [mx_min, mx_max] for at most
+ * mx_max_mapped_per_10kbp reads per 10 kbp of target (GoldPolish: 1, 30, -x). */
+int gp_mappings_load(const char* path, const gp_seqindex* targets, uint32_t mx_min, uint32_t mx_max,
+                     double mx_max_mapped_per_10kbp, gp_mappings** out);
+int gp_mappings_get(gp_mappings* m, const char* target_id, uint64_t* n, const char* const** ids);
+void gp_mappings_destroy(gp_mappings* m);
+/* serve_batch's read selection (src/goldpolish_targeted_bfs.cpp:86-131) for every target of
+ * every batch, and the batch's contigs as scripts/goldpolish:344-355 writes them: batch b holds
+ * target_ids[batch_target_begin[b] .. batch_target_begin[b+1]).  The job is then the same as one
+ * made by gp_job_create from the same bytes. */
+int gp_job_create_from_files(gp_ctx* ctx, const gp_params* params, const gp_seqindex* targets,
+                             const gp_seqindex* reads, gp_mappings* mappings,
+                             double max_reads_per_10kbp, uint32_t n_batches,
+                             const uint32_t* batch_target_begin, const char* const* target_ids,
+                             gp_job** out);
 
 #ifdef __cplusplus
 }
