@@ -32,6 +32,7 @@ SYMBOLS = [
     "gp_seqindex_build", "gp_seqindex_load", "gp_seqindex_save", "gp_seqindex_count",
     "gp_seqindex_entry", "gp_seqindex_find", "gp_seqindex_read", "gp_seqindex_destroy",
     "gp_mappings_load", "gp_mappings_get", "gp_mappings_destroy", "gp_job_create_from_files",
+    "gp_target_extract", "gp_target_update_paf", "gp_target_reinsert",
 ]
 
 
@@ -148,6 +149,9 @@ def load_library(path=None):
     L.gp_job_create_from_files.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_double, C.c_uint32, u32p,
                                            C.POINTER(C.c_char_p), vpp]
+    L.gp_target_extract.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p]
+    L.gp_target_update_paf.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    L.gp_target_reinsert.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
     return L
 
 
@@ -220,6 +224,19 @@ def _arr(a, dtype):
 
 def _bytes(x):
     return x if isinstance(x, bytes) else str(x).encode()
+
+
+def target_extract(fasta_path, out_path, flank=64, bed_path=None):
+    _check(lib().gp_target_extract(_bytes(fasta_path), _bytes(bed_path) if bed_path else None,
+                                   int(flank), _bytes(out_path)))
+
+
+def target_update_paf(gaps_fasta_path, paf_path, out_path):
+    _check(lib().gp_target_update_paf(_bytes(gaps_fasta_path), _bytes(paf_path), _bytes(out_path)))
+
+
+def target_reinsert(fasta_path, polished_gaps_path, out_path):
+    _check(lib().gp_target_reinsert(_bytes(fasta_path), _bytes(polished_gaps_path), _bytes(out_path)))
 
 
 class SeqIndex:

@@ -212,6 +212,18 @@ int gp_job_create_from_files(gp_ctx* ctx, const gp_params* params, const gp_seqi
                              const uint32_t* batch_target_begin, const char* const* target_ids,
                              gp_job** out);
 
+/* ---- GoldPolish-Target's file-to-file steps around the path, host side -------
+ * gp_target_extract: windows to polish = soft-masked runs (bed_path == NULL) or BED intervals,
+ * each with `flank` bases either side, written upper-case as ">contig.N start-end"
+ * (scripts/goldpolish-target-extract-seq.py:60-148).
+ * gp_target_update_paf: PAF rows on the assembly -> rows on the windows, coordinates clipped
+ * (scripts/goldpolish-target-update-mapping.py:70-155).
+ * gp_target_reinsert: polished windows back into the assembly
+ * (scripts/goldpolish-target-post-processing.py:28-94). */
+int gp_target_extract(const char* fasta_path, const char* bed_path, uint32_t flank, const char* out_path);
+int gp_target_update_paf(const char* gaps_fasta_path, const char* paf_path, const char* out_path);
+int gp_target_reinsert(const char* fasta_path, const char* polished_gaps_path, const char* out_path);
+
 #ifdef __cplusplus
 }
 #endif
