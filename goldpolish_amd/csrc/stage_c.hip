@@ -1178,6 +1178,11 @@ __global__ __launch_bounds__(kApplyThreads) void apply_fills(CArgs a, uint64_t s
         const uint32_t fl = a.fill_len[gi];
         if (!fl)
             continue;
+        // A fill whose range reaches into the previous (right-hand) fill overwrites the start of
+        // it: every lane must be done writing that one first (found by tools/fuzz_parity.py:
+        // neighbouring gaps closer than two flanks, both closed).  Everything that decides
+        // whether this point is reached is uniform across the workgroup.
+        __syncthreads();
         const Flank f = flank_of(a, gi);
         const uint32_t pos = f.ls;
         const uint32_t size = P + (cap - sb);
@@ -1396,6 +1401,31 @@ int stage_c_run(gp_job* job)
     GP_HIP(hipGetLastError());
     if ((rc = job->t_bfs.end(s)) != GP_OK)
         return rc;
+    if (getenv("GP_SEALER_DEBUG")) {
+        // development aid: every closed gap of every contig, as the reference's ClosedGap
+        GP_HIP(hipStreamSynchronize(s));
+        std::vector<uint32_t> n_g(job->n_contigs), g_off(job->n_contigs + 1);
+        GP_HIP(hipMemcpy(n_g.data(), c->n_gaps.p, n_g.size() * 4, hipMemcpyDeviceToHost));
+        GP_HIP(hipMemcpy(g_off.data(), c->gap_off.p, g_off.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t cid = 0; cid < job->n_contigs; cid++) {
+            std::vector<Gap> gs(n_g[cid] ? n_g[cid] : 1);
+            std::vector<uint32_t> fl(gs.size()), ca(gs.size());
+            std::vector<uint64_t> fo(gs.size());
+            if (!n_g[cid])
+                continue;
+            GP_HIP(hipMemcpy(gs.data(), c->gaps.p + g_off[cid], n_g[cid] * sizeof(Gap), hipMemcpyDeviceToHost));
+            GP_HIP(hipMemcpy(fl.data(), c->fill_len.p + g_off[cid], n_g[cid] * 4, hipMemcpyDeviceToHost));
+            GP_HIP(hipMemcpy(ca.data(), c->closed_at.p + g_off[cid], n_g[cid] * 4, hipMemcpyDeviceToHost));
+            GP_HIP(hipMemcpy(fo.data(), c->fill_off.p + g_off[cid], n_g[cid] * 8, hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < n_g[cid]; i++) {
+                std::string f(fl[i], ' ');
+                if (fl[i])
+                    GP_HIP(hipMemcpy(&f[0], c->pool.p + fo[i], fl[i], hipMemcpyDeviceToHost));
+                fprintf(stderr, "DEVGAP contig %u gap %u s %u e %u fl %u closed_at %u fill %.40s...%s\n", cid, i, gs[i].s,
+                        gs[i].e, fl[i], ca[i], f.c_str(), fl[i] > 12 ? f.c_str() + fl[i] - 12 : "");
+            }
+        }
+    }
     b->cur ^= 1;
     return GP_OK;
 }

@@ -1,0 +1,21 @@
+"""A few seeds of tools/fuzz_parity.py: random small jobs (shapes, k lists, filter sizes,
+groupings, thresholds, N / lower-case / IUPAC drafts) through both stage-A schedules, whole path,
+against the oracle's batch driver."""
+import pathlib
+import sys
+
+import pytest
+
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1] / "tools"))
+pytestmark = pytest.mark.gpu
+
+
+def test_random_jobs_match_the_oracle(oracle, monkeypatch):
+    import fuzz_parity
+    from goldpolish_amd import core
+    with core.Context(0) as ctx:
+        # 1086: neighbouring gaps closer than two flanks, both closed (overlapping fills)
+        for seed in [1086] + list(range(7000, 7011)):
+            for mode in ("0", "1"):
+                monkeypatch.setenv("GP_STAGE_A_LOCAL", mode)
+                assert fuzz_parity.run_case(core, ctx, oracle, seed, mode) is None, (seed, mode)

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Randomised whole-path parity: many small random jobs (contig shapes, error rates, k lists,
+filter sizes, thresholds, batch grouping, ntEdit / Sealer parameters, soft-masked and N-holding
+drafts) through libgpcore on the GPU against the C oracle, stage by stage.  Dev tool; a few of
+its seeds run in tests/test_gpu_fuzz.py.  Usage: fuzz_parity.py [n_cases] [first_seed]"""
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import numpy as np
+
+
+def random_case(seed):
+    from goldpolish_amd import synth
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(1, 7))
+    lens = [int(rng.choice([90, 150, 400, 1500, 4000, 9000, 20000], p=[.05, .05, .1, .2, .3, .2, .1])) for _ in range(n)]
+    cov = float(rng.choice([3, 8, 15, 25, 40]))
+    w = synth.make_workload(lens, cov, seed=seed, draft_err=float(rng.choice([0.0, 0.003, 0.01, 0.03, 0.08])),
+                            read_err=float(rng.choice([0.0, 0.02, 0.06, 0.12])),
+                            read_mean=float(rng.choice([300, 2000, 15000])), read_min=int(rng.choice([25, 200, 1000])))
+    # sprinkle N runs, lower case and IUPAC letters into some drafts
+    buf = w.contig_buf.copy()
+    for c in range(w.n_contigs):
+        a, b = int(w.contig_off[c]), int(w.contig_off[c + 1])
+        mode = rng.integers(0, 4)
+        if mode == 1 and b - a > 200:
+            for _ in range(int(rng.integers(1, 4))):
+                s = int(rng.integers(a, b - 60)); L = int(rng.integers(1, 50))
+                buf[s:s + L] = ord("N")
+        elif mode == 2 and b - a > 200:
+            s = int(rng.integers(a, b - 100)); L = int(rng.integers(5, 90))
+            buf[s:s + L] = np.frombuffer(bytes(buf[s:s + L]).lower(), dtype=np.uint8)
+        elif mode == 3 and b - a > 50:
+            for _ in range(3):
+                buf[int(rng.integers(a, b))] = ord(rng.choice(list("RYSWKMBDHVn")))
+    w.contig_buf = buf
+    ks = [[32, 28, 24, 20], [32], [40, 25], [31, 21, 11], [63, 33], [24, 20, 16, 12], [20]][int(rng.integers(0, 7))]
+    sizes = [(10 * 1024 * 1024, 512 * 1024), (65536, 8192), (4099, 1024), (1 << 20, 1 << 16)][int(rng.integers(0, 4))]
+    # batch grouping: singletons, pairs, or everything in one batch
+    g = int(rng.integers(0, 3))
+    if g == 0:
+        bcb = list(range(n + 1))
+    elif g == 1:
+        bcb = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, size=2)]))
+    else:
+        bcb = [0, n]
+    extra = dict(missing_ratio=float(rng.choice([0.3, 0.5, 0.8])), edit_ratio=float(rng.choice([0.3, 0.5, 0.7])),
+                 sealer_max_paths=int(rng.choice([1, 2, 10])), sealer_max_branches=int(rng.choice([10, 1000])))
+    if rng.random() < 0.3:
+        w.kmer_threshold[:] = int(rng.integers(4, 14))
+    return w, ks, sizes, bcb, extra
+
+
+def run_case(core, ctx, O, seed, local_mode):
+    w, ks, (cbf, bf), bcb, extra = random_case(seed)
+    os.environ["GP_STAGE_A_LOCAL"] = local_mode
+    p = core.default_params(k_values=ks, cbf_bytes=cbf, bf_bytes=bf, **extra)
+    names = w.names
+    with core.Job(ctx, p, contig_buf=w.contig_buf, contig_off=w.contig_off, contig_read_begin=w.contig_read_begin,
+                  kmer_threshold=w.kmer_threshold, read_buf=w.read_buf, read_off=w.read_off,
+                  batch_contig_begin=bcb, name_len=[len(x) for x in names]) as job:
+        job.polish()
+        got = job.sequences()
+        filt = [[job.get_filter(b, ki).copy() for ki in range(len(ks))] for b in range(len(bcb) - 1)]
+    # the oracle's batch driver takes the same knobs under its own field names
+    op = O.batch_params(k_values=tuple(ks), cbf_bytes=cbf, bf_bytes=bf, ntedit_x=extra["missing_ratio"],
+                        ntedit_y=extra["edit_ratio"], sealer_P=extra["sealer_max_paths"],
+                        sealer_B=extra["sealer_max_branches"])
+    for b in range(len(bcb) - 1):
+        cs = list(range(bcb[b], bcb[b + 1]))
+        if not cs:
+            continue
+        outs, st, bfs = O.polish_batch([names[c] for c in cs], [bytes(w.contig_buf[int(w.contig_off[c]):int(w.contig_off[c + 1])]) for c in cs],
+                                       [w.reads_of(c) for c in cs], [int(w.kmer_threshold[c]) for c in cs], op, want_bfs=True)
+        for ki in range(len(ks)):
+            if not np.array_equal(filt[b][ki], bfs[ki]):
+                return f"filter mismatch batch {b} k index {ki}"
+        for c, o in zip(cs, outs):
+            if got[c] != o:
+                return f"sequence mismatch contig {c} (batch {b})"
+    return None
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    from goldpolish_amd import core
+    import oracle_lib
+    O = oracle_lib.Oracle(str(ROOT / "oracle" / "libgpo.so"))
+    bad = 0
+    t0 = time.time()
+    with core.Context(0) as ctx:
+        for seed in range(first, first + n):
+            for mode in ("0", "1"):
+                try:
+                    err = run_case(core, ctx, O, seed, mode)
+                except Exception as e:  # noqa: BLE001 -- a fuzz loop reports and goes on
+                    err = f"exception {type(e).__name__}: {e}"
+                if err:
+                    bad += 1
+                    print(f"seed {seed} local={mode}: {err}", flush=True)
+            if (seed - first) % 10 == 9:
+                print(f"... {seed - first + 1} cases, {bad} failures, {time.time() - t0:.0f} s", flush=True)
+    print(f"fuzz: {n} cases x 2 schedules, {bad} failures")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
