@@ -436,20 +436,31 @@ int gp_job_polish(gp_job* job, int sync)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
     int rc = stage_a_run(job);
-    for (uint32_t ki = 0; rc == GP_OK && ki < job->prm.n_k; ki++) {
-        if (ki == 0)
-            rc = stage_b_reset(job);
+    for (int attempt = 0; rc == GP_OK; attempt++) {
+        for (uint32_t ki = 0; rc == GP_OK && ki < job->prm.n_k; ki++) {
+            if (ki == 0)
+                rc = stage_b_reset(job);
+            if (rc == GP_OK)
+                rc = stage_b_pass(job, ki);
+        }
         if (rc == GP_OK)
-            rc = stage_b_pass(job, ki);
+            rc = stage_b_guard(job);
+        if (rc == GP_OK)
+            rc = stage_mask(job);
+        if (rc == GP_OK && job->prm.run_sealer)
+            rc = stage_c_run(job);
+        if (rc == GP_OK)
+            rc = stage_upper(job);
+        // errors raised inside kernels surface when stage_upper reads the statistics back
+        if (rc != GP_ERR_CAPACITY || attempt == 4)
+            break;
+        // a contig grew past its slot (ntEdit inserting on a near-saturated filter): twice the
+        // room, and stages B and C again from the unedited contigs; the filters stay
+        job->bc_slack *= 2;
+        stage_bc_release(job);
+        if ((rc = stage_bc_prepare(job)) != GP_OK)
+            break;
     }
-    if (rc == GP_OK)
-        rc = stage_b_guard(job);
-    if (rc == GP_OK)
-        rc = stage_mask(job);
-    if (rc == GP_OK && job->prm.run_sealer)
-        rc = stage_c_run(job);
-    if (rc == GP_OK)
-        rc = stage_upper(job);
     return finish(job, rc, sync);
 }
 

@@ -128,6 +128,7 @@ struct gp_job {
 
     // ---- stage B/C state (see stage_b.hip / stage_c.hip)
     gp::StageBC* bc = nullptr;
+    uint32_t bc_slack = 1; // sequence slots hold len + (len/2 + 4 KiB) * bc_slack bytes
 
     gp::KernelTimer t_first_pass, t_round, t_local, t_scan, t_walk, t_bfs, t_mask, t_upper, t_reset;
     gp_counters counters{};

@@ -1327,6 +1327,13 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             }
         }
         a.n_nodes[cid] = live;
+        if ((uint64_t)o > a.off[cid + 1] - a.off[cid]) {
+            // the edited contig no longer fits its slot: nothing is laid out, the host grows
+            // the slots and runs the cascade again (stage_b: capacity error)
+            atomicOr(a.err, 1024u);
+            o = 0;
+            a.n_nodes[cid] = 0;
+        }
         a.len_next[cid] = o;
         atomicAdd(&a.stats[0], S.st_scan);
         atomicAdd(&a.stats[1], S.st_sites);
@@ -1899,10 +1906,12 @@ int stage_bc_prepare(gp_job* job)
         b->h_off[c] = off;
         b->h_node_off[c] = noff;
         // room for net insertions (ntEdit) and gap fills (Sealer)
-        uint64_t cap = len + len / 2 + 4096;
+        // (doubled by gp_job_polish when a contig outgrows it: filters that call nearly every
+        // k-mer present make ntEdit insert without end)
+        uint64_t cap = len + (len / 2 + 4096) * job->bc_slack;
         cap = (cap + 1023) & ~1023ull; // slots start on ntedit_scan tile boundaries
         off += cap;
-        noff += len + 256;
+        noff += len + 256 + (len / 2 + 4096) * (job->bc_slack - 1);
     }
     b->h_off[n] = off;
     b->h_node_off[n] = noff;
@@ -2020,6 +2029,11 @@ static int pull_stats(gp_job* job)
         (rc = job->t_mask.collect()) != GP_OK || (rc = job->t_upper.collect()) != GP_OK ||
         (rc = job->t_bfs.collect()) != GP_OK || (rc = job->t_reset.collect()) != GP_OK)
         return rc;
+    if (err & (1u | 1024u | 512u)) {
+        set_error("a contig outgrew its device slot (code " + std::to_string(err) +
+                  "): gp_job_polish retries with larger slots, the step-wise calls do not");
+        return GP_ERR_CAPACITY;
+    }
     if (err) {
         set_error("device work buffer overflow (code " + std::to_string(err) + ")");
         return GP_ERR_STATE;

@@ -35,7 +35,8 @@ typedef enum gp_status {
     GP_ERR_THRESHOLD = -5,     /* kmer_threshold < 4 (reference: src/utils.cpp:105-107) */
     GP_ERR_STATE = -6,         /* stage called out of order */
     GP_ERR_UNSUPPORTED = -7,   /* parameter outside what the kernels implement */
-    GP_ERR_NOT_FOUND = -8      /* a sequence id is not in the index */
+    GP_ERR_NOT_FOUND = -8,     /* a sequence id is not in the index */
+    GP_ERR_CAPACITY = -9       /* an edited contig outgrew its device slot (gp_job_polish retries by itself) */
 } gp_status;
 
 typedef struct gp_ctx gp_ctx; /* one per device */
