@@ -649,8 +649,11 @@ void gpo_ntedit_default_params(gpo_ntedit_params* p, unsigned k, unsigned h)
 
 size_t gpo_ntedit_out_bound(size_t len) { return 2 * len + 64; }
 
-size_t gpo_ntedit_contig(const char* seq_in, size_t len, const uint8_t* bf, size_t bf_bytes,
-                         const gpo_ntedit_params* p, char* out, uint64_t* n_probes)
+/* Runs the edit loop; the edited sequence comes back in a malloc'ed buffer of exactly its
+ * length + 1 (filters that call nearly every k-mer present make ntEdit insert a lot: no bound
+ * in terms of the input length holds). */
+static size_t ntedit_run(const char* seq_in, size_t len, const uint8_t* bf, size_t bf_bytes,
+                         const gpo_ntedit_params* p, char** out_alloc, uint64_t* n_probes)
 {
     ed_t E;
     ed_t* e = &E;
@@ -812,6 +815,19 @@ size_t gpo_ntedit_contig(const char* seq_in, size_t len, const uint8_t* bf, size
     } while (go);
 
     /* writeEditsToFile, sequence line only */
+    size_t need = 0;
+    for (size_t ni = 0; ni < e->nn && e->nd[ni].type != -1; ni++) {
+        const node_t* n = &e->nd[ni];
+        if (n->type == 0) {
+            size_t s = n->s, cnt = n->e - n->s + 1;
+            if (s <= e->len)
+                need += cnt > e->len - s ? e->len - s : cnt;
+        } else {
+            need++;
+        }
+    }
+    char* out = (char*)malloc(need + 1);
+    *out_alloc = out;
     size_t o = 0;
     for (size_t ni = 0; ni < e->nn && e->nd[ni].type != -1; ni++) {
         const node_t* n = &e->nd[ni];
@@ -828,9 +844,29 @@ size_t gpo_ntedit_contig(const char* seq_in, size_t len, const uint8_t* bf, size
             out[o++] = (char)n->c;
         }
     }
+    out[o] = 0;
     if (n_probes)
         *n_probes += e->probes;
     free(e->seq);
     free(e->nd);
     return o;
+}
+
+size_t gpo_ntedit_contig_dyn(const char* seq, size_t len, const uint8_t* bf, size_t bf_bytes,
+                             const gpo_ntedit_params* p, char** out, uint64_t* n_probes)
+{
+    return ntedit_run(seq, len, bf, bf_bytes, p, out, n_probes);
+}
+
+/* Caller-provided buffer of gpo_ntedit_out_bound(len) bytes: returns the edited length; when
+ * that exceeds the bound only the first `bound` bytes were written. */
+size_t gpo_ntedit_contig(const char* seq, size_t len, const uint8_t* bf, size_t bf_bytes,
+                         const gpo_ntedit_params* p, char* out, uint64_t* n_probes)
+{
+    char* o = NULL;
+    const size_t n = ntedit_run(seq, len, bf, bf_bytes, p, &o, n_probes);
+    const size_t bound = gpo_ntedit_out_bound(len);
+    memcpy(out, o, n < bound ? n : bound);
+    free(o);
+    return n;
 }

@@ -97,10 +97,9 @@ int gpo_polish_batch(const gpo_batch_params* bp, unsigned n_contigs, const char*
                 dropped[c] = 1;
                 continue;
             }
-            char* o = (char*)malloc(gpo_ntedit_out_bound(cur_len[c]) + 1);
-            size_t ol = gpo_ntedit_contig(cur[c], cur_len[c], bfs[ki], bp->bf_bytes, &np, o,
-                                          &st->b_probes);
-            o[ol] = 0;
+            char* o = NULL;
+            size_t ol = gpo_ntedit_contig_dyn(cur[c], cur_len[c], bfs[ki], bp->bf_bytes, &np, &o,
+                                              &st->b_probes);
             free(cur[c]);
             cur[c] = o;
             cur_len[c] = ol;

@@ -84,6 +84,9 @@ class Oracle:
         L.gpo_ntedit_contig.restype = C.c_size_t
         L.gpo_ntedit_contig.argtypes = [C.c_char_p, C.c_size_t, u8p, C.c_size_t,
                                         C.POINTER(NteditParams), C.c_char_p, u64p]
+        L.gpo_ntedit_contig_dyn.restype = C.c_size_t
+        L.gpo_ntedit_contig_dyn.argtypes = [C.c_char_p, C.c_size_t, u8p, C.c_size_t,
+                                            C.POINTER(NteditParams), C.POINTER(C.c_void_p), u64p]
         L.gpo_mask.restype = C.c_size_t
         L.gpo_mask.argtypes = [C.c_char_p, C.c_size_t, C.c_uint, C.c_char_p]
         L.gpo_sealer_default_params.argtypes = [C.POINTER(SealerParams), C.c_uint]
@@ -160,11 +163,13 @@ class Oracle:
     def ntedit(self, seq, bf, k, h=4, params=None):
         seq = _b(seq)
         p = params or self.ntedit_params(k, h)
-        out = C.create_string_buffer(self.L.gpo_ntedit_out_bound(len(seq)) + 1)
+        out = C.c_void_p()
         probes = C.c_uint64(0)
-        n = self.L.gpo_ntedit_contig(seq, len(seq), bf.ctypes.data_as(u8p), bf.size, C.byref(p),
-                                     out, C.byref(probes))
-        return out.raw[:n], probes.value
+        n = self.L.gpo_ntedit_contig_dyn(seq, len(seq), bf.ctypes.data_as(u8p), bf.size, C.byref(p),
+                                         C.byref(out), C.byref(probes))
+        res = C.string_at(out, n)
+        self.L.gpo_free(out)
+        return res, probes.value
 
     # ---- mask / sealer
     def mask(self, seq, k):

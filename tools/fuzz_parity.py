@@ -39,6 +39,20 @@ def random_case(seed):
             for _ in range(3):
                 buf[int(rng.integers(a, b))] = ord(rng.choice(list("RYSWKMBDHVn")))
     w.contig_buf = buf
+    if rng.random() < 0.35 and w.read_buf.size > 400:
+        # low-complexity stretches (homopolymers, short tandem repeats) in reads and drafts: the same
+        # k-mer many times in a row, i.e. long chains of operations on the same counters
+        rb = w.read_buf.copy()
+        for target in (rb, buf):
+            for _ in range(int(rng.integers(1, 6))):
+                L = int(rng.integers(20, 300))
+                if target.size <= L + 1:
+                    continue
+                s0 = int(rng.integers(0, target.size - L))
+                unit = [b"A", b"T", b"AC", b"GGC", b"ACGT", b"AAAAAAAAAC"][int(rng.integers(0, 6))]
+                target[s0:s0 + L] = np.frombuffer((unit * (L // len(unit) + 1))[:L], dtype=np.uint8)
+        w.read_buf = rb
+        w.contig_buf = buf
     ks = [[32, 28, 24, 20], [32], [40, 25], [31, 21, 11], [63, 33], [24, 20, 16, 12], [20]][int(rng.integers(0, 7))]
     sizes = [(10 * 1024 * 1024, 512 * 1024), (65536, 8192), (4099, 1024), (1 << 20, 1 << 16)][int(rng.integers(0, 4))]
     # batch grouping: singletons, pairs, or everything in one batch
@@ -86,6 +100,64 @@ def run_case(core, ctx, O, seed, local_mode):
     return None
 
 
+def run_staged(core, ctx, O, seed, local_mode):
+    """step-wise API with random ntEdit / Sealer parameters, every stage against the oracle"""
+    w, ks, (cbf, bf), bcb, extra = random_case(seed)
+    rng = np.random.default_rng(seed + 77)
+    os.environ["GP_STAGE_A_LOCAL"] = local_mode
+    nt = dict(max_insertions=int(rng.choice([0, 1, 3, 5])), max_deletions=int(rng.choice([0, 2, 5, 10])),
+              jump=int(rng.choice([1, 2, 3, 5])), missing_ratio=extra["missing_ratio"], edit_ratio=extra["edit_ratio"],
+              soft_mask=int(rng.integers(0, 2)), min_contig_len=int(rng.choice([100, 50, 500])))
+    se = dict(sealer_max_paths=extra["sealer_max_paths"], sealer_max_branches=extra["sealer_max_branches"],
+              sealer_max_gap=int(rng.choice([30, 800])), sealer_max_cost=int(rng.choice([300, 100000])))
+    p = core.default_params(k_values=ks, cbf_bytes=cbf, bf_bytes=bf, **nt, **se)
+    contig = lambda c: bytes(w.contig_buf[int(w.contig_off[c]):int(w.contig_off[c + 1])])
+    batch_of = {c: b for b in range(len(bcb) - 1) for c in range(bcb[b], bcb[b + 1])}
+    with core.Job(ctx, p, contig_buf=w.contig_buf, contig_off=w.contig_off, contig_read_begin=w.contig_read_begin,
+                  kmer_threshold=w.kmer_threshold, read_buf=w.read_buf, read_off=w.read_off,
+                  batch_contig_begin=bcb, name_len=[len(x) for x in w.names]) as job:
+        try:
+            job.build_filters()
+            filt = [[job.get_filter(b, ki).copy() for ki in range(len(ks))] for b in range(len(bcb) - 1)]
+            cur = [contig(c) for c in range(w.n_contigs)]
+            for ki, k in enumerate(ks):
+                job.ntedit_pass(ki)
+                got = job.sequences()
+                for c in range(w.n_contigs):
+                    if cur[c] is None or len(cur[c]) < p.min_contig_len:
+                        cur[c] = None
+                        if got[c] is not None:
+                            return f"contig {c} should have been dropped at k index {ki}"
+                        continue
+                    q = O.ntedit_params(k, p.hash_num, max_insertions=p.max_insertions, max_deletions=p.max_deletions,
+                                        missing_ratio=p.missing_ratio, edit_ratio=p.edit_ratio, jump=p.jump,
+                                        mask=p.soft_mask, min_contig_len=p.min_contig_len)
+                    want, _ = O.ntedit(cur[c], filt[batch_of[c]][ki], k, p.hash_num, q)
+                    if got[c] != want:
+                        return f"ntedit mismatch contig {c} k {k}"
+                    cur[c] = want
+            job.mask()
+            m = job.sequences()
+            for c in range(w.n_contigs):
+                if cur[c] is not None and m[c] != O.mask(cur[c], ks[0]):
+                    return f"mask mismatch contig {c}"
+            job.sealer()
+            sq = job.sequences()
+            for c in range(w.n_contigs):
+                if m[c] is None:
+                    continue
+                want, _ = O.sealer(m[c], ks, filt[batch_of[c]], p.hash_num, max_paths=p.sealer_max_paths,
+                                   max_branches=p.sealer_max_branches, max_gap_len=p.sealer_max_gap,
+                                   max_cost=p.sealer_max_cost)
+                if sq[c] != want:
+                    return f"sealer mismatch contig {c}"
+        except core.GpError as e:
+            if e.code == -9:
+                return None  # a contig outgrew its slot: the step-wise calls report it (gp_job_polish retries)
+            raise
+    return None
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -98,7 +170,7 @@ def main():
         for seed in range(first, first + n):
             for mode in ("0", "1"):
                 try:
-                    err = run_case(core, ctx, O, seed, mode)
+                    err = run_case(core, ctx, O, seed, mode) or run_staged(core, ctx, O, seed, mode)
                 except Exception as e:  # noqa: BLE001 -- a fuzz loop reports and goes on
                     err = f"exception {type(e).__name__}: {e}"
                 if err:
