@@ -63,7 +63,8 @@ def random_case(seed):
         bcb = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, size=2)]))
     else:
         bcb = [0, n]
-    extra = dict(missing_ratio=float(rng.choice([0.3, 0.5, 0.8])), edit_ratio=float(rng.choice([0.3, 0.5, 0.7])),
+    hash_num = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 8]))
+    extra = dict(hash_num=hash_num, missing_ratio=float(rng.choice([0.3, 0.5, 0.8])), edit_ratio=float(rng.choice([0.3, 0.5, 0.7])),
                  sealer_max_paths=int(rng.choice([1, 2, 10])), sealer_max_branches=int(rng.choice([10, 1000])))
     if rng.random() < 0.3:
         w.kmer_threshold[:] = int(rng.integers(4, 14))
@@ -84,7 +85,7 @@ def run_case(core, ctx, O, seed, local_mode):
     # the oracle's batch driver takes the same knobs under its own field names
     op = O.batch_params(k_values=tuple(ks), cbf_bytes=cbf, bf_bytes=bf, ntedit_x=extra["missing_ratio"],
                         ntedit_y=extra["edit_ratio"], sealer_P=extra["sealer_max_paths"],
-                        sealer_B=extra["sealer_max_branches"])
+                        sealer_B=extra["sealer_max_branches"], hash_num=extra["hash_num"])
     for b in range(len(bcb) - 1):
         cs = list(range(bcb[b], bcb[b + 1]))
         if not cs:
@@ -110,7 +111,7 @@ def run_staged(core, ctx, O, seed, local_mode):
               soft_mask=int(rng.integers(0, 2)), min_contig_len=int(rng.choice([100, 50, 500])))
     se = dict(sealer_max_paths=extra["sealer_max_paths"], sealer_max_branches=extra["sealer_max_branches"],
               sealer_max_gap=int(rng.choice([30, 800])), sealer_max_cost=int(rng.choice([300, 100000])))
-    p = core.default_params(k_values=ks, cbf_bytes=cbf, bf_bytes=bf, **nt, **se)
+    p = core.default_params(k_values=ks, cbf_bytes=cbf, bf_bytes=bf, hash_num=extra["hash_num"], **nt, **se)
     contig = lambda c: bytes(w.contig_buf[int(w.contig_off[c]):int(w.contig_off[c + 1])])
     batch_of = {c: b for b in range(len(bcb) - 1) for c in range(bcb[b], bcb[b + 1])}
     with core.Job(ctx, p, contig_buf=w.contig_buf, contig_off=w.contig_off, contig_read_begin=w.contig_read_begin,
