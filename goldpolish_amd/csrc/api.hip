@@ -352,7 +352,6 @@ void gp_job_destroy(gp_job* job)
     job->t_bfs.destroy();
     job->t_mask.destroy();
     job->t_upper.destroy();
-    job->t_reset.destroy();
     delete job;
 }
 
@@ -545,8 +544,6 @@ int gp_job_kernel_time(gp_job* job, const char* kernel, double* total_ms, uint64
         t = &job->t_mask;
     else if (!std::strcmp(kernel, "upper"))
         t = &job->t_upper;
-    else if (!std::strcmp(kernel, "reset_guard"))
-        t = &job->t_reset;
     if (!t) {
         set_error("gp_job_kernel_time: unknown kernel name");
         return GP_ERR_INVALID_ARG;

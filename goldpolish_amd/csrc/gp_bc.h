@@ -43,7 +43,7 @@ struct StageBC {
 
 // tile-parallel helpers of stage_b.hip that stage C reuses
 int launch_classify(gp_job* job);
-int launch_copy_flagged(gp_job* job, uint32_t reject);
+int launch_copy_flagged(gp_job* job, uint32_t reject, uint32_t min_len = 0);
 int stage_c_prepare(gp_job* job);
 void stage_c_release(gp_job* job);
 

@@ -130,7 +130,7 @@ struct gp_job {
     gp::StageBC* bc = nullptr;
     uint32_t bc_slack = 1; // sequence slots hold len + (len/2 + 4 KiB) * bc_slack bytes
 
-    gp::KernelTimer t_first_pass, t_round, t_local, t_scan, t_walk, t_bfs, t_mask, t_upper, t_reset;
+    gp::KernelTimer t_first_pass, t_round, t_local, t_scan, t_walk, t_bfs, t_mask, t_upper;
     gp_counters counters{};
     bool filters_ready = false;
 };

@@ -37,10 +37,11 @@
 namespace gp {
 
 constexpr int kWalkThreads = 256;
+constexpr int kCacheWords = 64;                 // 4096 contig positions of both bitmaps ...
+constexpr int kCacheBases = kCacheWords * 64 + 256; // ... and their bases plus one site window
 constexpr int kMatTile = 4096; // bytes per workgroup in the tile-parallel copy kernels
 constexpr int kMaxK = 64;
 constexpr int kZMax = 2 * kMaxK + 16 + kWalkThreads; // window chars in LDS
-constexpr int kMaxCand = 341 + 16;
 
 struct WalkArgs {
     uint8_t* seq;            // current sequences (mutated in place)
@@ -129,23 +130,27 @@ struct Shared {
     int32_t request;
     uint32_t nz;              // chars available in Z
     uint32_t scan_j0, scan_n; // first k-mer index / number of k-mers of the scan
-    uint32_t scan_found;
     uint32_t draft;
     uint32_t n_sub;
     uint8_t subs[4];
     uint32_t sub_in_bf[4], sub_present[4];
     uint32_t confirm_missing, confirm_bad;
     uint32_t num_del;
-    uint32_t sweep_index_char, sweep_del_from;
     uint32_t best_key;        // (support << 16) | order, reduced with atomicMax
     unsigned long long st_scan, st_sites, st_probes, st_edits;
     uint8_t Z[kZMax];
+    // window of the contig the head is in, kept in LDS while everything right of the head is
+    // untouched: the two bitmaps thread 0 scans and the bases a site's window is cut from
+    unsigned long long c_site[kCacheWords], c_ok[kCacheWords];
+    uint64_t cw0;             // first bitmap word in the cache (absolute index)
+    uint32_t cwn;             // words in the cache
+    uint32_t cp0, cpn;        // contig positions [cp0, cp0 + cpn) held in c_seq
+    alignas(16) uint8_t c_seq[kCacheBases];
     uint64_t scan_fh[kWalkThreads], scan_rh[kWalkThreads];
     uint32_t wave_min[kWalkThreads / 64];
-    uint8_t cand_sup[kMaxCand];
 };
 
-enum { REQ_DONE = 0, REQ_SCAN, REQ_SITE, REQ_NEXT, REQ_BITSCAN };
+enum { REQ_DONE = 0, REQ_SCAN, REQ_SITE, REQ_NEXT, REQ_BITSCAN, REQ_REFILL };
 
 __device__ inline uint64_t roll_f(const HashTab& t, uint64_t fh, uint8_t out, uint8_t in)
 {
@@ -240,6 +245,14 @@ __device__ inline Node nd_cached(const Ctx& c, Shared& S, uint32_t i)
 }
 
 __device__ inline void nd_cache_drop(Shared& S) { S.nc_idx[0] = S.nc_idx[1] = 0xFFFFFFFEu; }
+
+// thread 0's writes into the contig go to memory and to the LDS copy of that stretch
+__device__ inline void seq_store(const Ctx& c, Shared& S, uint32_t pos, uint8_t v)
+{
+    c.seq[pos] = v;
+    if (pos - S.cp0 < S.cpn)
+        S.c_seq[pos - S.cp0] = v;
+}
 
 // inverse of sroln
 __device__ inline uint64_t srorn(uint64_t x, uint32_t n)
@@ -544,7 +557,7 @@ __device__ void make_edit(const Ctx& c, Shared& S, uint8_t draft, Best& b)
     switch (b.type) {
     case 1:
         if (tnode.type == 0)
-            c.seq[S.ti] = b.sub_base;
+            seq_store(c, S, S.ti, b.sub_base);
         else if (tnode.type == 1)
             c.nd[S.tn].c = b.sub_base;
         changelast(ht, S.fh, S.rh, draft, b.sub_base);
@@ -616,7 +629,7 @@ __device__ void make_edit(const Ctx& c, Shared& S, uint8_t draft, Best& b)
         if (c.a->soft_mask) {
             uint8_t lo = to_lower(draft);
             if (tnode.type == 0)
-                c.seq[S.ti] = lo;
+                seq_store(c, S, S.ti, lo);
             else if (tnode.type == 1)
                 c.nd[S.tn].c = lo;
             changelast(ht, S.fh, S.rh, draft, lo);
@@ -834,6 +847,10 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
         S.fast_head = 0;
         S.confirmed = 0;
         S.nc_next = 0;
+        S.cw0 = 0;
+        S.cwn = 0;
+        S.cp0 = 0;
+        S.cpn = 0;
         nd_cache_drop(S);
         if (hi + k - 1 < len) {
             hash_kmer(S.ht, c.seq + hi, k, S.fh, S.rh);
@@ -867,9 +884,26 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                 const uint64_t base_bit = a.off[cid];
                 uint32_t words_left = 16;
                 int32_t next_req = REQ_DONE;
+                // bitmap words from the LDS window when they are there
+                auto site_w = [&](uint64_t w) -> unsigned long long {
+                    const uint64_t i = w - S.cw0;
+                    return i < S.cwn ? S.c_site[i] : a.bm_site[w];
+                };
+                auto ok_w = [&](uint64_t w) -> unsigned long long {
+                    const uint64_t i = w - S.cw0;
+                    return i < S.cwn ? S.c_ok[i] : a.bm_ok[w];
+                };
+                if (p <= last_p && ((base_bit + p) >> 6) - S.cw0 + 3 >= (uint64_t)S.cwn &&
+                    S.cw0 + S.cwn <= ((base_bit + len - 1) >> 6)) {
+                    // the head is leaving the window (or there is none yet): every lane fetches the next
+                    S.bit_from = p;
+                    S.request = REQ_REFILL;
+                    p = last_p + 1; // skip the scan below; it resumes after the refill
+                    next_req = REQ_REFILL;
+                }
                 while (p <= last_p) {
                     const uint64_t bit = base_bit + p;
-                    unsigned long long w = a.bm_site[bit >> 6] & a.bm_ok[bit >> 6];
+                    unsigned long long w = site_w(bit >> 6) & ok_w(bit >> 6);
                     w &= ~0ULL << (bit & 63);
                     if (!w) {
                         const uint32_t np = (uint32_t)((((bit >> 6) + 1) << 6) - base_bit);
@@ -893,13 +927,13 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                     bool ok = (uint64_t)cand + 2ull * k <= len;
                     if (ok) {
                         const uint64_t b2 = base_bit + cand + k;
-                        ok = (a.bm_ok[b2 >> 6] >> (b2 & 63)) & 1ULL;
+                        ok = (ok_w(b2 >> 6) >> (b2 & 63)) & 1ULL;
                     }
                     uint32_t missing = 0;
                     if (ok) {
                         for (uint32_t q = 0; q < k; q += jump) {
                             const uint64_t b3 = base_bit + cand + 1 + q;
-                            missing += (uint32_t)((a.bm_site[b3 >> 6] >> (b3 & 63)) & 1ULL);
+                            missing += (uint32_t)((site_w(b3 >> 6) >> (b3 & 63)) & 1ULL);
                         }
                         S.st_probes += (k + jump - 1) / jump;
                     }
@@ -976,6 +1010,37 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
         const int req = S.request;
         if (req == REQ_DONE)
             break;
+
+        if (req == REQ_REFILL) {
+            // slide the LDS window to the word that holds position bit_from
+            const uint64_t base_bit = a.off[cid];
+            const uint64_t w0 = (base_bit + S.bit_from) >> 6, w_last = (base_bit + len - 1) >> 6;
+            const uint32_t nw = (uint32_t)min((uint64_t)kCacheWords, w_last - w0 + 1);
+            const uint32_t p0 = (uint32_t)((w0 << 6) - base_bit); // slots start on 1024-byte boundaries
+            const uint32_t nb = min((uint32_t)kCacheBases, len - p0);
+            for (uint32_t i = tid; i < nw; i += kWalkThreads) {
+                S.c_site[i] = a.bm_site[w0 + i];
+                S.c_ok[i] = a.bm_ok[w0 + i];
+            }
+            {
+                const uint4* src4 = reinterpret_cast<const uint4*>(c.seq + p0); // p0 is a multiple of 64
+                uint4* dst4 = reinterpret_cast<uint4*>(S.c_seq);
+                for (uint32_t i = tid; i < nb / 16; i += kWalkThreads)
+                    dst4[i] = src4[i];
+                for (uint32_t i = (nb / 16) * 16 + tid; i < nb; i += kWalkThreads)
+                    S.c_seq[i] = c.seq[p0 + i];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                S.cw0 = w0;
+                S.cwn = nw;
+                S.cp0 = p0;
+                S.cpn = nb;
+                S.request = REQ_NEXT;
+            }
+            __syncthreads();
+            continue;
+        }
 
         if (req == REQ_BITSCAN) {
             const uint32_t from = S.bit_from, last_p = len - k;
@@ -1095,8 +1160,10 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
         // flags are read once, here, by everybody; thread 0 only rewrites them behind barriers
         const uint32_t f_fast = S.fast_head, f_hash = S.need_hash, f_confirmed = S.confirmed;
         if (f_fast) {
-            for (uint32_t i = tid; i < S.nz; i += kWalkThreads)
-                S.Z[i] = c.seq[S.hi + i];
+            for (uint32_t i = tid; i < S.nz; i += kWalkThreads) {
+                const uint32_t pos = S.hi + i;
+                S.Z[i] = pos - S.cp0 < S.cpn ? S.c_seq[pos - S.cp0] : c.seq[pos];
+            }
             __syncthreads();
         }
         {
@@ -1246,7 +1313,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                 // trial + revert leaves the UPPER-case draft base behind (:1608-1615)
                 Node tnode = nd_cached(c, S, S.tn);
                 if (tnode.type == 0) {
-                    c.seq[S.ti] = (uint8_t)S.draft;
+                    seq_store(c, S, S.ti, (uint8_t)S.draft);
                 } else if (tnode.type == 1) {
                     c.nd[S.tn].c = S.draft;
                     nd_cache_drop(S);
@@ -2005,7 +2072,6 @@ int stage_b_reset(gp_job* job)
     job->t_mask.reset();
     job->t_upper.reset();
     job->t_bfs.reset();
-    job->t_reset.reset();
     return GP_OK;
 }
 
@@ -2027,7 +2093,7 @@ static int pull_stats(gp_job* job)
     int rc;
     if ((rc = job->t_walk.collect()) != GP_OK || (rc = job->t_scan.collect()) != GP_OK ||
         (rc = job->t_mask.collect()) != GP_OK || (rc = job->t_upper.collect()) != GP_OK ||
-        (rc = job->t_bfs.collect()) != GP_OK || (rc = job->t_reset.collect()) != GP_OK)
+        (rc = job->t_bfs.collect()) != GP_OK)
         return rc;
     if (err & (1u | 1024u | 512u)) {
         set_error("a contig outgrew its device slot (code " + std::to_string(err) +
@@ -2140,18 +2206,9 @@ int stage_mask(gp_job* job)
     int rc = job->t_mask.begin(s, job->n_contigs);
     if (rc != GP_OK)
         return rc;
-    GP_HIP(hipMemsetAsync(b->flags.p, 0, job->n_contigs * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(classify_kernel, dim3(b->n_tiles), dim3(256), 0, s,
-                       (const uint8_t*)b->seq[b->cur].p, (const uint64_t*)b->off.p,
-                       (const uint32_t*)b->len[b->cur].p, (const uint8_t*)b->dropped.p,
-                       (const uint32_t*)b->tile_contig.p, (const uint32_t*)b->tile_first.p,
-                       b->flags.p);
-    hipLaunchKernelGGL(copy_flagged, dim3(b->n_tiles), dim3(256), 0, s,
-                       (const uint8_t*)b->seq[b->cur].p, b->seq[b->cur ^ 1].p,
-                       (const uint64_t*)b->off.p, (const uint32_t*)b->len[b->cur].p,
-                       b->len[b->cur ^ 1].p, (const uint8_t*)b->dropped.p,
-                       (const uint32_t*)b->tile_contig.p, (const uint32_t*)b->tile_first.p,
-                       (const uint32_t*)b->flags.p, 1u, job->prm.k[0]);
+    // contigs without anything to mask are copied tile-parallel; the rest go through the FSM
+    if ((rc = launch_classify(job)) != GP_OK || (rc = launch_copy_flagged(job, 1u, job->prm.k[0])) != GP_OK)
+        return rc;
     hipLaunchKernelGGL(mask_kernel, dim3(job->n_contigs), dim3(kMaskThreads), 0, s,
                        (const uint8_t*)b->seq[b->cur].p, (const uint64_t*)b->off.p,
                        (const uint32_t*)b->len[b->cur].p, b->seq[b->cur ^ 1].p,
@@ -2178,7 +2235,7 @@ int launch_classify(gp_job* job)
     return GP_OK;
 }
 
-int launch_copy_flagged(gp_job* job, uint32_t reject)
+int launch_copy_flagged(gp_job* job, uint32_t reject, uint32_t min_len)
 {
     StageBC* b = job->bc;
     hipStream_t s = job->ctx->stream;
@@ -2187,7 +2244,7 @@ int launch_copy_flagged(gp_job* job, uint32_t reject)
                        (const uint64_t*)b->off.p, (const uint32_t*)b->len[b->cur].p,
                        b->len[b->cur ^ 1].p, (const uint8_t*)b->dropped.p,
                        (const uint32_t*)b->tile_contig.p, (const uint32_t*)b->tile_first.p,
-                       (const uint32_t*)b->flags.p, reject, 0u);
+                       (const uint32_t*)b->flags.p, reject, min_len);
     GP_HIP(hipGetLastError());
     return GP_OK;
 }

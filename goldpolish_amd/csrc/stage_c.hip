@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(64) void sealer_consensus(CArgs a)
 // --------------------------------------------------------------- splicing
 constexpr int kApplyThreads = 256;
 
-__global__ __launch_bounds__(kApplyThreads) void apply_fills(CArgs a, uint64_t slot_cap_unused)
+__global__ __launch_bounds__(kApplyThreads) void apply_fills(CArgs a)
 {
     const uint32_t cid = blockIdx.x, tid = threadIdx.x;
     if (a.dropped[cid] || !(a.flags[cid] & 2u))
@@ -1396,8 +1396,7 @@ int stage_c_run(gp_job* job)
         hipLaunchKernelGGL(sealer_connect, dim3(kWorkers), dim3(64), 0, s, a);
         hipLaunchKernelGGL(sealer_consensus, dim3(kNwWorkers), dim3(64), 0, s, a);
     }
-    hipLaunchKernelGGL(apply_fills, dim3(job->n_contigs), dim3(kApplyThreads), 0, s, a,
-                       (uint64_t)0);
+    hipLaunchKernelGGL(apply_fills, dim3(job->n_contigs), dim3(kApplyThreads), 0, s, a);
     GP_HIP(hipGetLastError());
     if ((rc = job->t_bfs.end(s)) != GP_OK)
         return rc;
