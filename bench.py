@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--workload", default="config2")
     ap.add_argument("--no-aux", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl",
+                    help="gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -140,18 +142,20 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the polishing core has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % torch.cuda.device_count()   # == local_rank on a full node
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        dist.init_process_group(args.backend)
+    on_gpu = args.backend == "nccl"
     from goldpolish_amd import core
 
     def run(kind, steps, warmup, want_roofline):
         w, ks = make_workload(kind, seed=2 + rank)
         params = core.default_params(k_values=ks)
-        ctx = core.Context(local_rank)
+        ctx = core.Context(device_index)
         job = core.Job.from_workload(ctx, params, w)
 
         def step():
@@ -162,6 +166,8 @@ def main():
                 lens_t = torch.from_numpy(lens.astype(np.int64)).cuda()
                 payload = torch.empty(max(int(lens.sum()), 1), dtype=torch.uint8, device="cuda")
                 job.sequences_into_device(payload.data_ptr(), payload.numel())
+                if not on_gpu:   # rehearsal: the same exchange over host memory
+                    lens_t, payload = lens_t.cpu(), payload.cpu()
                 gather_to_rank0(lens_t, payload[:int(lens.sum())], rank, world)
 
         for _ in range(warmup):
@@ -177,7 +183,7 @@ def main():
             dist.barrier()
         dt = time.perf_counter() - t0
         if dist:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         res = {"bp_per_rank": w.total_bp, "dt": dt, "steps": steps, "counters": job.counters(),
