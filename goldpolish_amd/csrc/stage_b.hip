@@ -2090,6 +2090,13 @@ static int pull_stats(gp_job* job)
     job->counters.c_gaps = st[4];
     job->counters.c_closed = st[5];
     job->counters.c_vertex_tests = st[6];
+    job->counters.c_no_start_goal = st[7];
+    job->counters.c_no_path = st[8];
+    job->counters.c_unique_path = st[9];
+    job->counters.c_multiple_paths = st[10];
+    job->counters.c_too_many_paths = st[11];
+    job->counters.c_too_many_branches = st[12];
+    job->counters.c_max_cost = st[13];
     int rc;
     if ((rc = job->t_walk.collect()) != GP_OK || (rc = job->t_scan.collect()) != GP_OK ||
         (rc = job->t_mask.collect()) != GP_OK || (rc = job->t_upper.collect()) != GP_OK ||

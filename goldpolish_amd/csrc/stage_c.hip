@@ -143,7 +143,8 @@ struct CArgs {
     int32_t* nw;
     uint32_t* epoch;
     uint32_t* err;
-    unsigned long long* stats; // [4] gaps [5] closed [6] vertex tests
+    unsigned long long* stats; // [4] gaps [5] closed [6] vertex tests [7] no start/goal [8] no path [9] unique
+                               // [10] multiple [11] too many paths [12] too many branches [13] max cost
     const uint32_t* flags;     // classify_kernel: bit 1 = the contig holds a gap character
 };
 
@@ -853,8 +854,10 @@ __device__ void connect_one(const CArgs& a, Search& S, uint32_t it, uint32_t wid
     const Flank f = flank_of(a, gi);
     const uint32_t k = a.k;
     const uint32_t l1 = f.le - f.ls, l2 = f.re - f.rs;
-    if (l1 < k || l2 < k)
+    if (l1 < k || l2 < k) {
+        atomicAdd(&a.stats[7], 1ull); // a flank shorter than k: "No start/goal kmer"
         return;
+    }
     const uint8_t* s = a.seq + a.off[g.contig];
     for (uint32_t i = 0; i < l1; i++)
         r1[i] = up(s[f.ls + i]);
@@ -879,6 +882,7 @@ __device__ void connect_one(const CArgs& a, Search& S, uint32_t it, uint32_t wid
         (void)start_kmer_pos(S, r2, l2, 3); // the reference evaluates both (probe count)
     if (sp == kNoMatch || gp == kNoMatch) {
         atomicAdd(&a.stats[6], S.tests);
+        atomicAdd(&a.stats[7], 1ull);
         return;
     }
     // ---- set the search up in this worker's arena
@@ -941,8 +945,15 @@ __device__ void connect_one(const CArgs& a, Search& S, uint32_t it, uint32_t wid
     atomicAdd(&a.stats[6], S.tests);
     if (S.overflow)
         atomicOr(a.err, 64u);
-    if (rc != R_FOUND)
+    // the reference's per-k log lines (sealer.cpp:656-683), summed over the k runs
+    if (rc != R_FOUND) {
+        const int slot = rc == R_NO_PATH ? 8 : rc == R_TOO_MANY_PATHS ? 11 : rc == R_TOO_MANY_BRANCHES ? 12
+                         : rc == R_MAX_COST ? 13 : -1;
+        if (slot >= 0)
+            atomicAdd(&a.stats[slot], 1ull);
         return;
+    }
+    atomicAdd(&a.stats[S.found_n == 1 ? 9 : 10], 1ull);
     // closing removes every gap that shares this left flank from the later k runs
     atomicMin(&a.closed_at[g.left_rep], a.ki + 1);
     atomicAdd(&a.stats[5], 1ull);

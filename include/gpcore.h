@@ -114,6 +114,14 @@ typedef struct gp_counters {
     uint64_t c_closed;       /* gaps closed */
     uint64_t c_vertex_tests; /* k-mer membership tests during BFS */
     uint64_t a_reservations; /* device-scope atomics spent on reservations (grid-wide schedule) */
+    /* Sealer's per-k log lines (subprojects/sealer/sealer.cpp:656-683), summed over the k runs */
+    uint64_t c_no_start_goal;     /* "No start/goal kmer" */
+    uint64_t c_no_path;           /* "No path" */
+    uint64_t c_unique_path;       /* "Unique path" */
+    uint64_t c_multiple_paths;    /* "Multiple paths" */
+    uint64_t c_too_many_paths;    /* "Too many paths" */
+    uint64_t c_too_many_branches; /* "Too many branches" */
+    uint64_t c_max_cost;          /* "Max cost exceeded" */
 } gp_counters;
 
 /* ---- library / context ------------------------------------------------- */

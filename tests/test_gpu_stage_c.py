@@ -43,7 +43,16 @@ def _sealer_check(core, ctx, oracle, seqs, filters_per_contig, params):
                                      max_cost=p.sealer_max_cost, max_gap_len=p.sealer_max_gap)
             assert got[i] == want, (i, len(got[i]), len(want))
             stats.append(st)
-        return job.counters(), stats
+        # Sealer's log lines (sealer.cpp:656-683) as counters, summed over contigs and k runs
+        c = job.counters()
+        for dev, orc in (("c_gaps", "gaps_found"), ("c_closed", "gaps_closed"),
+                         ("c_no_start_goal", "no_start_goal"), ("c_no_path", "no_path"),
+                         ("c_unique_path", "unique_path"), ("c_multiple_paths", "multiple_paths"),
+                         ("c_too_many_paths", "too_many_paths"),
+                         ("c_too_many_branches", "too_many_branches"),
+                         ("c_max_cost", "max_cost_exceeded"), ("c_vertex_tests", "vertex_tests")):
+            assert c[dev] == sum(getattr(st, orc) for st in stats), (dev, c[dev])
+        return c, stats
     finally:
         job.close()
 
