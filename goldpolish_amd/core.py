@@ -23,7 +23,7 @@ u64p = C.POINTER(C.c_uint64)
 
 # every symbol include/gpcore.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "gp_last_error", "gp_version", "gp_default_params", "gp_ctx_create", "gp_ctx_destroy",
+    "gp_last_error", "gp_version", "gp_device_bytes_in_use", "gp_default_params", "gp_ctx_create", "gp_ctx_destroy",
     "gp_ctx_stream", "gp_kmer_threshold", "gp_rank_reads", "gp_job_create", "gp_job_destroy",
     "gp_job_polish", "gp_job_build_filters", "gp_job_ntedit_pass", "gp_job_ntedit_guard",
     "gp_job_mask", "gp_job_sealer", "gp_job_upper", "gp_job_sync", "gp_job_get_filter",
@@ -109,6 +109,7 @@ def load_library(path=None):
     L = C.CDLL(str(path))
     L.gp_last_error.restype = C.c_char_p
     L.gp_version.restype = C.c_int
+    L.gp_device_bytes_in_use.restype = C.c_uint64
     L.gp_default_params.argtypes = [C.POINTER(Params)]
     L.gp_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.gp_ctx_destroy.argtypes = [C.c_void_p]
@@ -182,6 +183,10 @@ def default_params(k_values=None, **kw) -> Params:
     for a, b in kw.items():
         setattr(p, a, b)
     return p
+
+
+def device_bytes_in_use() -> int:
+    return int(lib().gp_device_bytes_in_use())
 
 
 def kmer_threshold(bases: int) -> int:

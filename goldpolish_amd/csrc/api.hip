@@ -3,6 +3,7 @@
 #include "gp_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -12,6 +13,9 @@
 namespace gp {
 
 static thread_local std::string g_err;
+
+static std::atomic<long long> g_device_bytes{0};
+void track_device_bytes(long long delta) { g_device_bytes += delta; }
 
 void set_error(const std::string& msg) { g_err = msg; }
 
@@ -31,6 +35,12 @@ extern "C" {
 const char* gp_last_error(void) { return g_err.c_str(); }
 
 int gp_version(void) { return 100; }
+
+uint64_t gp_device_bytes_in_use(void)
+{
+    const long long v = g_device_bytes.load();
+    return v > 0 ? (uint64_t)v : 0;
+}
 
 void gp_default_params(gp_params* p)
 {

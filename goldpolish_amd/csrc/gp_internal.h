@@ -13,6 +13,7 @@
 namespace gp {
 
 void set_error(const std::string& msg);
+void track_device_bytes(long long delta); // bytes this library holds on devices (gp_device_bytes_in_use)
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 #define GP_HIP(call)                                                    \
@@ -39,12 +40,15 @@ struct DevBuf {
             return GP_ERR_OOM;
         }
         n = count;
+        track_device_bytes((long long)(count * sizeof(T)));
         return GP_OK;
     }
     void release()
     {
-        if (p)
+        if (p) {
             (void)hipFree(p);
+            track_device_bytes(-(long long)(n * sizeof(T)));
+        }
         p = nullptr;
         n = 0;
     }

@@ -127,6 +127,10 @@ typedef struct gp_counters {
 /* ---- library / context ------------------------------------------------- */
 const char* gp_last_error(void);
 int gp_version(void);
+/* Device memory (bytes, all devices) this library holds right now: lets a caller size its jobs.
+ * A job needs about n_batches * n_k * (cbf_bytes + bf_bytes) for the filters, 30 bytes per contig
+ * base and 1 byte per read base, plus 13 GiB of Sealer search arenas per job with run_sealer. */
+uint64_t gp_device_bytes_in_use(void);
 void gp_default_params(gp_params* p);
 int gp_ctx_create(int device, gp_ctx** out);
 void gp_ctx_destroy(gp_ctx* ctx);

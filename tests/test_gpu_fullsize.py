@@ -187,3 +187,19 @@ def test_a_thousand_short_contigs_whole_path(gp, oracle):
         outs, _, _ = oracle.polish_batch([w.names[i]], [w.contig(i)], [w.reads_of(i)],
                                          [int(w.kmer_threshold[i])], op)
         assert got[i] == outs[0], i
+
+
+def test_device_memory_is_accounted_and_released(gp):
+    """gp_device_bytes_in_use follows job creation, the capacity retry and destruction (no leak)"""
+    core, ctx = gp
+    base = core.device_bytes_in_use()
+    w = synth.make_workload([20_000, 8_000], 20, seed=5)
+    p = core.default_params()
+    with core.Job.from_workload(ctx, p, w) as job:
+        held = core.device_bytes_in_use() - base
+        filters = 2 * p.n_k * (p.cbf_bytes + p.bf_bytes)
+        assert held > filters + 12 * (1 << 30)          # filters + the Sealer's search arenas
+        assert held < filters + 16 * (1 << 30)
+        job.polish()
+        assert core.device_bytes_in_use() - base >= held
+    assert core.device_bytes_in_use() == base
