@@ -63,6 +63,20 @@ def random_case(seed):
         bcb = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, size=2)]))
     else:
         bcb = [0, n]
+    if rng.random() < 0.4 and w.read_buf.size > 200:
+        # reads are not clean either: N runs, lower-case stretches, IUPAC letters
+        rb = w.read_buf.copy()
+        for _ in range(int(rng.integers(1, 12))):
+            s0 = int(rng.integers(0, rb.size - 60))
+            L = int(rng.integers(1, 60))
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                rb[s0:s0 + L] = ord("N")
+            elif kind == 1:
+                rb[s0:s0 + L] = np.frombuffer(bytes(rb[s0:s0 + L]).lower(), dtype=np.uint8)
+            else:
+                rb[s0] = ord(rng.choice(list("RYKMSWnacgt")))
+        w.read_buf = rb
     hash_num = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 8]))
     extra = dict(hash_num=hash_num, missing_ratio=float(rng.choice([0.3, 0.5, 0.8])), edit_ratio=float(rng.choice([0.3, 0.5, 0.7])),
                  sealer_max_paths=int(rng.choice([1, 2, 10])), sealer_max_branches=int(rng.choice([10, 1000])))
