@@ -29,6 +29,7 @@ struct StageBC {
     DevBuf<unsigned long long> stats; // b_scan_kmers, b_sites, b_probes, b_edits, c_*
     DevBuf<uint8_t> batch_skip;
     DevBuf<unsigned long long> bm_site, bm_ok; // stage B bitmaps, one bit per slot position
+    DevBuf<uint4> site_rec;    // one SiteRec (16 B) per slot position, see ntedit_site_eval; empty = disabled
     DevBuf<uint32_t> n_nodes;           // [n_contigs]
     DevBuf<uint32_t> flags;             // [n_contigs] classify_kernel: 1 = not plain ACGT, 2 = has a gap char
     DevBuf<uint32_t> tile_contig, tile_first; // output tiles of materialize_kernel

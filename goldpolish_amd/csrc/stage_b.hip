@@ -43,6 +43,8 @@ constexpr int kMatTile = 4096; // bytes per workgroup in the tile-parallel copy 
 constexpr int kMaxK = 64;
 constexpr int kZMax = 2 * kMaxK + 16 + kWalkThreads; // window chars in LDS
 
+struct SiteRec;
+
 struct WalkArgs {
     uint8_t* seq;            // current sequences (mutated in place)
     uint8_t* out;            // next sequences
@@ -63,6 +65,7 @@ struct WalkArgs {
     const unsigned long long* bm_site; // bit (off[c] + p): k-mer at p is absent from the filter
     const unsigned long long* bm_ok;   // bit (off[c] + p): bases p .. p+k-1 are all accepted
     uint32_t* n_nodes;                 // live nodes per contig after the walk
+    SiteRec* site_rec;                 // [slot position] what the trials at a confirmed site decide (or null)
     uint32_t* err;
     unsigned long long* stats;
 };
@@ -150,7 +153,18 @@ struct Shared {
     uint32_t wave_min[kWalkThreads / 64];
 };
 
-enum { REQ_DONE = 0, REQ_SCAN, REQ_SITE, REQ_NEXT, REQ_BITSCAN, REQ_REFILL };
+enum { REQ_DONE = 0, REQ_SCAN, REQ_SITE, REQ_NEXT, REQ_BITSCAN, REQ_REFILL, REQ_SWEEP };
+
+// What the trials at one confirmed site decide, worked out ahead of the walk for every site of
+// the untouched contig (ntedit_site_eval); the walk only consumes it (16 bytes per slot position).
+struct SiteRec {
+    uint8_t type;      // Best::type: 0 nothing, 1 substitution, 2 insertion, 3 deletion
+    uint8_t sub_base;
+    uint8_t indel_len;
+    uint8_t flags;     // bit 0: record valid; bit 1: some substitute's k-mer was in the filter (trial + revert happened)
+    uint8_t indel[8];
+    uint32_t probes;   // filter look-ups the trials made
+};
 
 __device__ inline uint64_t roll_f(const HashTab& t, uint64_t fh, uint8_t out, uint8_t in)
 {
@@ -769,6 +783,255 @@ __device__ void indel_sweep(const Ctx& c, Shared& S, uint8_t index_char, uint32_
     atomicAdd(&S.st_probes, (unsigned long long)probes);
 }
 
+// ---- every site of the untouched contig, ahead of the walk.
+// While everything right of the walker's head is untouched contig ("clean"), what happens at a
+// confirmed site -- which substitute k-mers are in the filter, which substitution / insertion /
+// deletion wins -- depends on nothing but the 2k+12 bases from the site on and the filter.  Only
+// about one site in a hundred ends in an edit, so instead of making the serial walk stop at each
+// one (ten barrier-separated phases, three dependent memory round trips), every workgroup of
+// this kernel takes 256 positions, finds the confirmed sites among them from the two bitmaps
+// exactly as the walk does, runs the trials of each (same code path as REQ_SITE: prefix-XOR
+// window hashes, one substitute per wave, the insertion / deletion sweep) and leaves a 16-byte
+// record.  The walk then only reads records; sites it reaches in a stretch that an edit has
+// touched are still worked out on the spot.  Case changes that trials leave behind (a reverted
+// trial writes the draft base back in upper case, soft masking lower-cases it) do not change
+// any hash, so records stay valid.
+constexpr int kEvalTile = 256;
+
+__global__ __launch_bounds__(kWalkThreads, 6) void ntedit_site_eval(WalkArgs a, const uint32_t* tile_contig,
+                                                                const uint32_t* tile_first)
+{
+    __shared__ Shared S;
+    __shared__ uint32_t s_cand[kEvalTile], s_n;
+    const uint32_t tid = threadIdx.x;
+    // the tile tables are per 4096-position tile (kMatTile); this kernel cuts them in 16
+    const uint32_t big = blockIdx.x / (kMatTile / kEvalTile), sub = blockIdx.x % (kMatTile / kEvalTile);
+    const uint32_t cid = tile_contig[big];
+    if (a.dropped[cid])
+        return;
+    const uint32_t len = a.len_cur[cid];
+    const uint32_t k = a.k, jump = a.jump;
+    if (len < a.min_contig_len || len < 2 * k)
+        return;
+    const uint32_t p0 = (big - tile_first[cid]) * kMatTile + sub * kEvalTile;
+    if (p0 + k > len)
+        return;
+    const uint64_t base_bit = a.off[cid];
+    Ctx c;
+    c.a = &a;
+    c.seq = a.seq + a.off[cid];
+    c.nd = nullptr;
+    c.node_cap = 0;
+    c.bf = a.bf + ((uint64_t)a.contig_batch[cid] * a.n_k + a.ki) * a.bf_words;
+    c.len = len;
+    c.k = k;
+    if (tid == 0) {
+        for (uint32_t code = 0; code < 5; code++) {
+            uint64_t sd = code < 4 ? seed_of_code(code) : 0ULL;
+            S.ht.f[code] = sd;
+            S.ht.r[code] = sd;
+            S.ht.fk[code] = sroln(sd, k);
+            S.ht.rk[code] = sroln(sd, k);
+        }
+        s_n = 0;
+        S.st_probes = 0;
+    }
+    __syncthreads();
+    {
+        // confirmed site at p (ntedit.cpp:1487-1523, from the bitmaps as the walk does it)
+        const uint32_t p = p0 + tid;
+        bool cand = false;
+        if (p + k <= len) {
+            const uint64_t bit = base_bit + p;
+            cand = ((a.bm_site[bit >> 6] & a.bm_ok[bit >> 6]) >> (bit & 63)) & 1ULL;
+            cand = cand && (uint64_t)p + 2ull * k <= len;
+            if (cand) {
+                const uint64_t b2 = bit + k;
+                cand = (a.bm_ok[b2 >> 6] >> (b2 & 63)) & 1ULL;
+            }
+            if (cand) {
+                uint32_t missing = 0;
+                for (uint32_t q = 0; q < k; q += jump) {
+                    const uint64_t b3 = bit + 1 + q;
+                    missing += (uint32_t)((a.bm_site[b3 >> 6] >> (b3 & 63)) & 1ULL);
+                }
+                cand = missing >= a.need_missing;
+            }
+        }
+        if (cand)
+            s_cand[atomicAdd(&s_n, 1u)] = p;
+    }
+    __syncthreads();
+    const uint32_t n_cand = s_n;
+    for (uint32_t ci = 0; ci < n_cand; ci++) {
+        const uint32_t cand = s_cand[ci];
+        __syncthreads();
+        if (tid == 0) {
+            S.hi = cand;
+            S.ti = cand + k - 1;
+            S.nz = min(2 * k + 12, len - cand);
+            S.best_key = 0;
+            S.st_probes = 0;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < S.nz; i += kWalkThreads)
+            S.Z[i] = c.seq[cand + i];
+        __syncthreads();
+        {
+            const uint32_t nzz = S.nz;
+            uint64_t tf = 0, tr = 0;
+            if (tid < nzz) {
+                tf = srorn(S.ht.f[fcode(S.Z[tid])], tid);
+                tr = sroln(S.ht.r[rcode(S.Z[tid])], tid);
+            }
+            const int lane = tid & 63, wave = tid >> 6;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint64_t uf = __shfl_up(tf, o), ur = __shfl_up(tr, o);
+                if (lane >= o) {
+                    tf ^= uf;
+                    tr ^= ur;
+                }
+            }
+            if (lane == 63) {
+                S.wave_f[wave] = tf;
+                S.wave_r[wave] = tr;
+            }
+            __syncthreads();
+            uint64_t pf = 0, pr = 0;
+            for (int w = 0; w < wave; w++) {
+                pf ^= S.wave_f[w];
+                pr ^= S.wave_r[w];
+            }
+            if (tid < nzz) {
+                S.PF[tid + 1] = tf ^ pf;
+                S.QR[tid + 1] = tr ^ pr;
+            }
+            if (tid == 0) {
+                S.PF[0] = 0;
+                S.QR[0] = 0;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                S.fh = win_f(S, 0, k);
+                S.rh = win_r(S, 0, k);
+                S.char_in = S.Z[k - 1];
+                S.draft = to_upper(S.Z[k - 1]);
+                const char* sb;
+                switch ((uint8_t)S.draft) {
+                case 'A': sb = "TCG"; break;
+                case 'T': sb = "ACG"; break;
+                case 'C': sb = "ATG"; break;
+                case 'G': sb = "ATC"; break;
+                case 'R': sb = "TC"; break;
+                case 'Y': sb = "AG"; break;
+                case 'S': sb = "AT"; break;
+                case 'W': sb = "CG"; break;
+                case 'K': sb = "AC"; break;
+                case 'M': sb = "TG"; break;
+                case 'B': sb = "A"; break;
+                case 'D': sb = "C"; break;
+                case 'H': sb = "G"; break;
+                case 'V': sb = "T"; break;
+                default: sb = ""; break;
+                }
+                uint32_t n = 0;
+                for (; sb[n]; n++)
+                    S.subs[n] = (uint8_t)sb[n];
+                S.n_sub = n;
+                for (uint32_t i = 0; i < 4; i++)
+                    S.sub_in_bf[i] = S.sub_present[i] = 0;
+                S.num_del = 1;
+            }
+            __syncthreads();
+        }
+        {
+            const uint32_t si = tid >> 6, q = tid & 63;
+            if (si < S.n_sub) {
+                const uint8_t sb = S.subs[si];
+                if (q == 63) {
+                    uint64_t fh = S.fh, rh = S.rh;
+                    changelast(S.ht, fh, rh, (uint8_t)S.draft, sb);
+                    if (bf_contains(a, c.bf, fh + rh))
+                        S.sub_in_bf[si] = 1;
+                } else if (q < k && q % jump == 0 && k + q < S.nz) {
+                    const uint32_t a0 = q + 1, site = k - 1;
+                    uint64_t f = win_f(S, a0, k), r = win_r(S, a0, k);
+                    if (a0 <= site) {
+                        const uint8_t old_c = S.Z[site];
+                        f ^= sroln(S.ht.f[fcode(old_c)] ^ S.ht.f[fcode(sb)], (a0 + k - 1) - site);
+                        r ^= sroln(S.ht.r[rcode(old_c)] ^ S.ht.r[rcode(sb)], site - a0);
+                    }
+                    if (bf_contains(a, c.bf, f + r))
+                        atomicAdd(&S.sub_present[si], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        Best best;
+        best.type = 0;
+        best.sup = 0;
+        best.sub_base = 0;
+        best.indel_len = 0;
+        uint32_t any_in_bf = 0;
+        for (uint32_t si = 0; si < S.n_sub; si++) {
+            if (!S.sub_in_bf[si])
+                continue;
+            any_in_bf = 1;
+            if (tid == 0)
+                S.st_probes += 1 + (k + jump - 1) / jump;
+            const uint32_t present = S.sub_present[si];
+            if (present >= a.need_edit) {
+                if (present >= best.sup) {
+                    best.type = 1;
+                    best.sub_base = S.subs[si];
+                    best.sup = present;
+                }
+                continue;
+            }
+            if (best.type != 1) {
+                __syncthreads();
+                if (tid == 0)
+                    S.best_key = 0;
+                __syncthreads();
+                indel_sweep(c, S, S.subs[si], S.num_del);
+                __syncthreads();
+                const uint32_t key = S.best_key;
+                uint32_t n_del = (a.max_ins_tries > 0 && S.num_del <= a.max_del)
+                                     ? min(a.max_del - S.num_del + 1, a.max_ins_tries)
+                                     : 0u;
+                const uint32_t del_from = S.num_del;
+                __syncthreads();
+                if (tid == 0)
+                    S.num_del = del_from + n_del;
+                if (key) {
+                    const uint32_t order = key & 0xFFFF;
+                    best.sup = key >> 16;
+                    if (order & 1) {
+                        best.type = 3;
+                        best.indel_len = del_from + (order >> 1);
+                    } else {
+                        best.type = 2;
+                        best.indel_len = indel_string(S.subs[si], order >> 1, best.indel);
+                    }
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            SiteRec r;
+            r.type = (uint8_t)best.type;
+            r.sub_base = best.sub_base;
+            r.indel_len = (uint8_t)best.indel_len;
+            r.flags = (uint8_t)(1u | (any_in_bf << 1));
+            for (int i = 0; i < 8; i++)
+                r.indel[i] = (best.type == 2 && (uint32_t)i < best.indel_len) ? best.indel[i] : 0;
+            r.probes = (uint32_t)S.st_probes;
+            a.site_rec[base_bit + cand] = r;
+        }
+    }
+}
+
 // kMinWaves: 1 = as many registers as the compiler likes (136: three workgroups per CU, the
 // fastest single walk); 6 = 80 registers (six per CU; some spills).  With thousands of contigs
 // the walk is throughput-bound on resident workgroups and the tight build is 17 % faster; with a
@@ -875,7 +1138,12 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             Node tnode = nd_cached(c, S, S.tn);
             const bool plain = tnode.type == 0 && tnode.e == len - 1 && S.ti <= tnode.e;
             const bool clean = plain && S.hn == S.tn && S.hi >= S.clean_from && a.bm_site != nullptr;
-            if (clean) {
+            if (clean && a.site_rec != nullptr) {
+                // everything from the head on is untouched contig and every site there has its
+                // record: all lanes sweep forward to the first site that ends in an edit
+                S.bit_from = S.hi + (S.cur_tested ? 1u : 0u);
+                S.request = REQ_SWEEP;
+            } else if (clean) {
                 // everything from the head on is untouched contig: the precomputed bitmaps
                 // say where the next testable, absent k-mer starts AND whether the k k-mers
                 // after it confirm it, so unconfirmed candidates cost no barrier at all
@@ -1010,6 +1278,112 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
         const int req = S.request;
         if (req == REQ_DONE)
             break;
+
+        if (req == REQ_SWEEP) {
+            // 256 positions at a time: which are confirmed sites (bitmaps), what do their records
+            // say?  Sites where the trials change nothing only leave counters and a case change
+            // behind (a reverted trial writes the draft base back in upper case, soft masking
+            // lower-cases it), all independent of each other, so every lane settles its own; the
+            // first site that ends in an edit stops the sweep and thread 0 applies it.
+            const uint32_t last_p = len - k, p_start = S.bit_from;
+            const uint64_t base_bit = a.off[cid];
+            uint32_t p = p_start, first = 0xFFFFFFFFu;
+            uint32_t my_sites = 0;
+            unsigned long long my_probes = 0;
+            while (p <= last_p) {
+                const uint32_t pos = p + tid;
+                bool cand = false, looked = false;
+                if (pos <= last_p && (uint64_t)pos + 2ull * k <= len) {
+                    const uint64_t bit = base_bit + pos;
+                    cand = ((a.bm_site[bit >> 6] & a.bm_ok[bit >> 6]) >> (bit & 63)) & 1ULL;
+                    if (cand) {
+                        const uint64_t b2 = bit + k;
+                        cand = (a.bm_ok[b2 >> 6] >> (b2 & 63)) & 1ULL;
+                    }
+                    if (cand) {
+                        looked = true; // the reference makes its confirm look-ups here
+                        uint32_t missing = 0;
+                        for (uint32_t q = 0; q < k; q += jump) {
+                            const uint64_t b3 = bit + 1 + q;
+                            missing += (uint32_t)((a.bm_site[b3 >> 6] >> (b3 & 63)) & 1ULL);
+                        }
+                        cand = missing >= a.need_missing;
+                    }
+                }
+                SiteRec r;
+                r.flags = 0;
+                r.type = 0;
+                r.probes = 0;
+                if (cand)
+                    r = a.site_rec[base_bit + pos];
+                const bool stop = cand && (!(r.flags & 1u) || r.type != 0);
+                first = block_min(S, stop ? pos : 0xFFFFFFFFu);
+                if (looked && pos <= first)
+                    my_probes += (k + jump - 1) / jump;
+                if (cand && pos < first) {
+                    my_sites++;
+                    my_probes += r.probes;
+                    const uint32_t ti = pos + k - 1;
+                    const uint8_t draft = to_upper(c.seq[ti]);
+                    if (a.soft_mask)
+                        seq_store(c, S, ti, to_lower(draft));
+                    else if (r.flags & 2u)
+                        seq_store(c, S, ti, draft);
+                }
+                if (first != 0xFFFFFFFFu)
+                    break;
+                p += kWalkThreads;
+            }
+            if (my_sites)
+                atomicAdd(&S.st_sites, (unsigned long long)my_sites);
+            if (my_probes)
+                atomicAdd(&S.st_probes, my_probes);
+            __syncthreads();
+            if (tid == 0) {
+                if (first == 0xFFFFFFFFu) {
+                    if (p_start <= last_p)
+                        S.st_scan += last_p + 1 - p_start;
+                    S.request = REQ_DONE; // nothing left that the reference could act on
+                } else {
+                    S.st_scan += first - p_start + 1;
+                    const SiteRec r = a.site_rec[base_bit + first];
+                    const uint32_t ti = first + k - 1;
+                    S.hi = first;
+                    S.ti = ti;
+                    S.cur_tested = 1;
+                    S.min_tested_ti = 0;
+                    if (!(r.flags & 1u)) {
+                        // no record (cannot happen while the contig is as the pass found it):
+                        // work the site out on the spot
+                        S.need_hash = 1;
+                        S.confirmed = 1;
+                        S.request = REQ_SITE;
+                    } else {
+                        const uint8_t raw = c.seq[ti], draft = to_upper(raw);
+                        S.st_sites++;
+                        S.st_probes += r.probes;
+                        if (r.flags & 2u)
+                            seq_store(c, S, ti, draft); // trial + revert leaves the upper-case draft base
+                        S.need_hash = 0;
+                        S.confirmed = 0;
+                        hash_kmer(S.ht, c.seq + first, k, S.fh, S.rh);
+                        S.char_in = raw;
+                        S.draft = draft;
+                        Best b;
+                        b.type = r.type;
+                        b.sub_base = r.sub_base;
+                        b.indel_len = r.indel_len;
+                        b.sup = 0;
+                        for (int i = 0; i < 8; i++)
+                            b.indel[i] = r.indel[i];
+                        make_edit(c, S, draft, b);
+                        S.request = REQ_NEXT;
+                    }
+                }
+            }
+            __syncthreads();
+            continue;
+        }
 
         if (req == REQ_REFILL) {
             // slide the LDS window to the word that holds position bit_from
@@ -2000,6 +2374,8 @@ int stage_bc_prepare(gp_job* job)
         (rc = b->batch_skip.alloc(job->n_batches)) != GP_OK ||
         (rc = b->bm_site.alloc(off / 64 + 64)) != GP_OK ||
         (rc = b->bm_ok.alloc(off / 64 + 64)) != GP_OK || (rc = b->n_nodes.alloc(n)) != GP_OK ||
+        (getenv("GP_NTEDIT_SPECULATE") && getenv("GP_NTEDIT_SPECULATE")[0] == '0'
+             ? GP_OK : (rc = b->site_rec.alloc(off + 64))) != GP_OK ||
         (rc = b->tile_first.alloc((size_t)n + 1)) != GP_OK || (rc = b->flags.alloc(n)) != GP_OK)
         return rc;
     {
@@ -2154,6 +2530,7 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     a.bm_site = b->bm_site.p;
     a.bm_ok = b->bm_ok.p;
     a.n_nodes = b->n_nodes.p;
+    a.site_rec = b->site_rec.n ? reinterpret_cast<SiteRec*>(b->site_rec.p) : nullptr;
     hipStream_t s = job->ctx->stream;
     // 1. membership bitmap of the pass's input, every CU
     int rc = job->t_scan.begin(s, b->total_slots);
@@ -2162,6 +2539,13 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     hipLaunchKernelGGL(ntedit_scan, dim3((unsigned)((b->total_slots + kScanTile - 1) / kScanTile)),
                        dim3(256), 0, s, a, job->n_contigs, b->bm_site.p, b->bm_ok.p);
     GP_HIP(hipGetLastError());
+    if (a.site_rec) {
+        // 1b. what the trials decide at every confirmed site of the untouched contigs
+        GP_HIP(hipMemsetAsync(b->site_rec.p, 0, b->site_rec.n * sizeof(uint4), s));
+        hipLaunchKernelGGL(ntedit_site_eval, dim3(b->n_tiles * (kMatTile / kEvalTile)), dim3(kWalkThreads), 0, s,
+                           a, (const uint32_t*)b->tile_contig.p, (const uint32_t*)b->tile_first.p);
+        GP_HIP(hipGetLastError());
+    }
     if ((rc = job->t_scan.end(s)) != GP_OK)
         return rc;
     // 2. the ordered walk, one workgroup per contig; 3. copy the edited contigs out
