@@ -858,8 +858,51 @@ __global__ __launch_bounds__(kWalkThreads, 6) void ntedit_site_eval(WalkArgs a, 
                 cand = missing >= a.need_missing;
             }
         }
-        if (cand)
-            s_cand[atomicAdd(&s_n, 1u)] = p;
+        if (cand) {
+            // first look, one lane per site: is any substitute's k-mer in the filter at all?  If
+            // not, the trials end right there (no look-up is counted, nothing is edited, no trial
+            // is reverted) -- the fate of nearly every site when the filter is not crowded.
+            uint64_t fh, rh;
+            hash_kmer(S.ht, c.seq + p, k, fh, rh);
+            const uint8_t draft = to_upper(c.seq[p + k - 1]);
+            const char* sb;
+            switch (draft) {
+            case 'A': sb = "TCG"; break;
+            case 'T': sb = "ACG"; break;
+            case 'C': sb = "ATG"; break;
+            case 'G': sb = "ATC"; break;
+            case 'R': sb = "TC"; break;
+            case 'Y': sb = "AG"; break;
+            case 'S': sb = "AT"; break;
+            case 'W': sb = "CG"; break;
+            case 'K': sb = "AC"; break;
+            case 'M': sb = "TG"; break;
+            case 'B': sb = "A"; break;
+            case 'D': sb = "C"; break;
+            case 'H': sb = "G"; break;
+            case 'V': sb = "T"; break;
+            default: sb = ""; break;
+            }
+            bool any = false;
+            for (uint32_t i = 0; sb[i]; i++) {
+                uint64_t f2 = fh, r2 = rh;
+                changelast(S.ht, f2, r2, draft, (uint8_t)sb[i]);
+                any |= bf_contains(a, c.bf, f2 + r2);
+            }
+            if (any) {
+                s_cand[atomicAdd(&s_n, 1u)] = p; // the full trials below
+            } else {
+                SiteRec r;
+                r.type = 0;
+                r.sub_base = 0;
+                r.indel_len = 0;
+                r.flags = 1;
+                for (int i = 0; i < 8; i++)
+                    r.indel[i] = 0;
+                r.probes = 0;
+                a.site_rec[base_bit + p] = r;
+            }
+        }
     }
     __syncthreads();
     const uint32_t n_cand = s_n;
