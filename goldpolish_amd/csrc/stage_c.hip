@@ -42,12 +42,17 @@ constexpr uint32_t kVertCap = 1u << 17;     // <= max_cost + 2 vertices per sear
 constexpr uint32_t kEdgeCap = 2u * kVertCap + 64;
 constexpr uint32_t kMaxPathsDev = 16;
 constexpr uint32_t kPathCap = 1024;          // vertices per stored path
+// lane-per-gap first attempt: a small private arena per lane; what outgrows it, or finds paths
+// to enumerate, is done again by the one-gap-per-wave workers with their big arenas
+constexpr uint32_t kSmallSlotBits = 8, kSmallVerts = 96, kSmallEdges = 256;
+constexpr uint32_t kSimtWaves = 2048;   // waves of the lane-per-gap kernel ...
+constexpr uint32_t kSimtLanes = 16;     // ... and the lanes of each that take a gap (divergent walks serialise)
 constexpr uint32_t kNwMax = 1800;            // longest sequence the consensus aligner takes
 constexpr int kWorkers = 1024;
 constexpr int kNwWorkers = 16;
 
 enum { FWD = 0, REV = 1 };
-enum { R_FOUND = 0, R_TOO_MANY_PATHS, R_TOO_MANY_BRANCHES, R_CYCLE, R_MAX_COST, R_MEM, R_NO_PATH };
+enum { R_FOUND = 0, R_TOO_MANY_PATHS, R_TOO_MANY_BRANCHES, R_CYCLE, R_MAX_COST, R_MEM, R_NO_PATH, R_DEFER };
 enum { V_SUCCESS = 0, V_SKIP, V_ABORT };
 
 struct Gap {
@@ -87,6 +92,8 @@ struct CState {
     DevBuf<uint32_t> fill_len;     // [G] 0 = not closed
     DevBuf<uint32_t> table_left, table_pair; // exact hash sets, value = gap index + 1
     DevBuf<uint32_t> work;         // valid gaps
+    DevBuf<uint32_t> defer;        // gaps left for the one-per-wave workers
+    DevBuf<uint8_t> small;         // kSimtWaves x kSimtLanes lane arenas (SmallArena)
     DevBuf<uint32_t> queue;        // [0] work count [1] head [2] multi count [3] multi head
     DevBuf<uint8_t> pool;          // fills and connecting sequences
     DevBuf<unsigned long long> pool_head;
@@ -130,6 +137,7 @@ struct CArgs {
     uint32_t* table_pair;
     uint32_t table_bits;
     uint32_t* work;
+    uint32_t* defer;     // gaps phase 1 (lane per gap) left for phase 2, count in queue[4]
     uint32_t* queue;
     uint8_t* pool;
     unsigned long long* pool_head;
@@ -357,6 +365,8 @@ struct Search {
     SeedTab st;
     uint32_t* slots;
     uint32_t epoch;
+    uint32_t slot_bits, vert_cap, edge_cap; // of the arena in use (a worker's big one or a lane's small one)
+    bool small;                              // lane-per-gap attempt: no room for path enumeration
     Vert* v;
     Edge* e;
     uint32_t nv, ne;
@@ -476,13 +486,14 @@ __device__ inline uint64_t mix_km(uint64_t a, uint64_t b)
 
 __device__ uint32_t vert_get(Search& S, const uint64_t km[2], uint64_t fh, uint64_t rh)
 {
-    uint32_t slot = (uint32_t)(mix_km(km[0], km[1]) >> 40) & (kSlots - 1);
-    const uint32_t tag = S.epoch << kSlotBits;
+    const uint32_t n_slots = 1u << S.slot_bits;
+    uint32_t slot = (uint32_t)(mix_km(km[0], km[1]) >> 40) & (n_slots - 1);
+    const uint32_t tag = S.epoch << S.slot_bits;
     for (;;) {
         uint32_t sv = S.slots[slot];
-        if ((sv & ~(kSlots - 1)) != tag || sv == 0) {
+        if ((sv & ~(n_slots - 1)) != tag || sv == 0) {
             // empty for this search
-            if (S.nv >= kVertCap - 1) {
+            if (S.nv >= S.vert_cap - 1) {
                 S.overflow = true;
                 return 0;
             }
@@ -499,10 +510,10 @@ __device__ uint32_t vert_get(Search& S, const uint64_t km[2], uint64_t fh, uint6
             S.slots[slot] = tag | (id + 1);
             return id;
         }
-        uint32_t id = (sv & (kSlots - 1)) - 1;
+        uint32_t id = (sv & (n_slots - 1)) - 1;
         if (S.v[id].km[0] == km[0] && S.v[id].km[1] == km[1])
             return id;
-        slot = (slot + 1) & (kSlots - 1);
+        slot = (slot + 1) & (n_slots - 1);
     }
 }
 
@@ -513,7 +524,7 @@ __device__ void hist_add_edge(Search& S, int gi, uint32_t u, uint32_t v)
     for (uint32_t e = U.head[gi]; e != 0xFFFFFFFFu; e = S.e[e].next)
         if (S.e[e].to == v)
             return;
-    if (S.ne >= kEdgeCap) {
+    if (S.ne >= S.edge_cap) {
         S.overflow = true;
         return;
     }
@@ -769,6 +780,8 @@ __device__ int bidi_search(Search& S)
         else if (dir == FWD && S.qh[REV] < S.qt[REV])
             dir = REV;
     }
+    if (S.small && S.overflow)
+        return R_MEM; // the small arena ran out: whatever else was flagged is not final
     if (S.too_many_paths)
         return R_TOO_MANY_PATHS;
     if (S.too_many_branches)
@@ -777,6 +790,8 @@ __device__ int bidi_search(Search& S)
         return R_MAX_COST;
     if (S.overflow)
         return R_MEM;
+    if (S.small && (S.found_n || S.n_ce))
+        return R_DEFER; // paths to enumerate: that needs a worker's scratch
     int overall = S.found_n ? R_FOUND : R_NO_PATH;
     for (uint32_t i = 0; i < S.n_ce; i++) {
         int rc = build_paths_edge(S, S.ce_u[i], S.ce_v[i]);
@@ -843,20 +858,29 @@ __device__ void write_merged(const CArgs& a, uint32_t gi, const uint8_t* r1, uin
     a.fill_len[gi] = lm;
 }
 
-__device__ void connect_one(const CArgs& a, Search& S, uint32_t it, uint32_t wid, uint8_t* r1,
-                            uint8_t* r2, uint8_t* tmp)
+struct SmallArena {
+    Vert v[kSmallVerts];
+    Edge e[kSmallEdges];
+    uint32_t slots[1u << kSmallSlotBits];
+    uint32_t q[2][kSmallVerts];
+};
+
+// One gap at one k.  `sm` != null: lane-per-gap attempt in that lane's small arena; returns true
+// when the gap has to be done again by a worker (arena too small, or paths to enumerate) --
+// nothing of such an attempt is counted or written.
+__device__ bool connect_one(const CArgs& a, Search& S, uint32_t gi, uint32_t wid, uint8_t* r1,
+                            uint8_t* r2, uint8_t* tmp, SmallArena* sm)
 {
-    const uint32_t gi = a.work[it];
     const Gap g = a.gaps[gi];
     // still in `flanks`?  (last gap of its flank pair, left flank not closed at a larger k)
     if (a.pair_last[g.pair_rep] != gi + 1 || a.closed_at[g.left_rep] <= a.ki)
-        return;
+        return false;
     const Flank f = flank_of(a, gi);
     const uint32_t k = a.k;
     const uint32_t l1 = f.le - f.ls, l2 = f.re - f.rs;
     if (l1 < k || l2 < k) {
         atomicAdd(&a.stats[7], 1ull); // a flank shorter than k: "No start/goal kmer"
-        return;
+        return false;
     }
     const uint8_t* s = a.seq + a.off[g.contig];
     for (uint32_t i = 0; i < l1; i++)
@@ -883,28 +907,48 @@ __device__ void connect_one(const CArgs& a, Search& S, uint32_t it, uint32_t wid
     if (sp == kNoMatch || gp == kNoMatch) {
         atomicAdd(&a.stats[6], S.tests);
         atomicAdd(&a.stats[7], 1ull);
-        return;
+        return false;
     }
-    // ---- set the search up in this worker's arena
-    uint32_t ep = a.epoch[wid] + 1;
-    S.slots = a.slots + (uint64_t)wid * kSlots;
-    if (ep >= (1u << (32 - kSlotBits))) {
-        for (uint32_t i = 0; i < kSlots; i++)
-            S.slots[i] = 0;
-        ep = 1;
+    S.small = sm != nullptr;
+    if (sm) {
+        // ---- lane-private small arena
+        for (uint32_t i = 0; i < (1u << kSmallSlotBits); i++)
+            sm->slots[i] = 0;
+        S.slots = sm->slots;
+        S.epoch = 1;
+        S.slot_bits = kSmallSlotBits;
+        S.vert_cap = kSmallVerts;
+        S.edge_cap = kSmallEdges;
+        S.v = sm->v;
+        S.e = sm->e;
+        S.q[0] = sm->q[0];
+        S.q[1] = sm->q[1];
+        S.dfs_path = S.dfs_it = S.left = S.right = S.found = nullptr;
+    } else {
+        // ---- this worker's arena
+        uint32_t ep = a.epoch[wid] + 1;
+        S.slots = a.slots + (uint64_t)wid * kSlots;
+        if (ep >= (1u << (32 - kSlotBits))) {
+            for (uint32_t i = 0; i < kSlots; i++)
+                S.slots[i] = 0;
+            ep = 1;
+        }
+        a.epoch[wid] = ep;
+        S.epoch = ep;
+        S.slot_bits = kSlotBits;
+        S.vert_cap = kVertCap;
+        S.edge_cap = kEdgeCap;
+        S.v = a.verts + (uint64_t)wid * kVertCap;
+        S.e = a.edges + (uint64_t)wid * kEdgeCap;
+        uint32_t* sc = a.scratch + (uint64_t)wid * kScratchWords;
+        S.q[0] = sc;
+        S.q[1] = sc + kVertCap;
+        S.dfs_path = sc + 2 * kVertCap;
+        S.dfs_it = S.dfs_path + 2 * kPathCap;
+        S.left = S.dfs_it + 2 * kPathCap;
+        S.right = S.left + kMaxPathsDev * kPathCap;
+        S.found = S.right + kMaxPathsDev * kPathCap;
     }
-    a.epoch[wid] = ep;
-    S.epoch = ep;
-    S.v = a.verts + (uint64_t)wid * kVertCap;
-    S.e = a.edges + (uint64_t)wid * kEdgeCap;
-    uint32_t* sc = a.scratch + (uint64_t)wid * kScratchWords;
-    S.q[0] = sc;
-    S.q[1] = sc + kVertCap;
-    S.dfs_path = sc + 2 * kVertCap;
-    S.dfs_it = S.dfs_path + 2 * kPathCap;
-    S.left = S.dfs_it + 2 * kPathCap;
-    S.right = S.left + kMaxPathsDev * kPathCap;
-    S.found = S.right + kMaxPathsDev * kPathCap;
     S.nv = S.ne = 0;
     S.qh[0] = S.qh[1] = S.qt[0] = S.qt[1] = 0;
     S.left_n = S.right_n = S.found_n = 0;
@@ -936,12 +980,18 @@ __device__ void connect_one(const CArgs& a, Search& S, uint32_t it, uint32_t wid
     const uint16_t md = (uint16_t)(S.max_len - 1);
     S.max_depth[FWD] = (uint16_t)(md / 2 + md % 2);
     S.max_depth[REV] = (uint16_t)(md / 2);
+    if (S.overflow)
+        return true; // (small arena) not even the two end vertices fitted
     if (S.start == S.goal && 1 >= S.min_len) {
+        if (sm)
+            return true; // a path already: a worker's business
         S.found[0] = S.start;
         S.found_len[0] = 1;
         S.found_n = 1;
     }
     const int rc = bidi_search(S);
+    if (sm && (rc == R_DEFER || rc == R_MEM))
+        return true;
     atomicAdd(&a.stats[6], S.tests);
     if (S.overflow)
         atomicOr(a.err, 64u);
@@ -951,7 +1001,7 @@ __device__ void connect_one(const CArgs& a, Search& S, uint32_t it, uint32_t wid
                          : rc == R_MAX_COST ? 13 : -1;
         if (slot >= 0)
             atomicAdd(&a.stats[slot], 1ull);
-        return;
+        return false;
     }
     atomicAdd(&a.stats[S.found_n == 1 ? 9 : 10], 1ull);
     // closing removes every gap that shares this left flank from the later k runs
@@ -965,7 +1015,7 @@ __device__ void connect_one(const CArgs& a, Search& S, uint32_t it, uint32_t wid
         const uint32_t mi = atomicAdd(&a.queue[2], 1u);
         if (mi >= a.multi_cap) {
             atomicOr(a.err, 128u);
-            return;
+            return false;
         }
         MultiHdr& h = a.multi[mi];
         h.gap = gi;
@@ -982,26 +1032,55 @@ __device__ void connect_one(const CArgs& a, Search& S, uint32_t it, uint32_t wid
                     a.pool[at + i] = tmp[i];
         }
     }
+    return false;
 }
 
+// Phase 1: one gap per LANE.  A lane walks its gap's graph in a small arena of its own; the
+// sixty-four walks of a wave diverge freely (each is a handful of dependent look-ups, so there
+// is little to lose and a factor of tens in gaps in flight to gain).  What does not fit, or
+// finds paths to enumerate, goes on the list for phase 2.
+__global__ __launch_bounds__(64) void sealer_connect_lanes(CArgs a, SmallArena* arenas)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_work = a.queue[0];
+    SmallArena* mine = arenas + (uint64_t)blockIdx.x * kSimtLanes + (lane % kSimtLanes);
+    Search S;
+    uint8_t r1[64], r2[64];
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0)
+            base = atomicAdd(&a.queue[1], kSimtLanes);
+        base = __shfl(base, 0);
+        if (base >= n_work)
+            break; // every wave leaves here once the queue has drained
+        const uint32_t it = base + lane;
+        if (lane < kSimtLanes && it < n_work) {
+            const uint32_t gi = a.work[it];
+            if (connect_one(a, S, gi, 0, r1, r2, nullptr, mine))
+                a.defer[atomicAdd(&a.queue[4], 1u)] = gi;
+        }
+    }
+}
+
+// Phase 2: one gap per wave, lane 0 walking, with the worker's big arena: whatever phase 1 left
 __global__ __launch_bounds__(64) void sealer_connect(CArgs a)
 {
     __shared__ Search S;
     __shared__ uint8_t r1[64], r2[64], tmp[kPathCap + 64];
     __shared__ uint32_t item;
     const uint32_t wid = blockIdx.x, lane = threadIdx.x;
-    const uint32_t n_work = a.queue[0];
+    const uint32_t n_work = a.queue[4];
     for (;;) {
         if (lane == 0)
-            item = atomicAdd(&a.queue[1], 1u);
+            item = atomicAdd(&a.queue[5], 1u);
         __syncthreads();
         const uint32_t it = item;
         __syncthreads();
         if (it >= n_work)
-            break; // every wave leaves here once the queue has drained
+            break; // every wave leaves here once the list has drained
         // one lane walks the graph; the wave reconverges before the next fetch
         if (lane == 0)
-            connect_one(a, S, it, wid, r1, r2, tmp);
+            (void)connect_one(a, S, a.defer[it], wid, r1, r2, tmp, nullptr);
     }
 }
 
@@ -1307,6 +1386,8 @@ int stage_c_prepare(gp_job* job)
         (rc = c->closed_at.alloc(g)) != GP_OK || (rc = c->fill_off.alloc(g)) != GP_OK ||
         (rc = c->fill_len.alloc(g)) != GP_OK || (rc = c->table_left.alloc(1ull << tb)) != GP_OK ||
         (rc = c->table_pair.alloc(1ull << tb)) != GP_OK || (rc = c->work.alloc(g)) != GP_OK ||
+        (rc = c->defer.alloc(g)) != GP_OK ||
+        (rc = c->small.alloc((uint64_t)kSimtWaves * kSimtLanes * sizeof(SmallArena))) != GP_OK ||
         (rc = c->queue.alloc(8)) != GP_OK || (rc = c->pool.alloc(c->pool_cap)) != GP_OK ||
         (rc = c->pool_head.alloc(1)) != GP_OK || (rc = c->multi.alloc(c->multi_cap)) != GP_OK ||
         (rc = c->slots.alloc((uint64_t)kWorkers * kSlots)) != GP_OK ||
@@ -1370,6 +1451,7 @@ int stage_c_run(gp_job* job)
     a.table_pair = c->table_pair.p;
     a.table_bits = c->table_bits;
     a.work = c->work.p;
+    a.defer = c->defer.p;
     a.queue = c->queue.p;
     a.pool = c->pool.p;
     a.pool_head = c->pool_head.p;
@@ -1404,6 +1486,9 @@ int stage_c_run(gp_job* job)
         // queue heads back to 0, counts stay
         GP_HIP(hipMemsetAsync(c->queue.p + 1, 0, sizeof(uint32_t), s));
         GP_HIP(hipMemsetAsync(c->queue.p + 2, 0, 2 * sizeof(uint32_t), s));
+        GP_HIP(hipMemsetAsync(c->queue.p + 4, 0, 2 * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(sealer_connect_lanes, dim3(kSimtWaves), dim3(64), 0, s, a,
+                           reinterpret_cast<SmallArena*>(c->small.p));
         hipLaunchKernelGGL(sealer_connect, dim3(kWorkers), dim3(64), 0, s, a);
         hipLaunchKernelGGL(sealer_consensus, dim3(kNwWorkers), dim3(64), 0, s, a);
     }
