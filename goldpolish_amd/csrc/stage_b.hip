@@ -1334,6 +1334,34 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             uint32_t my_sites = 0;
             unsigned long long my_probes = 0;
             while (p <= last_p) {
+                {
+                    // nothing absent and testable in this chunk's words (every lane reads the same
+                    // few words, so this is uniform)?  Then fast-forward: one word per lane,
+                    // 16 k positions per step, to the next word that holds a bit.
+                    const uint64_t w_lo = (base_bit + p) >> 6, w_hi = (base_bit + min(p + kWalkThreads - 1, last_p)) >> 6;
+                    unsigned long long any = 0;
+                    for (uint64_t w = w_lo; w <= w_hi; w++)
+                        any |= a.bm_site[w] & a.bm_ok[w];
+                    if (!any) {
+                        const uint64_t w_last = (base_bit + last_p) >> 6;
+                        uint64_t w0 = w_hi + 1;
+                        uint32_t found = 0xFFFFFFFFu;
+                        while (w0 <= w_last && found == 0xFFFFFFFFu) {
+                            const uint64_t w = w0 + tid;
+                            uint32_t hit = 0xFFFFFFFFu;
+                            if (w <= w_last && (a.bm_site[w] & a.bm_ok[w]))
+                                hit = (uint32_t)(w - w_lo);
+                            found = block_min(S, hit);
+                            w0 += kWalkThreads;
+                        }
+                        if (found == 0xFFFFFFFFu) {
+                            p = last_p + 1; // ran off the end
+                            break;
+                        }
+                        p = (uint32_t)(((w_lo + found) << 6) - base_bit);
+                        continue;
+                    }
+                }
                 const uint32_t pos = p + tid;
                 bool cand = false, looked = false;
                 if (pos <= last_p && (uint64_t)pos + 2ull * k <= len) {
