@@ -1180,7 +1180,9 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
         if (tid == 0 && S.request == REQ_NEXT) {
             Node tnode = nd_cached(c, S, S.tn);
             const bool plain = tnode.type == 0 && tnode.e == len - 1 && S.ti <= tnode.e;
-            const bool clean = plain && S.hn == S.tn && S.hi >= S.clean_from && a.bm_site != nullptr;
+            // (the first k-mer looked at starts at hi, or at hi + 1 when the one at hi has been tested)
+            const bool clean = plain && S.hn == S.tn && S.hi + (S.cur_tested ? 1u : 0u) >= S.clean_from &&
+                               a.bm_site != nullptr;
             if (clean && a.site_rec != nullptr) {
                 // everything from the head on is untouched contig and every site there has its
                 // record: all lanes sweep forward to the first site that ends in an edit
@@ -1276,6 +1278,10 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                     uint32_t ahead = len - 1 - S.ti;
                     uint32_t j0 = S.cur_tested ? 1u : 0u;
                     uint32_t n = min((uint32_t)kWalkThreads, ahead + 1 - j0);
+                    // head and tail in the final run: k-mer j starts at contig position hi + j, and
+                    // from clean_from on the records answer -- hash only what an edit has touched
+                    if (S.hn == S.tn && S.clean_from > S.hi + j0 && a.site_rec != nullptr)
+                        n = min(n, S.clean_from - (S.hi + j0));
                     if (n == 0) {
                         S.request = REQ_DONE; // the next roll would fail: end of contig
                     } else {
