@@ -11,6 +11,15 @@ from test_gpu_stage_a import _custom_workload, oracle_filters
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["sites ahead of the walk", "every site on the spot"], autouse=True)
+def walk_mode(request, monkeypatch):
+    """both ways the walk gets a site's decision: from ntedit_site_eval's records (default) and
+    worked out on the spot at every site (GP_NTEDIT_SPECULATE=0)"""
+    if request.param == "every site on the spot":
+        monkeypatch.setenv("GP_NTEDIT_SPECULATE", "0")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def gp():
     from goldpolish_amd import core
