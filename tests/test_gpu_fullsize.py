@@ -203,3 +203,25 @@ def test_device_memory_is_accounted_and_released(gp):
         job.polish()
         assert core.device_bytes_in_use() - base >= held
     assert core.device_bytes_in_use() == base
+
+
+def test_sixty_contigs_of_25_kbp_whole_path(gp, oracle):
+    """The aux benchmark's regime at a size the oracle handles in seconds: 25 kbp contigs, 30x
+    reads, full cascade -- hundreds of edits and dozens of gaps per contig; every polished contig
+    and every filter against the oracle's batch driver."""
+    core, ctx = gp
+    w = synth.make_workload([25_000] * 60, 30, seed=404)
+    p = core.default_params()
+    with core.Job.from_workload(ctx, p, w) as job:
+        job.polish()
+        got = job.sequences()
+        c = job.counters()
+        filt = [job.get_filter(b, 3).copy() for b in (0, 17, 59)]
+    assert c["b_edits"] > 5000 and c["c_closed"] > 500
+    op = oracle.batch_params()
+    for i in range(w.n_contigs):
+        outs, _, bfs = oracle.polish_batch([w.names[i]], [w.contig(i)], [w.reads_of(i)],
+                                           [int(w.kmer_threshold[i])], op, want_bfs=True)
+        assert got[i] == outs[0], i
+        if i in (0, 17, 59):
+            assert np.array_equal(filt[(0, 17, 59).index(i)], bfs[3]), i
