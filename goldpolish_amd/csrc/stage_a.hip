@@ -1088,15 +1088,22 @@ int stage_a_run(gp_job* job)
                           hipMemcpyHostToDevice, s));
     a.batch_pos = job->d_batch_pos.p;
     // Which batches replay alone in a workgroup (cbf_local) and which go through the grid-wide
-    // reservation rounds?  A workgroup works a batch off tile after tile, about 15 us per 1024
-    // positions whatever else runs, so that pays when there are enough batches to fill the
-    // chip and none of them is long; a long contig's batch needs the whole chip on its one
-    // filter.  GP_STAGE_A_LOCAL: 0 never, 1 every batch, default by size.
+    // reservation rounds?  The local replay pays when there are enough batches to fill the chip
+    // and none of them is long; a long contig's batch needs the whole chip on its one filter.
+    // GP_STAGE_A_LOCAL: 0 never, 1 every batch, default by size.
     std::vector<uint32_t> order;
     uint32_t n_big = job->n_batches;
     {
-        const uint64_t local_max = env_u64("GP_STAGE_A_LOCAL_MAX", 3ull << 19); // positions per batch
+        // A workgroup replays its pair at about 15 us per 512-position tile when it has the memory
+        // system to itself; all of them together are bound by random line traffic, about 4.5 G
+        // operations/s.  A batch may go local as long as its own replay stays well inside the time
+        // the whole local set needs anyway (so that it is not the critical path), or is short.
         const uint64_t mode = p.hash_num <= 4 ? env_u64("GP_STAGE_A_LOCAL", 2) : 0; // the LDS table holds 4 touches per operation
+        uint64_t local_max = env_u64("GP_STAGE_A_LOCAL_MAX", 3ull << 19); // positions per batch
+        if (mode == 2) {
+            double t_all = (double)job->read_positions * p.n_k / 4.5e9;   // s, if every batch went local
+            local_max = std::max<uint64_t>(local_max, (uint64_t)(0.5 * t_all / 15e-6 * 512.0));
+        }
         std::vector<uint32_t> small;
         for (uint32_t bi = 0; bi < job->n_batches; bi++) {
             const uint64_t len = batch_pos[bi + 1] - batch_pos[bi];
