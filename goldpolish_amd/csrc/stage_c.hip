@@ -46,7 +46,7 @@ constexpr uint32_t kPathCap = 1024;          // vertices per stored path
 // to enumerate, is done again by the one-gap-per-wave workers with their big arenas
 constexpr uint32_t kSmallSlotBits = 8, kSmallVerts = 96, kSmallEdges = 256;
 constexpr uint32_t kSimtWaves = 2048;   // waves of the lane-per-gap kernel ...
-constexpr uint32_t kSimtLanes = 16;     // ... and the lanes of each that take a gap (divergent walks serialise)
+constexpr uint32_t kSimtLanes = 32;     // ... and the lanes of each that take a gap (divergent walks serialise)
 constexpr uint32_t kNwMax = 1800;            // longest sequence the consensus aligner takes
 constexpr int kWorkers = 1024;
 constexpr int kNwWorkers = 16;
