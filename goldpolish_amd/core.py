@@ -33,6 +33,7 @@ SYMBOLS = [
     "gp_seqindex_entry", "gp_seqindex_find", "gp_seqindex_read", "gp_seqindex_destroy",
     "gp_mappings_load", "gp_mappings_get", "gp_mappings_destroy", "gp_job_create_from_files",
     "gp_target_extract", "gp_target_update_paf", "gp_target_reinsert",
+    "gp_filter_save", "gp_filter_load",
 ]
 
 
@@ -155,6 +156,8 @@ def load_library(path=None):
     L.gp_target_extract.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p]
     L.gp_target_update_paf.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
     L.gp_target_reinsert.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    L.gp_filter_save.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64, u8p]
+    L.gp_filter_load.argtypes = [C.c_char_p, u32p, u32p, u64p, u8p, C.c_uint64]
     return L
 
 
@@ -231,6 +234,20 @@ def _arr(a, dtype):
 
 def _bytes(x):
     return x if isinstance(x, bytes) else str(x).encode()
+
+
+def filter_save(path, k, hash_num, data: np.ndarray):
+    d = _arr(data, np.uint8)
+    _check(lib().gp_filter_save(_bytes(path), k, hash_num, d.size, d.ctypes.data_as(u8p)))
+
+
+def filter_load(path):
+    """(k, hash_num, bytes as uint8 array)"""
+    k, h, n = C.c_uint32(), C.c_uint32(), C.c_uint64()
+    _check(lib().gp_filter_load(_bytes(path), C.byref(k), C.byref(h), C.byref(n), None, 0))
+    buf = np.zeros(max(n.value, 1), dtype=np.uint8)
+    _check(lib().gp_filter_load(_bytes(path), None, None, None, buf.ctypes.data_as(u8p), buf.size))
+    return k.value, h.value, buf[:n.value]
 
 
 def target_extract(fasta_path, out_path, flank=64, bed_path=None):

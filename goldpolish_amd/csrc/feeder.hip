@@ -467,6 +467,68 @@ int gp_mappings_get(gp_mappings* m, const char* target_id, uint64_t* n, const ch
 
 void gp_mappings_destroy(gp_mappings* m) { delete m; }
 
+/* bfs[i]->save("<batch>-k<k>.bf") / KmerBloomFilter(path), src/goldpolish_targeted_bfs.cpp:138-140 and
+ * subprojects/ntedit/ntedit.cpp:2013-2022 -- in this build's OWN container, not btllib's (that
+ * header cannot be pinned here): the line "GPBF1 <k> <hash_num> <bytes>\n", then the
+ * filter bytes (bit n -> byte n/8, mask 1 << n%8, the order btllib uses in memory). */
+int gp_filter_save(const char* path, uint32_t k, uint32_t hash_num, uint64_t bytes, const uint8_t* data)
+{
+    if (!path || !data)
+        return GP_ERR_INVALID_ARG;
+    FILE* f = std::fopen(path, "wb");
+    if (!f) {
+        set_error(std::string("cannot write ") + path);
+        return GP_ERR_INVALID_ARG;
+    }
+    std::fprintf(f, "GPBF1 %u %u %llu\n", k, hash_num, (unsigned long long)bytes);
+    const bool ok = std::fwrite(data, 1, bytes, f) == bytes;
+    std::fclose(f);
+    if (!ok) {
+        set_error(std::string("short write to ") + path);
+        return GP_ERR_INVALID_ARG;
+    }
+    return GP_OK;
+}
+
+int gp_filter_load(const char* path, uint32_t* k, uint32_t* hash_num, uint64_t* bytes, uint8_t* buf,
+                   uint64_t buf_bytes)
+{
+    if (!path)
+        return GP_ERR_INVALID_ARG;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) {
+        set_error(std::string("cannot open ") + path);
+        return GP_ERR_INVALID_ARG;
+    }
+    unsigned kk = 0, hh = 0;
+    unsigned long long bb = 0;
+    char magic[8] = { 0 };
+    if (std::fscanf(f, "%7s %u %u %llu", magic, &kk, &hh, &bb) != 4 || std::strcmp(magic, "GPBF1") != 0 ||
+        std::fgetc(f) != '\n') {
+        std::fclose(f);
+        set_error(std::string(path) + " is not a GPBF1 filter file (btllib's own .bf files are not read, see SURVEY 8f-1)");
+        return GP_ERR_UNSUPPORTED;
+    }
+    if (k)
+        *k = kk;
+    if (hash_num)
+        *hash_num = hh;
+    if (bytes)
+        *bytes = bb;
+    int rc = GP_OK;
+    if (buf) {
+        if (buf_bytes < bb) {
+            set_error("gp_filter_load: buffer too small");
+            rc = GP_ERR_INVALID_ARG;
+        } else if (std::fread(buf, 1, bb, f) != bb) {
+            set_error(std::string("short read from ") + path);
+            rc = GP_ERR_INVALID_ARG;
+        }
+    }
+    std::fclose(f);
+    return rc;
+}
+
 /* What serve_batch does before it fills the filters (src/goldpolish_targeted_bfs.cpp:86-131), for
  * every target of every batch, plus what scripts/goldpolish:344-355 does when it writes
  * batch.fa: the contig comes from the target file, its reads are the mapped reads ranked by

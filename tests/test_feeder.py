@@ -187,3 +187,17 @@ def test_job_from_files_equals_job_from_arrays(tmp_path):
                 assert b.sequences() == want
                 assert [b.get_filter(i, 0).tobytes() for i in range(3)] == want_f
     assert any(x is not None and x != w.contig(i) for i, x in enumerate(want))   # something was polished
+
+
+def test_filter_file_round_trip(tmp_path):
+    """the build's own filter container (GPBF1): what save()/load of a .bf does for the reference"""
+    core = _core()
+    rng = np.random.default_rng(9)
+    data = rng.integers(0, 256, size=4099, dtype=np.uint8)
+    core.filter_save(tmp_path / "b-k24.bf", 24, 4, data)
+    k, h, got = core.filter_load(tmp_path / "b-k24.bf")
+    assert (k, h) == (24, 4) and np.array_equal(got, data)
+    assert (tmp_path / "b-k24.bf").read_bytes().startswith(b"GPBF1 24 4 4099\n")
+    (tmp_path / "other.bf").write_bytes(b"[BTLKmerBloomFilter_v2]\nbytes = 4\n")
+    with pytest.raises(core.GpError):
+        core.filter_load(tmp_path / "other.bf")
