@@ -33,7 +33,7 @@ SYMBOLS = [
     "gp_seqindex_entry", "gp_seqindex_find", "gp_seqindex_read", "gp_seqindex_destroy",
     "gp_mappings_load", "gp_mappings_get", "gp_mappings_destroy", "gp_job_create_from_files",
     "gp_target_extract", "gp_target_update_paf", "gp_target_reinsert",
-    "gp_filter_save", "gp_filter_load",
+    "gp_filter_save", "gp_filter_load", "gp_job_write_fasta",
 ]
 
 
@@ -156,6 +156,7 @@ def load_library(path=None):
     L.gp_target_extract.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p]
     L.gp_target_update_paf.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
     L.gp_target_reinsert.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    L.gp_job_write_fasta.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_char_p, C.c_int]
     L.gp_filter_save.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64, u8p]
     L.gp_filter_load.argtypes = [C.c_char_p, u32p, u32p, u64p, u8p, C.c_uint64]
     return L
@@ -475,6 +476,12 @@ class Job:
     def sequences_into_device(self, device_ptr: int, nbytes: int):
         """Packs the surviving records at a device pointer on this job's GPU (no host hop)."""
         _check(lib().gp_job_get_sequences_device(self._h, C.c_void_p(device_ptr), nbytes))
+
+    def write_fasta(self, path, names=None, append=False):
+        arr = None
+        if names is not None:
+            arr = (C.c_char_p * max(len(names), 1))(*[_bytes(n) for n in names])
+        _check(lib().gp_job_write_fasta(self._h, arr, _bytes(path), int(append)))
 
     def counters(self) -> dict:
         c = Counters()

@@ -546,6 +546,7 @@ int gp_job_create_from_files(gp_ctx* ctx, const gp_params* params, const gp_seqi
     std::vector<uint64_t> contig_off(n_contigs + 1, 0), read_off(1, 0);
     std::vector<uint32_t> name_len(n_contigs), read_begin(n_contigs + 1, 0), thr(n_contigs);
     std::vector<uint8_t> contig_buf, read_buf;
+    std::vector<std::string> headers(n_contigs);
     for (uint32_t c = 0; c < n_contigs; c++) {
         const auto* t = targets->find(target_ids[c]);
         if (!t) {
@@ -565,6 +566,9 @@ int gp_job_create_from_files(gp_ctx* ctx, const gp_params* params, const gp_seqi
             while (hb > 0 && pread(targets->fd, &ch, 1, (off_t)(hb - 1)) == 1 && ch != '\n')
                 hb--;
             name_len[c] = nl > hb ? (uint32_t)(nl - hb - 1) : 0; // without the '>'
+            headers[c].resize(name_len[c]);
+            if (name_len[c] && read_exact(targets, hb + 1, name_len[c], (uint8_t*)&headers[c][0]) != GP_OK)
+                return GP_ERR_INVALID_ARG;
         }
         uint64_t n_ids = 0;
         const char* const* ids = nullptr;
@@ -608,7 +612,52 @@ int gp_job_create_from_files(gp_ctx* ctx, const gp_params* params, const gp_seqi
     bs.n_reads = (uint32_t)(read_off.size() - 1);
     bs.read_buf = read_buf.data();
     bs.read_off = read_off.data();
-    return gp_job_create(ctx, params, &bs, out);
+    const int rc_create = gp_job_create(ctx, params, &bs, out);
+    if (rc_create == GP_OK)
+        (*out)->headers = std::move(headers);
+    return rc_create;
+}
+
+/* The batch's final FASTA (scripts/goldpolish-make:46-47 `goldpolish-to-upper`, collected in input
+ * order by scripts/goldpolish-reaper:51-73): ">id[ comment]" and the polished sequence, records
+ * ntEdit dropped left out.  names == NULL: the header lines of the target file (jobs made by
+ * gp_job_create_from_files). */
+int gp_job_write_fasta(gp_job* job, const char* const* names, const char* path, int append)
+{
+    if (!job || !path)
+        return GP_ERR_INVALID_ARG;
+    if (!names && job->headers.size() != job->n_contigs) {
+        set_error("gp_job_write_fasta: names are needed for a job that was not made from files");
+        return GP_ERR_INVALID_ARG;
+    }
+    std::vector<uint64_t> lens(job->n_contigs ? job->n_contigs : 1);
+    std::vector<uint8_t> dropped(lens.size());
+    uint64_t total = 0;
+    int rc = gp_job_get_lengths(job, lens.data(), dropped.data(), &total);
+    if (rc != GP_OK)
+        return rc;
+    std::vector<uint8_t> buf(total ? total : 1);
+    if ((rc = gp_job_get_sequences(job, buf.data(), buf.size())) != GP_OK)
+        return rc;
+    FILE* f = std::fopen(path, append ? "ab" : "wb");
+    if (!f) {
+        set_error(std::string("cannot write ") + path);
+        return GP_ERR_INVALID_ARG;
+    }
+    uint64_t at = 0;
+    for (uint32_t c = 0; c < job->n_contigs; c++) {
+        if (dropped[c])
+            continue;
+        const char* nm = names ? names[c] : job->headers[c].c_str();
+        std::fputc('>', f);
+        std::fputs(nm, f);
+        std::fputc('\n', f);
+        std::fwrite(buf.data() + at, 1, lens[c], f);
+        std::fputc('\n', f);
+        at += lens[c];
+    }
+    std::fclose(f);
+    return GP_OK;
 }
 
 } // extern "C"

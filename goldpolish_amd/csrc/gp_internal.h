@@ -95,6 +95,7 @@ struct gp_job {
     gp_ctx* ctx = nullptr;
     gp_params prm{};
     uint32_t n_batches = 0, n_contigs = 0, n_reads = 0;
+    std::vector<std::string> headers;     // "id[ comment]" per contig when the job came from files
 
     // ---- inputs resident in HBM
     // reads: every read followed by one '\n' separator, in (batch, contig, rank)

@@ -181,6 +181,10 @@ int gp_job_get_sequences(gp_job* job, uint8_t* buf, uint64_t buf_bytes);
 /* Same bytes, written to a DEVICE pointer on the job's GPU (e.g. a buffer that goes
  * straight into an RCCL send): no host hop. */
 int gp_job_get_sequences_device(gp_job* job, void* device_buf, uint64_t buf_bytes);
+/* The job's final FASTA, records in input order, dropped ones left out (what
+ * scripts/goldpolish-reaper:51-73 collects).  names[c] = "id[ comment]"; NULL = the header lines of
+ * the target file for jobs made by gp_job_create_from_files.  append != 0 appends. */
+int gp_job_write_fasta(gp_job* job, const char* const* names, const char* path, int append);
 int gp_job_get_counters(gp_job* job, gp_counters* out);
 /* Average device time (ms) of the dominant stage-A kernel's launches since the
  * last gp_job_build_filters, measured with HIP events on the context stream,

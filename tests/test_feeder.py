@@ -186,6 +186,11 @@ def test_job_from_files_equals_job_from_arrays(tmp_path):
                 b.polish()
                 assert b.sequences() == want
                 assert [b.get_filter(i, 0).tobytes() for i in range(3)] == want_f
+                # FASTA out: the target file's header lines, input order, dropped records left out
+                b.write_fasta(tmp_path / "out.fa")
+                exp = b"".join(b">" + w.names[c].encode() + (b" some comment" if c % 2 else b"") + b"\n" + want[c] + b"\n"
+                               for c in range(w.n_contigs) if want[c] is not None)
+                assert (tmp_path / "out.fa").read_bytes() == exp
     assert any(x is not None and x != w.contig(i) for i, x in enumerate(want))   # something was polished
 
 
