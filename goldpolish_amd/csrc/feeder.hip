@@ -490,6 +490,47 @@ int gp_filter_save(const char* path, uint32_t k, uint32_t hash_num, uint64_t byt
     return GP_OK;
 }
 
+/* Reader for the header SURVEY.md 8a-A7 describes for btllib's own files: a first line
+ * "[BTLKmerBloomFilter_v<n>]", then "key = value" lines in any order (bytes, hash_num, k are needed,
+ * hash_fn and anything else is skipped), then "[HeaderEnd]", then the filter bytes. UNPINNED: no
+ * btllib source or btllib-written file exists in this image, so this follows the
+ * published layout only and is exercised with hand-written headers; the payload must be exactly
+ * `bytes` long or the file is refused. Leaves f at the first payload byte. */
+static bool read_btl_header(FILE* f, unsigned* k, unsigned* hash_num, unsigned long long* bytes)
+{
+    char line[256];
+    if (!std::fgets(line, sizeof line, f) || std::strncmp(line, "[BTLKmerBloomFilter_v", 21) != 0)
+        return false;
+    bool have_k = false, have_h = false, have_b = false, ended = false;
+    while (std::fgets(line, sizeof line, f)) {
+        if (std::strncmp(line, "[HeaderEnd]", 11) == 0) {
+            ended = true;
+            break;
+        }
+        char key[64];
+        unsigned long long v = 0;
+        if (std::sscanf(line, " %63[A-Za-z_] = %llu", key, &v) != 2)
+            continue;
+        if (!std::strcmp(key, "k")) {
+            *k = (unsigned)v;
+            have_k = true;
+        } else if (!std::strcmp(key, "hash_num")) {
+            *hash_num = (unsigned)v;
+            have_h = true;
+        } else if (!std::strcmp(key, "bytes")) {
+            *bytes = v;
+            have_b = true;
+        }
+    }
+    if (!ended || !have_k || !have_h || !have_b)
+        return false;
+    const long at = std::ftell(f);
+    std::fseek(f, 0, SEEK_END);
+    const long end = std::ftell(f);
+    std::fseek(f, at, SEEK_SET);
+    return (unsigned long long)(end - at) == *bytes;
+}
+
 int gp_filter_load(const char* path, uint32_t* k, uint32_t* hash_num, uint64_t* bytes, uint8_t* buf,
                    uint64_t buf_bytes)
 {
@@ -505,9 +546,12 @@ int gp_filter_load(const char* path, uint32_t* k, uint32_t* hash_num, uint64_t* 
     char magic[8] = { 0 };
     if (std::fscanf(f, "%7s %u %u %llu", magic, &kk, &hh, &bb) != 4 || std::strcmp(magic, "GPBF1") != 0 ||
         std::fgetc(f) != '\n') {
-        std::fclose(f);
-        set_error(std::string(path) + " is not a GPBF1 filter file (btllib's own .bf files are not read, see SURVEY 8f-1)");
-        return GP_ERR_UNSUPPORTED;
+        std::rewind(f);
+        if (!read_btl_header(f, &kk, &hh, &bb)) {
+            std::fclose(f);
+            set_error(std::string(path) + " is neither a GPBF1 file nor a [BTLKmerBloomFilter_v*] file with bytes, hash_num and k");
+            return GP_ERR_UNSUPPORTED;
+        }
     }
     if (k)
         *k = kk;

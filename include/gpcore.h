@@ -232,7 +232,9 @@ int gp_job_create_from_files(gp_ctx* ctx, const gp_params* params, const gp_seqi
 /* One Bloom filter to / from a file, in this build's own container ("GPBF1 k hash_num bytes\n" +
  * the bytes of gp_job_get_filter): what `bfs[i]->save("<batch>-k<k>.bf")` and ntEdit's / Sealer's
  * filter loading do for the reference, for tools that are all this build's.  btllib's own .bf
- * header is not written or read.  buf == NULL: header only. */
+ * header is never written; gp_filter_load also accepts a "[BTLKmerBloomFilter_v*]" / key = value /
+ * "[HeaderEnd]" header as SURVEY.md 8a-A7 lays it out, UNPINNED (no btllib-written file here,
+ * SURVEY.md 8f-1).  buf == NULL: header only. */
 int gp_filter_save(const char* path, uint32_t k, uint32_t hash_num, uint64_t bytes, const uint8_t* data);
 int gp_filter_load(const char* path, uint32_t* k, uint32_t* hash_num, uint64_t* bytes, uint8_t* buf,
                    uint64_t buf_bytes);

@@ -206,3 +206,22 @@ def test_filter_file_round_trip(tmp_path):
     (tmp_path / "other.bf").write_bytes(b"[BTLKmerBloomFilter_v2]\nbytes = 4\n")
     with pytest.raises(core.GpError):
         core.filter_load(tmp_path / "other.bf")
+
+
+def test_filter_file_btl_style_header(tmp_path):
+    """a file laid out the way SURVEY 8a-A7 describes btllib's (hand-written header: that layout is
+    UNPINNED here): keys in any order, unknown keys skipped, payload length checked"""
+    core = _core()
+    rng = np.random.default_rng(10)
+    data = rng.integers(0, 256, size=1024, dtype=np.uint8)
+    hdr = b'[BTLKmerBloomFilter_v6]\nhash_fn = "ntHash_v1"\nk = 28\nbytes = 1024\nhash_num = 3\n[HeaderEnd]\n'
+    (tmp_path / "x.bf").write_bytes(hdr + data.tobytes())
+    k, h, got = core.filter_load(tmp_path / "x.bf")
+    assert (k, h) == (28, 3) and np.array_equal(got, data)
+    for bad in (hdr + data.tobytes()[:-1],                                   # short payload
+                hdr.replace(b"k = 28\n", b"") + data.tobytes(),              # a plain BloomFilter: no k
+                hdr.replace(b"[HeaderEnd]\n", b"") + data.tobytes(),
+                b"[BTLCountingBloomFilter_v6]\n" + hdr.split(b"\n", 1)[1] + data.tobytes()):
+        (tmp_path / "bad.bf").write_bytes(bad)
+        with pytest.raises(core.GpError):
+            core.filter_load(tmp_path / "bad.bf")
