@@ -26,6 +26,26 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line)
     return e == hipErrorOutOfMemory ? GP_ERR_OOM : GP_ERR_HIP;
 }
 
+int on_exception(const char* where) noexcept
+{
+    int rc = GP_ERR_INVALID_ARG;
+    try {
+        try {
+            throw;
+        } catch (const std::bad_alloc&) {
+            rc = GP_ERR_OOM;
+            g_err = std::string(where) + ": out of host memory";
+        } catch (const std::exception& e) {
+            g_err = std::string(where) + ": " + e.what();
+        } catch (...) {
+            g_err = std::string(where) + ": unknown exception";
+        }
+    } catch (...) {
+        // the message itself could not be built; the status still says what happened
+    }
+    return rc;
+}
+
 } // namespace gp
 
 using namespace gp;
@@ -71,7 +91,7 @@ void gp_default_params(gp_params* p)
 }
 
 int gp_ctx_create(int device, gp_ctx** out)
-{
+try {
     if (!out) {
         set_error("gp_ctx_create: out is NULL");
         return GP_ERR_INVALID_ARG;
@@ -99,7 +119,7 @@ int gp_ctx_create(int device, gp_ctx** out)
     }
     *out = c;
     return GP_OK;
-}
+} GP_CATCH("gp_ctx_create")
 
 void gp_ctx_destroy(gp_ctx* ctx)
 {
@@ -124,7 +144,7 @@ int gp_kmer_threshold(uint64_t mapped_bases)
 size_t gp_rank_reads(size_t n, const char* const* ids, const double* phred_avg,
                      const uint64_t* lens, uint64_t target_len, double max_reads_per_10kbp,
                      uint32_t* order, uint64_t* bases)
-{
+try {
     if (bases)
         *bases = 0;
     if (n == 0 || !ids || !phred_avg || !lens || !order)
@@ -151,7 +171,7 @@ size_t gp_rank_reads(size_t n, const char* const* ids, const double* phred_avg,
     if (bases)
         *bases = sum;
     return use;
-}
+} GP_CATCH_SIZE("gp_rank_reads")
 
 static int check_params(const gp_params& p)
 {
@@ -185,7 +205,7 @@ static int check_params(const gp_params& p)
 }
 
 int gp_job_create(gp_ctx* ctx, const gp_params* params, const gp_batch_set* set, gp_job** out)
-{
+try {
     if (!ctx || !params || !set || !out) {
         set_error("gp_job_create: NULL argument");
         return GP_ERR_INVALID_ARG;
@@ -238,10 +258,11 @@ int gp_job_create(gp_ctx* ctx, const gp_params* params, const gp_batch_set* set,
     j->n_batches = set->n_batches;
     j->n_contigs = set->n_contigs;
     j->n_reads = set->n_reads;
-    auto fail = [&](int code) {
-        gp_job_destroy(j);
-        return code;
-    };
+    struct Owner { // frees the half-built job on every early return and on an exception
+        gp_job* j;
+        ~Owner() { gp_job_destroy(j); }
+    } owner{ j };
+    auto fail = [&](int code) { return code; };
 
     // ---- host-side tables
     j->h_batch_contig_begin.assign(set->batch_contig_begin,
@@ -340,9 +361,10 @@ int gp_job_create(gp_ctx* ctx, const gp_params* params, const gp_batch_set* set,
         return fail(rc);
     if ((rc = stage_bc_prepare(j)) != GP_OK)
         return fail(rc);
+    owner.j = nullptr;
     *out = j;
     return GP_OK;
-}
+} GP_CATCH("gp_job_create")
 
 void gp_job_destroy(gp_job* job)
 {
@@ -366,12 +388,12 @@ void gp_job_destroy(gp_job* job)
 }
 
 int gp_job_sync(gp_job* job)
-{
+try {
     if (!job)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipStreamSynchronize(job->ctx->stream));
     return GP_OK;
-}
+} GP_CATCH("gp_job_sync")
 
 static int finish(gp_job* job, int rc, int sync)
 {
@@ -383,15 +405,15 @@ static int finish(gp_job* job, int rc, int sync)
 }
 
 int gp_job_build_filters(gp_job* job, int sync)
-{
+try {
     if (!job)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
     return finish(job, stage_a_run(job), sync);
-}
+} GP_CATCH("gp_job_build_filters")
 
 int gp_job_ntedit_pass(gp_job* job, uint32_t k_index, int sync)
-{
+try {
     if (!job || k_index >= job->prm.n_k)
         return GP_ERR_INVALID_ARG;
     if (!job->filters_ready) {
@@ -405,24 +427,24 @@ int gp_job_ntedit_pass(gp_job* job, uint32_t k_index, int sync)
     if (rc == GP_OK)
         rc = stage_b_pass(job, k_index);
     return finish(job, rc, sync);
-}
+} GP_CATCH("gp_job_ntedit_pass")
 
 int gp_job_ntedit_guard(gp_job* job, int sync)
-{
+try {
     if (!job)
         return GP_ERR_INVALID_ARG;
     return finish(job, stage_b_guard(job), sync);
-}
+} GP_CATCH("gp_job_ntedit_guard")
 
 int gp_job_mask(gp_job* job, int sync)
-{
+try {
     if (!job)
         return GP_ERR_INVALID_ARG;
     return finish(job, stage_mask(job), sync);
-}
+} GP_CATCH("gp_job_mask")
 
 int gp_job_sealer(gp_job* job, int sync)
-{
+try {
     if (!job)
         return GP_ERR_INVALID_ARG;
     if (!job->filters_ready) {
@@ -430,17 +452,17 @@ int gp_job_sealer(gp_job* job, int sync)
         return GP_ERR_STATE;
     }
     return finish(job, stage_c_run(job), sync);
-}
+} GP_CATCH("gp_job_sealer")
 
 int gp_job_upper(gp_job* job, int sync)
-{
+try {
     if (!job)
         return GP_ERR_INVALID_ARG;
     return finish(job, stage_upper(job), sync);
-}
+} GP_CATCH("gp_job_upper")
 
 int gp_job_polish(gp_job* job, int sync)
-{
+try {
     if (!job)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
@@ -471,10 +493,10 @@ int gp_job_polish(gp_job* job, int sync)
             break;
     }
     return finish(job, rc, sync);
-}
+} GP_CATCH("gp_job_polish")
 
 int gp_job_get_filter(gp_job* job, uint32_t batch, uint32_t k_index, uint8_t* out)
-{
+try {
     if (!job || !out || batch >= job->n_batches || k_index >= job->prm.n_k) {
         set_error("gp_job_get_filter: bad argument");
         return GP_ERR_INVALID_ARG;
@@ -485,10 +507,10 @@ int gp_job_get_filter(gp_job* job, uint32_t batch, uint32_t k_index, uint8_t* ou
     GP_HIP(hipMemcpy(out, job->d_bf.p + ((uint64_t)batch * job->prm.n_k + k_index) * words,
                      job->prm.bf_bytes, hipMemcpyDeviceToHost));
     return GP_OK;
-}
+} GP_CATCH("gp_job_get_filter")
 
 int gp_job_set_filters(gp_job* job, const uint8_t* filters)
-{
+try {
     if (!job || !filters)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
@@ -498,43 +520,43 @@ int gp_job_set_filters(gp_job* job, const uint8_t* filters)
                      hipMemcpyHostToDevice));
     job->filters_ready = true;
     return GP_OK;
-}
+} GP_CATCH("gp_job_set_filters")
 
 int gp_job_get_lengths(gp_job* job, uint64_t* lengths, uint8_t* dropped, uint64_t* total)
-{
+try {
     if (!job)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
     return stage_lengths(job, lengths, dropped, total);
-}
+} GP_CATCH("gp_job_get_lengths")
 
 int gp_job_get_sequences(gp_job* job, uint8_t* buf, uint64_t buf_bytes)
-{
+try {
     if (!job || !buf)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
     return stage_sequences(job, buf, buf_bytes);
-}
+} GP_CATCH("gp_job_get_sequences")
 
 int gp_job_get_sequences_device(gp_job* job, void* device_buf, uint64_t buf_bytes)
-{
+try {
     if (!job || !device_buf)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
     return stage_sequences_device(job, device_buf, buf_bytes);
-}
+} GP_CATCH("gp_job_get_sequences_device")
 
 int gp_job_get_counters(gp_job* job, gp_counters* out)
-{
+try {
     if (!job || !out)
         return GP_ERR_INVALID_ARG;
     *out = job->counters;
     return GP_OK;
-}
+} GP_CATCH("gp_job_get_counters")
 
 int gp_job_kernel_time(gp_job* job, const char* kernel, double* total_ms, uint64_t* launches,
                        uint64_t* units)
-{
+try {
     if (!job || !kernel)
         return GP_ERR_INVALID_ARG;
     const KernelTimer* t = nullptr;
@@ -565,6 +587,6 @@ int gp_job_kernel_time(gp_job* job, const char* kernel, double* total_ms, uint64
     if (units)
         *units = t->total_units;
     return GP_OK;
-}
+} GP_CATCH("gp_job_kernel_time")
 
 } // extern "C"

@@ -217,7 +217,7 @@ extern "C" {
 
 /* SeqIndex(seqs_filepath), src/seqindex.cpp:12-66 */
 int gp_seqindex_build(const char* seqs_path, gp_seqindex** out)
-{
+try {
     if (!seqs_path || !out)
         return GP_ERR_INVALID_ARG;
     std::ifstream in(seqs_path);
@@ -266,11 +266,11 @@ int gp_seqindex_build(const char* seqs_path, gp_seqindex** out)
     }
     *out = ix;
     return GP_OK;
-}
+} GP_CATCH("gp_seqindex_build")
 
 /* SeqIndex(index_filepath, seqs_filepath), src/seqindex.cpp:85-125 */
 int gp_seqindex_load(const char* index_path, const char* seqs_path, gp_seqindex** out)
-{
+try {
     if (!index_path || !seqs_path || !out)
         return GP_ERR_INVALID_ARG;
     std::ifstream in(index_path);
@@ -304,13 +304,13 @@ int gp_seqindex_load(const char* index_path, const char* seqs_path, gp_seqindex*
     }
     *out = ix;
     return GP_OK;
-}
+} GP_CATCH("gp_seqindex_load")
 
 /* SeqIndex::save, src/seqindex.cpp:68-83: id, start, length, average phred as operator<< prints a
  * double (six significant digits).  Lines come in file order here; the reference's order is
  * that of its hash map and the loader does not care. */
 int gp_seqindex_save(const gp_seqindex* ix, const char* index_path)
-{
+try {
     if (!ix || !index_path)
         return GP_ERR_INVALID_ARG;
     FILE* f = std::fopen(index_path, "w");
@@ -323,13 +323,13 @@ int gp_seqindex_save(const gp_seqindex* ix, const char* index_path)
                      (unsigned long long)e.len, e.phred);
     std::fclose(f);
     return GP_OK;
-}
+} GP_CATCH("gp_seqindex_save")
 
 uint64_t gp_seqindex_count(const gp_seqindex* ix) { return ix ? ix->entries.size() : 0; }
 
 int gp_seqindex_entry(const gp_seqindex* ix, uint64_t i, const char** id, uint64_t* start,
                       uint64_t* len, double* phred)
-{
+try {
     if (!ix || i >= ix->entries.size())
         return GP_ERR_INVALID_ARG;
     const auto& e = ix->entries[i];
@@ -342,11 +342,11 @@ int gp_seqindex_entry(const gp_seqindex* ix, uint64_t i, const char** id, uint64
     if (phred)
         *phred = e.phred;
     return GP_OK;
-}
+} GP_CATCH("gp_seqindex_entry")
 
 int gp_seqindex_find(const gp_seqindex* ix, const char* id, uint64_t* start, uint64_t* len,
                      double* phred)
-{
+try {
     if (!ix || !id)
         return GP_ERR_INVALID_ARG;
     const auto* e = ix->find(id);
@@ -359,12 +359,12 @@ int gp_seqindex_find(const gp_seqindex* ix, const char* id, uint64_t* start, uin
     if (phred)
         *phred = e->phred;
     return GP_OK;
-}
+} GP_CATCH("gp_seqindex_find")
 
 /* SeqIndex::get_seq, src/seqindex.hpp:59-102 (no 20 MiB limit here: the caller sizes buf) */
 int gp_seqindex_read(const gp_seqindex* ix, const char* id, uint8_t* buf, uint64_t buf_bytes,
                      uint64_t* len)
-{
+try {
     if (!ix || !id)
         return GP_ERR_INVALID_ARG;
     const auto* e = ix->find(id);
@@ -381,14 +381,14 @@ int gp_seqindex_read(const gp_seqindex* ix, const char* id, uint8_t* buf, uint64
         return GP_ERR_INVALID_ARG;
     }
     return read_exact(ix, e->start, e->len, buf);
-}
+} GP_CATCH("gp_seqindex_read")
 
 void gp_seqindex_destroy(gp_seqindex* ix) { delete ix; }
 
 /* AllMappings::AllMappings, src/mappings.cpp:15-36 */
 int gp_mappings_load(const char* path, const gp_seqindex* targets, uint32_t mx_min, uint32_t mx_max,
                      double mx_max_mapped_per_10kbp, gp_mappings** out)
-{
+try {
     if (!path || !targets || !out)
         return GP_ERR_INVALID_ARG;
     const std::string p = path;
@@ -446,12 +446,12 @@ int gp_mappings_load(const char* path, const gp_seqindex* targets, uint32_t mx_m
         m->by_target.emplace(kv.first, std::move(kv.second.ids));
     *out = m;
     return GP_OK;
-}
+} GP_CATCH("gp_mappings_load")
 
 /* AllMappings::get_mappings, src/mappings.cpp:337-345.  The pointers stay valid until the next
  * gp_mappings_get on this object. */
 int gp_mappings_get(gp_mappings* m, const char* target_id, uint64_t* n, const char* const** ids)
-{
+try {
     if (!m || !target_id || !n)
         return GP_ERR_INVALID_ARG;
     m->scratch.clear();
@@ -463,7 +463,7 @@ int gp_mappings_get(gp_mappings* m, const char* target_id, uint64_t* n, const ch
     if (ids)
         *ids = m->scratch.data();
     return GP_OK;
-}
+} GP_CATCH("gp_mappings_get")
 
 void gp_mappings_destroy(gp_mappings* m) { delete m; }
 
@@ -472,7 +472,7 @@ void gp_mappings_destroy(gp_mappings* m) { delete m; }
  * header cannot be pinned here): the line "GPBF1 <k> <hash_num> <bytes>\n", then the
  * filter bytes (bit n -> byte n/8, mask 1 << n%8, the order btllib uses in memory). */
 int gp_filter_save(const char* path, uint32_t k, uint32_t hash_num, uint64_t bytes, const uint8_t* data)
-{
+try {
     if (!path || !data)
         return GP_ERR_INVALID_ARG;
     FILE* f = std::fopen(path, "wb");
@@ -488,7 +488,7 @@ int gp_filter_save(const char* path, uint32_t k, uint32_t hash_num, uint64_t byt
         return GP_ERR_INVALID_ARG;
     }
     return GP_OK;
-}
+} GP_CATCH("gp_filter_save")
 
 /* Reader for the header SURVEY.md 8a-A7 describes for btllib's own files: a first line
  * "[BTLKmerBloomFilter_v<n>]", then "key = value" lines in any order (bytes, hash_num, k are needed,
@@ -533,7 +533,7 @@ static bool read_btl_header(FILE* f, unsigned* k, unsigned* hash_num, unsigned l
 
 int gp_filter_load(const char* path, uint32_t* k, uint32_t* hash_num, uint64_t* bytes, uint8_t* buf,
                    uint64_t buf_bytes)
-{
+try {
     if (!path)
         return GP_ERR_INVALID_ARG;
     FILE* f = std::fopen(path, "rb");
@@ -571,7 +571,7 @@ int gp_filter_load(const char* path, uint32_t* k, uint32_t* hash_num, uint64_t* 
     }
     std::fclose(f);
     return rc;
-}
+} GP_CATCH("gp_filter_load")
 
 /* What serve_batch does before it fills the filters (src/goldpolish_targeted_bfs.cpp:86-131), for
  * every target of every batch, plus what scripts/goldpolish:344-355 does when it writes
@@ -583,7 +583,7 @@ int gp_job_create_from_files(gp_ctx* ctx, const gp_params* params, const gp_seqi
                              double max_reads_per_10kbp, uint32_t n_batches,
                              const uint32_t* batch_target_begin, const char* const* target_ids,
                              gp_job** out)
-{
+try {
     if (!ctx || !params || !targets || !reads || !mappings || !batch_target_begin || !target_ids || !out)
         return GP_ERR_INVALID_ARG;
     const uint32_t n_contigs = batch_target_begin[n_batches];
@@ -660,14 +660,14 @@ int gp_job_create_from_files(gp_ctx* ctx, const gp_params* params, const gp_seqi
     if (rc_create == GP_OK)
         (*out)->headers = std::move(headers);
     return rc_create;
-}
+} GP_CATCH("gp_job_create_from_files")
 
 /* The batch's final FASTA (scripts/goldpolish-make:46-47 `goldpolish-to-upper`, collected in input
  * order by scripts/goldpolish-reaper:51-73): ">id[ comment]" and the polished sequence, records
  * ntEdit dropped left out.  names == NULL: the header lines of the target file (jobs made by
  * gp_job_create_from_files). */
 int gp_job_write_fasta(gp_job* job, const char* const* names, const char* path, int append)
-{
+try {
     if (!job || !path)
         return GP_ERR_INVALID_ARG;
     if (!names && job->headers.size() != job->n_contigs) {
@@ -702,6 +702,6 @@ int gp_job_write_fasta(gp_job* job, const char* const* names, const char* path, 
     }
     std::fclose(f);
     return GP_OK;
-}
+} GP_CATCH("gp_job_write_fasta")
 
 } // extern "C"

@@ -15,6 +15,12 @@ namespace gp {
 void set_error(const std::string& msg);
 void track_device_bytes(long long delta); // bytes this library holds on devices (gp_device_bytes_in_use)
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
+int on_exception(const char* where) noexcept; // inside a catch: records the message, gives the status
+
+// every entry point's body is a function-try-block closed by one of these: nothing is thrown
+// across the C boundary (std::bad_alloc from a host-side table becomes GP_ERR_OOM)
+#define GP_CATCH(where) catch (...) { return gp::on_exception(where); }
+#define GP_CATCH_SIZE(where) catch (...) { (void)gp::on_exception(where); return 0; }
 
 #define GP_HIP(call)                                                    \
     do {                                                                \

@@ -211,7 +211,7 @@ using namespace gp;
 extern "C" {
 
 int gp_target_extract(const char* fasta_path, const char* bed_path, uint32_t flank, const char* out_path)
-{
+try {
     if (!fasta_path || !out_path)
         return GP_ERR_INVALID_ARG;
     std::vector<Record> recs;
@@ -259,10 +259,10 @@ int gp_target_extract(const char* fasta_path, const char* bed_path, uint32_t fla
     }
     std::fclose(out);
     return GP_OK;
-}
+} GP_CATCH("gp_target_extract")
 
 int gp_target_update_paf(const char* gaps_fasta_path, const char* paf_path, const char* out_path)
-{
+try {
     if (!gaps_fasta_path || !paf_path || !out_path)
         return GP_ERR_INVALID_ARG;
     struct Window {
@@ -352,10 +352,10 @@ int gp_target_update_paf(const char* gaps_fasta_path, const char* paf_path, cons
     }
     std::fclose(out);
     return GP_OK;
-}
+} GP_CATCH("gp_target_update_paf")
 
 int gp_target_reinsert(const char* fasta_path, const char* polished_gaps_path, const char* out_path)
-{
+try {
     if (!fasta_path || !polished_gaps_path || !out_path)
         return GP_ERR_INVALID_ARG;
     std::vector<Record> recs, gaps;
@@ -412,6 +412,6 @@ int gp_target_reinsert(const char* fasta_path, const char* polished_gaps_path, c
     }
     std::fclose(out);
     return GP_OK;
-}
+} GP_CATCH("gp_target_reinsert")
 
 } // extern "C"

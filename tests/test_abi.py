@@ -58,3 +58,18 @@ def test_no_gpu_fails_loudly(gplib):
     with pytest.raises(gplib.GpError) as e:
         gplib.Context(0)
     assert e.value.code == -2
+
+
+def test_nothing_is_thrown_across_the_boundary(gplib):
+    """an allocation the host cannot make (std::length_error / bad_alloc inside the library)
+    comes back as a status + message, not as a C++ exception through ctypes"""
+    import ctypes as C
+    L = gplib.lib()
+    ids = (C.c_char_p * 1)(b"r")
+    ph = (C.c_double * 1)(1.0)
+    ln = (C.c_uint64 * 1)(1)
+    order = (C.c_uint32 * 1)()
+    bases = C.c_uint64(7)
+    got = L.gp_rank_reads(1 << 62, ids, ph, ln, 1000, 40.0, order, C.byref(bases))
+    assert got == 0 and bases.value == 0
+    assert b"gp_rank_reads" in L.gp_last_error()
