@@ -1168,10 +1168,12 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
     }
     __syncthreads();
 
-    // Each pass of this loop is one "request" decided by thread 0.  Every request
-    // moves the walker forward, so 4*len+4096 passes is a bug trap, never a limit.
-    for (uint32_t trip = 0;; trip++) {
-        if (trip > 4u * len + 4096u) {
+    // Each pass of this loop is one "request" decided by thread 0.  Every request moves the
+    // walker forward over the sequence as edited so far -- at most len positions plus one per
+    // node (an inserted base is a node) -- so this many passes is a bug trap, never a limit.
+    const uint64_t trip_trap = 8ull * ((uint64_t)len + c.node_cap) + 4096ull;
+    for (uint64_t trip = 0;; trip++) {
+        if (trip > trip_trap) {
             if (tid == 0)
                 atomicOr(a.err, 4u);
             break;
