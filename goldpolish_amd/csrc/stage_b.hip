@@ -2557,9 +2557,13 @@ static int pull_stats(gp_job* job)
         (rc = job->t_mask.collect()) != GP_OK || (rc = job->t_upper.collect()) != GP_OK ||
         (rc = job->t_bfs.collect()) != GP_OK)
         return rc;
-    if (err & (1u | 1024u | 512u)) {
-        set_error("a contig outgrew its device slot (code " + std::to_string(err) +
-                  "): gp_job_polish retries with larger slots, the step-wise calls do not");
+    // everything sized from the contig slots, which gp_job_polish doubles before it runs the
+    // cascade again -- 1: node list full, 8: more gaps than a slot of this size is given room for
+    // (only reachable through the step-wise calls on unmasked input), 32: Sealer's pool of
+    // connecting sequences full, 512 / 1024: filled / edited contig longer than its slot
+    if (err & (1u | 8u | 32u | 1024u | 512u)) {
+        set_error("a contig outgrew its device slot, or Sealer the arenas sized from the slots (code " +
+                  std::to_string(err) + "): gp_job_polish retries with larger slots, the step-wise calls do not");
         return GP_ERR_CAPACITY;
     }
     if (err) {
