@@ -92,6 +92,8 @@ void gpo_ntedit_default_params(gpo_ntedit_params* p, unsigned k, unsigned h);
  * contig of length >= min_contig_len.  out must hold at least
  * gpo_ntedit_out_bound(len) bytes; returns the edited length. */
 size_t gpo_ntedit_out_bound(size_t len);
+/* the i-th (0..340) insertion trial string starting with `first` (ntedit.cpp:198-343), for tests */
+unsigned gpo_ntedit_indel_string(unsigned char first, int i, char out[6]);
 /* the same with a malloc'ed result of exactly the edited length + 1 (free with gpo_free) */
 size_t gpo_ntedit_contig_dyn(const char* seq, size_t len, const uint8_t* bf, size_t bf_bytes,
                              const gpo_ntedit_params* p, char** out, uint64_t* n_probes);

@@ -140,6 +140,13 @@ static unsigned indel_string(unsigned char first, int i, char out[6])
     return L;
 }
 
+/* test hook: the i-th trial string for `first` (tests compare the whole enumeration with the
+ * order of the reference's multi_possible_bases table) */
+unsigned gpo_ntedit_indel_string(unsigned char first, int i, char out[6])
+{
+    return indel_string(first, i, out);
+}
+
 static void hash_init(ed_t* e, const char* kmer)
 {
     e->fh = gpo_ntf64(kmer, e->p->k);

@@ -219,3 +219,39 @@ def test_self_generated_pipeline_golden(oracle):
             assert (st.gaps_found, st.gaps_closed) == (want["sealer"]["gaps_found"],
                                                       want["sealer"]["gaps_closed"])
             assert sha(s.upper()) == want["final"]["sha"]
+
+
+def test_indel_trial_strings_follow_the_reference_table(oracle):
+    """tryIndels walks multi_possible_bases[first][0..340] (ntedit.cpp:198-343): every string of
+    length 1..5 that starts with `first`, shortest first, then A < C < G < T.  The oracle computes
+    the i-th string; here against that order spelled out, and -- where the reference tree is
+    mounted (this container, not the GPU box) -- against the table's text itself."""
+    import ctypes as C
+    import itertools
+    import pathlib
+    import re
+    L = oracle.L
+    L.gpo_ntedit_indel_string.restype = C.c_uint
+    L.gpo_ntedit_indel_string.argtypes = [C.c_ubyte, C.c_int, C.c_char_p]
+
+    def ours(first):
+        out = []
+        for i in range(341):
+            buf = C.create_string_buffer(8)
+            n = L.gpo_ntedit_indel_string(ord(first), i, buf)
+            out.append(buf.raw[:n].decode())
+        return out
+
+    for first in "ACGT":
+        want = [first + "".join(t) for n in range(5) for t in itertools.product("ACGT", repeat=n)]
+        assert ours(first) == want
+    ref = pathlib.Path("/root/reference/subprojects/ntedit/ntedit.cpp")
+    if ref.exists():
+        src = ref.read_text()
+        blk = src[src.index("multi_possible_bases = {"):]
+        blk = blk[:blk.index("};")]
+        tabs = {m.group(1): re.findall(r'"([ACGT]+)"', m.group(2))
+                for m in re.finditer(r"\{\s*'([ACGT])',\s*\{(.*?)\}\s*\}", blk, re.S)}
+        assert sorted(tabs) == list("ACGT")
+        for first in "ACGT":
+            assert ours(first) == tabs[first]
