@@ -404,6 +404,15 @@ static int finish(gp_job* job, int rc, int sync)
     return GP_OK;
 }
 
+// stages B and C keep their state in job->bc; it is gone only if growing the slots ran out of memory
+static int need_bc(const gp_job* job, const char* who)
+{
+    if (job->bc)
+        return GP_OK;
+    set_error(std::string(who) + ": the job lost its polishing state (allocation failed while growing the contig slots)");
+    return GP_ERR_STATE;
+}
+
 int gp_job_build_filters(gp_job* job, int sync)
 try {
     if (!job)
@@ -421,6 +430,8 @@ try {
         return GP_ERR_STATE;
     }
     GP_HIP(hipSetDevice(job->ctx->device));
+    if (int rcb = need_bc(job, "gp_job_ntedit_pass"))
+        return rcb;
     int rc = GP_OK;
     if (k_index == 0)
         rc = stage_b_reset(job);
@@ -433,6 +444,8 @@ int gp_job_ntedit_guard(gp_job* job, int sync)
 try {
     if (!job)
         return GP_ERR_INVALID_ARG;
+    if (int rcb = need_bc(job, "gp_job_ntedit_guard"))
+        return rcb;
     return finish(job, stage_b_guard(job), sync);
 } GP_CATCH("gp_job_ntedit_guard")
 
@@ -440,6 +453,8 @@ int gp_job_mask(gp_job* job, int sync)
 try {
     if (!job)
         return GP_ERR_INVALID_ARG;
+    if (int rcb = need_bc(job, "gp_job_mask"))
+        return rcb;
     return finish(job, stage_mask(job), sync);
 } GP_CATCH("gp_job_mask")
 
@@ -451,6 +466,8 @@ try {
         set_error("gp_job_sealer: filters have not been built or set");
         return GP_ERR_STATE;
     }
+    if (int rcb = need_bc(job, "gp_job_sealer"))
+        return rcb;
     return finish(job, stage_c_run(job), sync);
 } GP_CATCH("gp_job_sealer")
 
@@ -458,6 +475,8 @@ int gp_job_upper(gp_job* job, int sync)
 try {
     if (!job)
         return GP_ERR_INVALID_ARG;
+    if (int rcb = need_bc(job, "gp_job_upper"))
+        return rcb;
     return finish(job, stage_upper(job), sync);
 } GP_CATCH("gp_job_upper")
 
@@ -466,6 +485,8 @@ try {
     if (!job)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
+    if (int rcb = need_bc(job, "gp_job_polish"))
+        return rcb;
     int rc = stage_a_run(job);
     for (int attempt = 0; rc == GP_OK; attempt++) {
         for (uint32_t ki = 0; rc == GP_OK && ki < job->prm.n_k; ki++) {
@@ -489,8 +510,10 @@ try {
         // room, and stages B and C again from the unedited contigs; the filters stay
         job->bc_slack *= 2;
         stage_bc_release(job);
-        if ((rc = stage_bc_prepare(job)) != GP_OK)
+        if ((rc = stage_bc_prepare(job)) != GP_OK) {
+            stage_bc_release(job); // not a half-built state: later calls get GP_ERR_STATE
             break;
+        }
     }
     return finish(job, rc, sync);
 } GP_CATCH("gp_job_polish")
@@ -527,6 +550,8 @@ try {
     if (!job)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
+    if (int rcb = need_bc(job, "gp_job_get_lengths"))
+        return rcb;
     return stage_lengths(job, lengths, dropped, total);
 } GP_CATCH("gp_job_get_lengths")
 
@@ -535,6 +560,8 @@ try {
     if (!job || !buf)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
+    if (int rcb = need_bc(job, "gp_job_get_sequences"))
+        return rcb;
     return stage_sequences(job, buf, buf_bytes);
 } GP_CATCH("gp_job_get_sequences")
 
@@ -543,6 +570,8 @@ try {
     if (!job || !device_buf)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
+    if (int rcb = need_bc(job, "gp_job_get_sequences_device"))
+        return rcb;
     return stage_sequences_device(job, device_buf, buf_bytes);
 } GP_CATCH("gp_job_get_sequences_device")
 
