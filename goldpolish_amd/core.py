@@ -24,7 +24,7 @@ u64p = C.POINTER(C.c_uint64)
 # every symbol include/gpcore.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "gp_last_error", "gp_version", "gp_device_bytes_in_use", "gp_default_params", "gp_ctx_create", "gp_ctx_destroy",
-    "gp_ctx_stream", "gp_kmer_threshold", "gp_rank_reads", "gp_job_create", "gp_job_destroy",
+    "gp_ctx_stream", "gp_kmer_threshold", "gp_rank_reads", "gp_partition_batches", "gp_job_create", "gp_job_destroy",
     "gp_job_polish", "gp_job_build_filters", "gp_job_ntedit_pass", "gp_job_ntedit_guard",
     "gp_job_mask", "gp_job_sealer", "gp_job_upper", "gp_job_sync", "gp_job_get_filter",
     "gp_job_set_filters", "gp_job_get_lengths", "gp_job_get_sequences",
@@ -121,6 +121,7 @@ def load_library(path=None):
     L.gp_rank_reads.restype = C.c_size_t
     L.gp_rank_reads.argtypes = [C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_double), u64p,
                                 C.c_uint64, C.c_double, u32p, u64p]
+    L.gp_partition_batches.argtypes = [C.c_uint32, u64p, C.c_uint32, u32p, u64p]
     L.gp_job_create.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(BatchSet),
                                 C.POINTER(C.c_void_p)]
     L.gp_job_destroy.argtypes = [C.c_void_p]
@@ -206,6 +207,17 @@ def rank_reads(ids, phred, lens, target_len, s):
     bases = C.c_uint64(0)
     m = lib().gp_rank_reads(n, cids, ph, ln, int(target_len), float(s), order, C.byref(bases))
     return list(order[:m]), bases.value
+
+
+def partition_batches(cost, n_ranks):
+    """rank per batch, longest-first onto the least-loaded rank; returns (rank_of, rank_load)"""
+    cost = np.ascontiguousarray(cost, dtype=np.uint64)
+    rank_of = np.zeros(cost.size, dtype=np.uint32)
+    load = np.zeros(n_ranks, dtype=np.uint64)
+    _check(lib().gp_partition_batches(cost.size, cost.ctypes.data_as(C.POINTER(C.c_uint64)), n_ranks,
+                                      rank_of.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                      load.ctypes.data_as(C.POINTER(C.c_uint64))))
+    return rank_of, load
 
 
 class Context:

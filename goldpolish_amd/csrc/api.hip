@@ -173,6 +173,32 @@ try {
     return use;
 } GP_CATCH_SIZE("gp_rank_reads")
 
+/* SURVEY.md 8e */
+int gp_partition_batches(uint32_t n_batches, const uint64_t* cost, uint32_t n_ranks,
+                         uint32_t* rank_of, uint64_t* rank_load)
+try {
+    if (n_ranks == 0 || (n_batches && (!cost || !rank_of))) {
+        set_error("gp_partition_batches: bad argument");
+        return GP_ERR_INVALID_ARG;
+    }
+    std::vector<uint32_t> order(n_batches);
+    for (uint32_t b = 0; b < n_batches; b++)
+        order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+    std::vector<uint64_t> load(n_ranks, 0);
+    for (uint32_t b : order) {
+        uint32_t best = 0;
+        for (uint32_t r = 1; r < n_ranks; r++) // a node has 8 ranks: no heap needed
+            if (load[r] < load[best])
+                best = r;
+        rank_of[b] = best;
+        load[best] += cost[b];
+    }
+    if (rank_load)
+        std::copy(load.begin(), load.end(), rank_load);
+    return GP_OK;
+} GP_CATCH("gp_partition_batches")
+
 static int check_params(const gp_params& p)
 {
     if (p.n_k == 0 || p.n_k > GP_MAX_K_VALUES) {

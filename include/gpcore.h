@@ -148,6 +148,13 @@ int gp_kmer_threshold(uint64_t mapped_bases);
 size_t gp_rank_reads(size_t n, const char* const* ids, const double* phred_avg,
                      const uint64_t* lens, uint64_t target_len, double max_reads_per_10kbp,
                      uint32_t* order, uint64_t* bases);
+/* Which rank polishes which batch (the reference has no counterpart: its batches
+ * go to whichever worker holds a token, scripts/goldpolish:496-514): batches are dealt
+ * longest-first -- cost[b] = contig bases + mapped read bases of batch b -- to the rank with the
+ * least load so far; ties go to the lower batch index and the lower rank, so every rank computes
+ * the same answer without talking.  rank_of[n_batches] out; rank_load[n_ranks] out, may be NULL. */
+int gp_partition_batches(uint32_t n_batches, const uint64_t* cost, uint32_t n_ranks,
+                         uint32_t* rank_of, uint64_t* rank_load);
 
 /* ---- jobs --------------------------------------------------------------- */
 /* Copies the batch set to the device (host->HBM over PCIe; NOT part of the

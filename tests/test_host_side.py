@@ -6,6 +6,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = pathlib.Path(__file__).resolve().parents[1]
 
@@ -87,3 +88,25 @@ def test_oracle_under_address_sanitizer(tmp_path):
     r = subprocess.run([sys.executable, str(script), str(ROOT)], env=env, text=True,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0 and "ASAN_OK" in r.stdout, r.stdout[-3000:]
+
+
+def test_batches_are_dealt_longest_first_to_the_least_loaded_rank():
+    """the partition every rank computes for itself -- deterministic, complete, and
+    within the list-scheduling bound"""
+    from goldpolish_amd import core
+    rng = np.random.default_rng(5)
+    for n_batches, n_ranks in [(0, 4), (1, 8), (7, 8), (300, 8), (300, 3), (64, 1)]:
+        cost = rng.lognormal(14, 1.0, size=n_batches).astype(np.uint64)
+        rank_of, load = core.partition_batches(cost, n_ranks)
+        again, _ = core.partition_batches(cost, n_ranks)
+        assert np.array_equal(rank_of, again)
+        assert rank_of.size == n_batches and (rank_of < n_ranks).all()
+        assert [int(cost[rank_of == r].sum()) for r in range(n_ranks)] == [int(x) for x in load]
+        if n_batches:
+            # greedy list scheduling: nobody ends later than the mean load plus one batch
+            assert float(load.max()) <= float(cost.sum()) / n_ranks + float(cost.max()) * (1 - 1 / n_ranks) + 1
+    # ties: lower batch index first, lower rank first
+    rank_of, load = core.partition_batches([5, 5, 5, 5, 1], 2)
+    assert list(rank_of) == [0, 1, 0, 1, 0] and list(load) == [11, 10]
+    with pytest.raises(core.GpError):
+        core.partition_batches([1, 2], 0)
