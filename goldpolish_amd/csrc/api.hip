@@ -240,19 +240,42 @@ try {
     int rc = check_params(*params);
     if (rc != GP_OK)
         return rc;
-    if (set->n_contigs && (!set->contig_off || !set->contig_read_begin ||
-                           !set->contig_kmer_threshold || !set->batch_contig_begin)) {
+    // every array is checked before anything reads it: a job with no contigs or no reads at all
+    // is legal (it polishes nothing), NULL arrays that would have to be read are not
+    if (set->n_batches == 0 || !set->batch_contig_begin) {
+        set_error("gp_job_create: no batches, or batch_contig_begin is NULL");
+        return GP_ERR_INVALID_ARG;
+    }
+    if (set->n_contigs && (!set->contig_off || !set->contig_read_begin || !set->contig_kmer_threshold)) {
         set_error("gp_job_create: batch set has NULL arrays");
         return GP_ERR_INVALID_ARG;
     }
-    if (set->n_batches == 0 || set->batch_contig_begin[set->n_batches] != set->n_contigs) {
+    if (set->n_reads && (!set->read_off || !set->read_buf)) {
+        set_error("gp_job_create: n_reads > 0 but read_off / read_buf is NULL");
+        return GP_ERR_INVALID_ARG;
+    }
+    if (set->batch_contig_begin[0] != 0 || set->batch_contig_begin[set->n_batches] != set->n_contigs) {
         set_error("gp_job_create: batch_contig_begin does not cover the contigs");
         return GP_ERR_INVALID_ARG;
     }
+    for (uint32_t b = 0; b < set->n_batches; b++)
+        if (set->batch_contig_begin[b + 1] < set->batch_contig_begin[b]) {
+            set_error("gp_job_create: batch_contig_begin must be non-decreasing");
+            return GP_ERR_INVALID_ARG;
+        }
     if (set->n_contigs >= (1u << 28)) {
         set_error("gp_job_create: too many contigs in one job");
         return GP_ERR_UNSUPPORTED;
     }
+    if (set->n_contigs && set->contig_read_begin[set->n_contigs] > set->n_reads) {
+        set_error("gp_job_create: contig_read_begin exceeds n_reads");
+        return GP_ERR_INVALID_ARG;
+    }
+    for (uint32_t r = 0; r < set->n_reads; r++)
+        if (set->read_off[r + 1] < set->read_off[r]) {
+            set_error("gp_job_create: read_off must be non-decreasing");
+            return GP_ERR_INVALID_ARG;
+        }
     for (uint32_t c = 0; c < set->n_contigs; c++) {
         if (set->contig_read_begin[c + 1] < set->contig_read_begin[c] ||
             set->contig_off[c + 1] < set->contig_off[c]) {
@@ -270,8 +293,8 @@ try {
             return GP_ERR_INVALID_ARG;
         }
     }
-    if (set->n_contigs && set->contig_read_begin[set->n_contigs] > set->n_reads) {
-        set_error("gp_job_create: contig_read_begin exceeds n_reads");
+    if (set->n_contigs && set->contig_off[set->n_contigs] > set->contig_off[0] && !set->contig_buf) {
+        set_error("gp_job_create: contig_buf is NULL");
         return GP_ERR_INVALID_ARG;
     }
     GP_HIP(hipSetDevice(ctx->device));
@@ -301,7 +324,10 @@ try {
     j->h_contig_name_len.resize(set->n_contigs);
     for (uint32_t c = 0; c < set->n_contigs; c++)
         j->h_contig_name_len[c] = set->contig_name_len ? set->contig_name_len[c] : 0;
-    j->h_contig_off.assign(set->contig_off, set->contig_off + set->n_contigs + 1);
+    if (set->n_contigs)
+        j->h_contig_off.assign(set->contig_off, set->contig_off + set->n_contigs + 1);
+    else
+        j->h_contig_off.assign(1, 0);
 
     // ---- reads: concatenate with one separator after each read
     j->h_seg_start.resize((size_t)set->n_contigs + 1);
@@ -365,13 +391,13 @@ try {
         uint64_t cb = j->h_contig_off[set->n_contigs];
         if ((rc = j->d_contigs_in.alloc(cb + 64)) != GP_OK)
             return fail(rc);
-        if (cb) {
+        if (set->n_contigs && cb > set->contig_off[0]) {
             hipError_t e = hipMemcpy(j->d_contigs_in.p, set->contig_buf + set->contig_off[0],
                                      cb - set->contig_off[0], hipMemcpyHostToDevice);
             if (e != hipSuccess)
                 return fail(hip_fail(e, "upload contigs", __FILE__, __LINE__));
         }
-        if (set->contig_off[0] != 0) {
+        if (set->n_contigs && set->contig_off[0] != 0) {
             uint64_t base = set->contig_off[0];
             for (auto& o : j->h_contig_off)
                 o -= base;
@@ -417,6 +443,7 @@ int gp_job_sync(gp_job* job)
 try {
     if (!job)
         return GP_ERR_INVALID_ARG;
+    GP_HIP(hipSetDevice(job->ctx->device)); // a caller may hold contexts on several GPUs
     GP_HIP(hipStreamSynchronize(job->ctx->stream));
     return GP_OK;
 } GP_CATCH("gp_job_sync")
@@ -470,6 +497,7 @@ int gp_job_ntedit_guard(gp_job* job, int sync)
 try {
     if (!job)
         return GP_ERR_INVALID_ARG;
+    GP_HIP(hipSetDevice(job->ctx->device));
     if (int rcb = need_bc(job, "gp_job_ntedit_guard"))
         return rcb;
     return finish(job, stage_b_guard(job), sync);
@@ -479,6 +507,7 @@ int gp_job_mask(gp_job* job, int sync)
 try {
     if (!job)
         return GP_ERR_INVALID_ARG;
+    GP_HIP(hipSetDevice(job->ctx->device));
     if (int rcb = need_bc(job, "gp_job_mask"))
         return rcb;
     return finish(job, stage_mask(job), sync);
@@ -492,6 +521,7 @@ try {
         set_error("gp_job_sealer: filters have not been built or set");
         return GP_ERR_STATE;
     }
+    GP_HIP(hipSetDevice(job->ctx->device));
     if (int rcb = need_bc(job, "gp_job_sealer"))
         return rcb;
     return finish(job, stage_c_run(job), sync);
@@ -501,6 +531,7 @@ int gp_job_upper(gp_job* job, int sync)
 try {
     if (!job)
         return GP_ERR_INVALID_ARG;
+    GP_HIP(hipSetDevice(job->ctx->device));
     if (int rcb = need_bc(job, "gp_job_upper"))
         return rcb;
     return finish(job, stage_upper(job), sync);

@@ -606,9 +606,20 @@ try {
             // header line = the bytes between the previous newline and the sequence: ">id[ comment]"
             const uint64_t nl = t->start ? t->start - 1 : 0; // the newline that ends the header
             uint64_t hb = nl;
-            uint8_t ch = 0;
-            while (hb > 0 && pread(targets->fd, &ch, 1, (off_t)(hb - 1)) == 1 && ch != '\n')
-                hb--;
+            // walk back to the previous newline (or the start of the file), one pread per 4 KiB
+            for (bool found = false; hb > 0 && !found;) {
+                uint8_t chunk[4096];
+                const uint64_t n = std::min<uint64_t>(hb, sizeof chunk);
+                if (pread(targets->fd, chunk, n, (off_t)(hb - n)) != (ssize_t)n) {
+                    set_error(std::string("cannot read the header of target ") + target_ids[c]);
+                    return GP_ERR_INVALID_ARG;
+                }
+                uint64_t i = n;
+                while (i > 0 && chunk[i - 1] != '\n')
+                    i--;
+                found = i > 0;
+                hb -= n - i;
+            }
             name_len[c] = nl > hb ? (uint32_t)(nl - hb - 1) : 0; // without the '>'
             headers[c].resize(name_len[c]);
             if (name_len[c] && read_exact(targets, hb + 1, name_len[c], (uint8_t*)&headers[c][0]) != GP_OK)
@@ -685,22 +696,42 @@ try {
         return rc;
     FILE* f = std::fopen(path, append ? "ab" : "wb");
     if (!f) {
-        set_error(std::string("cannot write ") + path);
-        return GP_ERR_INVALID_ARG;
+        set_error(std::string("cannot open ") + path + " for writing: " + std::strerror(errno));
+        return GP_ERR_IO;
     }
+    // GoldPolish polishes in /dev/shm, where "no space left" is the usual failure: every write is
+    // checked, and a file that could not be written whole is put back to what it was before
+    // (a new file is removed, an appended one cut back), so that no truncated batch is collected
+    const long before = append ? std::ftell(f) : 0;
+    bool ok = true;
     uint64_t at = 0;
-    for (uint32_t c = 0; c < job->n_contigs; c++) {
+    for (uint32_t c = 0; ok && c < job->n_contigs; c++) {
         if (dropped[c])
             continue;
         const char* nm = names ? names[c] : job->headers[c].c_str();
-        std::fputc('>', f);
-        std::fputs(nm, f);
-        std::fputc('\n', f);
-        std::fwrite(buf.data() + at, 1, lens[c], f);
-        std::fputc('\n', f);
+        ok = std::fputc('>', f) != EOF && std::fputs(nm, f) != EOF && std::fputc('\n', f) != EOF &&
+             std::fwrite(buf.data() + at, 1, lens[c], f) == lens[c] && std::fputc('\n', f) != EOF;
         at += lens[c];
     }
-    std::fclose(f);
+    ok = ok && std::fflush(f) == 0;
+    const int write_errno = errno;
+    if (!ok && append && before >= 0) {
+        if (ftruncate(fileno(f), (off_t)before) != 0) {
+            // nothing more can be done for the file; the status below still reports the failure
+        }
+    }
+    if (std::fclose(f) != 0 && ok) {
+        set_error(std::string("closing ") + path + " failed: " + std::strerror(errno));
+        if (!append)
+            (void)std::remove(path);
+        return GP_ERR_IO;
+    }
+    if (!ok) {
+        if (!append)
+            (void)std::remove(path);
+        set_error(std::string("writing ") + path + " failed: " + std::strerror(write_errno));
+        return GP_ERR_IO;
+    }
     return GP_OK;
 } GP_CATCH("gp_job_write_fasta")
 

@@ -13,10 +13,19 @@
 //
 //   * "position in the concatenated read buffer" IS the serial order, so an
 //     operation's identity is (k index, position).
-//   * Counters never exceed thr and never decrease, and a minimum of thr-1 or thr
-//     both mean "insert".  An operation that sees all of its counters >= thr-1
-//     -- at ANY time, even ahead of its turn, even from a stale read -- inserts
-//     its k-mer and writes nothing ("settled", try_settle).
+//   * Counters never decrease, and no operation lifts a counter past its own
+//     threshold.  Let thr_max be the largest threshold any operation on this
+//     (batch, k) filter uses (contigs of one batch may differ: serve_batch works
+//     the threshold out per target, goldpolish_targeted_bfs.cpp:126-127).  A
+//     minimum of thr_max-1 or thr_max means "insert" for every operation, and
+//     no later decision can tell the two apart, so an operation that sees all
+//     of its counters >= thr_max-1 -- at ANY time, even ahead of its turn, even
+//     from a stale read: a read never shows the future -- inserts its k-mer and
+//     writes nothing ("settled").  With one threshold per filter (bsize = 1)
+//     thr_max is the operation's own threshold.  An operation whose minimum
+//     reaches its OWN thr-1 but not thr_max-1 is not settled: the serial update
+//     lifts those counters to thr, and a later operation with a larger
+//     threshold would see the difference, so it takes its turn like the rest.
 //   * Every other operation takes a deterministic reservation: atomicMin of
 //     (step tag, position) into a hashed slot for each of its counters; in the
 //     next step the operations that hold all their slots are exactly those
@@ -148,33 +157,6 @@ __device__ inline void bf_insert(const AArgs& a, uint32_t stream, const uint64_t
         if (!(*p & bit))
             atomicOr(p, bit);
     }
-}
-
-// One operation whose hash is known.  Returns true when it is finished, false
-// when it has to wait for its turn (then idx[] holds its counter indices).
-__device__ inline bool try_settle(const AArgs& a, uint32_t stream, uint32_t thr, uint32_t k,
-                                  uint64_t base, uint32_t* idx)
-{
-    uint64_t hv[kMaxHash];
-    hv[0] = base;
-    for (uint32_t i = 1; i < a.hash_num; i++)
-        hv[i] = ext_hash(base, k, i);
-    const uint8_t* cb = a.cbf + (uint64_t)stream * a.cbf_stride;
-    uint32_t c[kMaxHash];
-    uint32_t m = 255;
-    for (uint32_t i = 0; i < a.hash_num; i++) {
-        idx[i] = (uint32_t)fastmod(hv[i], a.cbf_mod);
-        c[i] = ctr_load<false>(a, cb, idx[i]);
-        m = min(m, c[i]);
-    }
-    if (m + 1 < thr)
-        return false;
-    // Every counter is already >= thr-1: the k-mer goes in whatever happens before this
-    // operation.  Its own update would only lift counters from thr-1 to thr, and no later
-    // decision can tell those two values apart (a minimum of thr-1 or thr both mean
-    // "insert", and neither is ever incremented from below again), so nothing is written.
-    bf_insert(a, stream, hv);
-    return true;
 }
 
 // A reservation is (tag, position) packed so that atomicMin prefers the newer round first
@@ -338,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
             const uint32_t stream = a.seg_batch[seg] * a.n_k + ki;
             n_ops++;
             // a saturated filter pair answers for itself: every counter is already high enough
-            // for any k-mer to go in, and every bit it could set is set (cbf_check_sat)
+            // for any k-mer of the batch to go in, and every bit it could set is set (cbf_check_sat)
             const uint32_t sat = a.sat[stream];
             if (sat == 3u)
                 continue;
@@ -359,15 +341,16 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
                 op_min[j] = m;
             }
         }
-        // pass 2: settle what can be settled (see try_settle); count what has to wait
+        // pass 2: settle what can be settled (top of the file); count what has to wait
 #pragma unroll
         for (int j = 0; j < kPerThread; j++) {
             if (!op_state[j])
                 continue;
             const uint32_t seg_j = op_seg[j];
-            const uint32_t stream = a.seg_batch[seg_j] * a.n_k + ki;
-            const uint32_t thr = a.seg_thr[seg_j] - 2 + ki;
-            if (op_state[j] == 2u || op_min[j] + 1 >= thr) {
+            const uint32_t batch_j = a.seg_batch[seg_j];
+            const uint32_t stream = batch_j * a.n_k + ki;
+            const uint32_t thr_max = a.batch_thr_max[batch_j] - 2 + ki;
+            if (op_state[j] == 2u || op_min[j] + 1 >= thr_max) { // settled, see the top of the file
                 uint64_t hv[kMaxHash];
                 hv[0] = op_base[j];
                 for (uint32_t i = 1; i < a.hash_num; i++)
@@ -500,8 +483,10 @@ __device__ inline bool round_op(const AArgs& a, const uint4 rec, const uint4 rix
     const uint32_t pos = rec.z;
     const uint32_t ki = rec.w & 7, seg = rec.w >> 3;
     const uint32_t k = a.kc[ki].k;
-    const uint32_t stream = a.seg_batch[seg] * a.n_k + ki;
+    const uint32_t batch = a.seg_batch[seg];
+    const uint32_t stream = batch * a.n_k + ki;
     const uint32_t thr = a.seg_thr[seg] - 2 + ki;
+    const uint32_t thr_max = a.batch_thr_max[batch] - 2 + ki;
     uint32_t idx[kMaxHash] = { rix.x, rix.y, rix.z, rix.w };
     // only four indices travel with the record; the rest are recomputed
     for (uint32_t h = 4; h < a.hash_num; h++)
@@ -532,8 +517,8 @@ __device__ inline bool round_op(const AArgs& a, const uint4 rec, const uint4 rix
             m++;
         }
         insert = m >= thr;
-    } else if (m + 1 >= thr) {
-        insert = true; // settled (see try_settle): no counter needs writing
+    } else if (m + 1 >= thr_max) {
+        insert = true; // settled (top of the file): no counter needs writing
     } else {
         const unsigned long long w = resv_word(tag_next, pos);
         for (uint32_t h = 0; h < a.hash_num; h++)
@@ -700,6 +685,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     const uint32_t stream = b * a.n_k + ki;
     uint8_t* cb = a.cbf + (uint64_t)stream * a.cbf_stride;
     const uint64_t b_start = a.batch_pos[b], b_end = a.batch_pos[b + 1];
+    const uint32_t thr_max = a.batch_thr_max[b] - 2 + ki; // what settling needs, see the top of the file
 
     if (threadIdx.x < 4)
         s_stats[threadIdx.x] = 0;
@@ -790,7 +776,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
                 if (!op_state[j])
                     continue;
                 if (round == 0 || (round & 7u) == 7u) {
-                    // settled (see try_settle): goes in, nothing to write.  Waiting operations
+                    // settled (top of the file): goes in, nothing to write.  Waiting operations
                     // look again every eighth round: a run of one k-mer (a homopolymer) would
                     // otherwise take a round per copy long after its counters are high enough.
                     uint32_t m = 255;
@@ -799,7 +785,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
                                                       : ctr_load<false>(a, cb, op_idx[j][h]);
                         m = min(m, c);
                     }
-                    if (m + 1 >= op_thr[j]) {
+                    if (m + 1 >= thr_max) {
                         uint64_t hv[kMaxHash];
                         hv[0] = op_base[j];
                         for (uint32_t i = 1; i < a.hash_num; i++)

@@ -36,7 +36,8 @@ typedef enum gp_status {
     GP_ERR_STATE = -6,         /* stage called out of order */
     GP_ERR_UNSUPPORTED = -7,   /* parameter outside what the kernels implement */
     GP_ERR_NOT_FOUND = -8,     /* a sequence id is not in the index */
-    GP_ERR_CAPACITY = -9       /* an edited contig outgrew its device slot (gp_job_polish retries by itself) */
+    GP_ERR_CAPACITY = -9,      /* an edited contig outgrew its device slot (gp_job_polish retries by itself) */
+    GP_ERR_IO = -10            /* an output file could not be written whole (it is removed / cut back) */
 } gp_status;
 
 typedef struct gp_ctx gp_ctx; /* one per device */
@@ -190,7 +191,9 @@ int gp_job_get_sequences(gp_job* job, uint8_t* buf, uint64_t buf_bytes);
 int gp_job_get_sequences_device(gp_job* job, void* device_buf, uint64_t buf_bytes);
 /* The job's final FASTA, records in input order, dropped ones left out (what
  * scripts/goldpolish-reaper:51-73 collects).  names[c] = "id[ comment]"; NULL = the header lines of
- * the target file for jobs made by gp_job_create_from_files.  append != 0 appends. */
+ * the target file for jobs made by gp_job_create_from_files.  append != 0 appends.  Every write
+ * is checked: on failure (disk full in /dev/shm ...) the answer is GP_ERR_IO and the file is left
+ * as it was before the call (a new one removed, an appended one cut back). */
 int gp_job_write_fasta(gp_job* job, const char* const* names, const char* path, int append);
 int gp_job_get_counters(gp_job* job, gp_counters* out);
 /* Average device time (ms) of the dominant stage-A kernel's launches since the

@@ -1,0 +1,137 @@
+"""Argument checking and failure behaviour of the C ABI on a machine with a GPU: what
+gp_job_create refuses before it reads an array, empty jobs, and an output file that cannot be
+written whole (GoldPolish polishes in /dev/shm: disk full is the usual failure)."""
+import ctypes as C
+import os
+import resource
+
+import numpy as np
+import pytest
+
+from goldpolish_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gp():
+    from goldpolish_amd import core
+    ctx = core.Context(0)
+    yield core, ctx
+    ctx.close()
+
+
+def _batch_set(core, w, **override):
+    keep = dict(bcb=np.arange(w.n_contigs + 1, dtype=np.uint32), cbuf=np.ascontiguousarray(w.contig_buf),
+                coff=np.ascontiguousarray(w.contig_off, dtype=np.uint64),
+                nlen=np.zeros(max(w.n_contigs, 1), dtype=np.uint32),
+                crb=np.ascontiguousarray(w.contig_read_begin, dtype=np.uint32),
+                thr=np.ascontiguousarray(w.kmer_threshold, dtype=np.uint32),
+                rbuf=np.ascontiguousarray(w.read_buf), roff=np.ascontiguousarray(w.read_off, dtype=np.uint64))
+    bs = core.BatchSet()
+    bs.n_batches = w.n_contigs
+    bs.batch_contig_begin = keep["bcb"].ctypes.data_as(core.u32p)
+    bs.n_contigs = w.n_contigs
+    bs.contig_buf = keep["cbuf"].ctypes.data_as(core.u8p)
+    bs.contig_off = keep["coff"].ctypes.data_as(core.u64p)
+    bs.contig_name_len = keep["nlen"].ctypes.data_as(core.u32p)
+    bs.contig_read_begin = keep["crb"].ctypes.data_as(core.u32p)
+    bs.contig_kmer_threshold = keep["thr"].ctypes.data_as(core.u32p)
+    bs.n_reads = len(keep["roff"]) - 1
+    bs.read_buf = keep["rbuf"].ctypes.data_as(core.u8p)
+    bs.read_off = keep["roff"].ctypes.data_as(core.u64p)
+    for name, value in override.items():
+        setattr(bs, name, value)
+    return bs, keep
+
+
+def _create(core, ctx, bs):
+    h = C.c_void_p()
+    rc = core.lib().gp_job_create(ctx._h, C.byref(core.default_params()), C.byref(bs), C.byref(h))
+    if rc == 0:
+        core.lib().gp_job_destroy(h)
+    return rc, core.lib().gp_last_error().decode()
+
+
+def test_null_and_inconsistent_arrays_are_refused_before_they_are_read(gp):
+    core, ctx = gp
+    w = synth.make_workload([3000, 2000], 10, seed=4)
+    null_u32, null_u64, null_u8 = core.u32p(), core.u64p(), core.u8p()
+    for override, word in [
+            (dict(batch_contig_begin=null_u32), "batch_contig_begin"),
+            (dict(contig_off=null_u64), "NULL arrays"),
+            (dict(contig_read_begin=null_u32), "NULL arrays"),
+            (dict(contig_kmer_threshold=null_u32), "NULL arrays"),
+            (dict(read_off=null_u64), "read_off"),
+            (dict(read_buf=null_u8), "read_buf"),
+            (dict(contig_buf=null_u8), "contig_buf"),
+            (dict(n_reads=1), "exceeds n_reads"),
+            (dict(n_batches=0), "no batches")]:
+        bs, keep = _batch_set(core, w, **override)
+        rc, msg = _create(core, ctx, bs)
+        assert rc == -1 and word in msg, (override, rc, msg)
+    # offsets that run backwards
+    bs, keep = _batch_set(core, w)
+    keep["roff"][2] = keep["roff"][1] - 1
+    rc, msg = _create(core, ctx, bs)
+    assert rc == -1 and "read_off must be non-decreasing" in msg
+    bs, keep = _batch_set(core, w)
+    keep["bcb"][1] = 3
+    rc, msg = _create(core, ctx, bs)
+    assert rc == -1 and "batch_contig_begin" in msg
+    # and the untouched set is fine
+    bs, keep = _batch_set(core, w)
+    assert _create(core, ctx, bs)[0] == 0
+
+
+def test_a_job_without_contigs_or_without_reads_is_legal(gp, oracle):
+    core, ctx = gp
+    # one batch, no contigs, every per-contig array NULL
+    bs = core.BatchSet()
+    bcb = np.zeros(2, dtype=np.uint32)
+    bs.n_batches = 1
+    bs.batch_contig_begin = bcb.ctypes.data_as(core.u32p)
+    assert _create(core, ctx, bs)[0] == 0
+    # contigs but not a single read: empty filters, the path still runs (as the reference's does)
+    w = synth.make_workload([1500, 900], 0, seed=5)
+    assert w.read_off.size == 1
+    with core.Job.from_workload(ctx, core.default_params(), w) as job:
+        job.polish()
+        got = job.sequences()
+    for c in range(2):
+        outs, _, _ = oracle.polish_batch([w.names[c]], [w.contig(c)], [[]], [int(w.kmer_threshold[c])])
+        assert got[c] == outs[0]
+
+
+def test_fasta_that_cannot_be_written_whole_is_an_error_and_leaves_no_partial_file(gp, tmp_path):
+    core, ctx = gp
+    w = synth.make_workload([30000, 20000], 3, seed=6)
+    with core.Job.from_workload(ctx, core.default_params(k_values=[32]), w) as job:
+        job.polish()
+        good = tmp_path / "ok.fa"
+        job.write_fasta(good, names=w.names)
+        want = good.read_bytes()
+        assert want.count(b">") == 2 and len(want) > 50000
+        soft, hard = resource.getrlimit(resource.RLIMIT_FSIZE)
+        try:
+            # the process may not grow a file past 20000 bytes: write() fails with EFBIG
+            # (Python ignores SIGXFSZ), like ENOSPC on a full /dev/shm
+            resource.setrlimit(resource.RLIMIT_FSIZE, (20000, hard))
+            new = tmp_path / "new.fa"
+            with pytest.raises(core.GpError) as e:
+                job.write_fasta(new, names=w.names)
+            assert e.value.code == -10 and "new.fa" in str(e.value)
+            assert not new.exists()
+            app = tmp_path / "app.fa"
+            app.write_bytes(b">x\nACGT\n")
+            with pytest.raises(core.GpError) as e:
+                job.write_fasta(app, names=w.names, append=True)
+            assert e.value.code == -10
+            assert app.read_bytes() == b">x\nACGT\n"
+        finally:
+            resource.setrlimit(resource.RLIMIT_FSIZE, (soft, hard))
+        with pytest.raises(core.GpError) as e:
+            job.write_fasta(tmp_path / "no_such_dir" / "x.fa", names=w.names)
+        assert e.value.code == -10
+        job.write_fasta(app, names=w.names, append=True)
+        assert app.read_bytes() == b">x\nACGT\n" + want

@@ -19,7 +19,8 @@ def test_random_jobs_match_the_oracle(oracle, monkeypatch):
         # (gp_job_polish grows the slots and runs the cascade again); 300029: nearly empty filters,
         # low ratios: a 9 kbp contig leaves the cascade at 42 kbp (the walker's pass count
         # follows the edited length, not the input's)
-        for seed in [1086, 20621, 20645, 300029] + list(range(7000, 7009)):
+        # 400000+: several contigs per batch with different thresholds on small filters
+        for seed in [1086, 20621, 20645, 300029] + list(range(7000, 7009)) + list(range(400000, 400012)):
             for mode in ("0", "1"):
                 monkeypatch.setenv("GP_STAGE_A_LOCAL", mode)
                 assert fuzz_parity.run_case(core, ctx, oracle, seed, mode) is None, (seed, mode)

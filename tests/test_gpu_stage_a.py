@@ -147,6 +147,30 @@ def test_edge_cases_ragged_N_lowercase_repeats_and_shared_batches(gp, oracle):
     run_and_compare(core, ctx, oracle, w, p2)
 
 
+def test_mixed_thresholds_in_one_batch_with_colliding_counters(gp, oracle):
+    """Contigs of one batch share the counting filters but not the threshold
+    (goldpolish_targeted_bfs.cpp:126-131).  With a filter this small their counters collide, so a
+    counter one contig's operation leaves at its thr-1 instead of thr is seen by a later contig
+    with a larger threshold: settling may only use the batch's largest threshold."""
+    core, ctx = gp
+    rng = np.random.default_rng(21)
+    contigs, reads = [], []
+    for i in range(6):
+        g = synth.random_genome(2500, rng)
+        contigs.append(g.tobytes())
+        rs = []
+        for _ in range(24):
+            s0 = int(rng.integers(0, 1500))
+            rs.append(synth.mutate(g[s0:s0 + 1000], 0.04, rng).tobytes())
+        reads.append(rs)
+    for thr in ([4, 5, 7, 9, 11, 13], [13, 4, 9, 5, 12, 6], [4, 13, 4, 13, 4, 13], [6, 6, 6, 7, 6, 6]):
+        w = _custom_workload(contigs, reads, thr)
+        for cbf, bf, ks in [(4099, 1024, [32, 28, 24, 20]), (20011, 4096, [32, 20]), (70001, 8192, [25])]:
+            p = core.default_params(k_values=ks, cbf_bytes=cbf, bf_bytes=bf)
+            run_and_compare(core, ctx, oracle, w, p, batch_contig_begin=[0, 6])
+            run_and_compare(core, ctx, oracle, w, p, batch_contig_begin=[0, 2, 6])
+
+
 def test_threshold_below_4_is_refused(gp):
     core, ctx = gp
     w = _custom_workload([b"ACGT" * 100], [[b"ACGT" * 100]], [3])

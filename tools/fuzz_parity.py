@@ -82,6 +82,16 @@ def random_case(seed):
                  sealer_max_paths=int(rng.choice([1, 2, 10])), sealer_max_branches=int(rng.choice([10, 1000])))
     if rng.random() < 0.3:
         w.kmer_threshold[:] = int(rng.integers(4, 14))
+    if seed >= 400000:
+        # (seeds below keep the cases they always had)  Contigs of one batch with DIFFERENT
+        # thresholds, ascending or interleaved, on small counting filters so that their counters
+        # collide: the settle shortcut of stage A may only use the batch's largest threshold
+        r2 = np.random.default_rng(seed ^ 0x5EED)
+        if r2.random() < 0.7:
+            t = r2.integers(4, 14, size=n)
+            w.kmer_threshold[:] = np.sort(t) if r2.random() < 0.5 else t
+            bcb = [0, n] if r2.random() < 0.6 else sorted(set([0, n, int(r2.integers(0, n + 1))]))
+            sizes = [(4099, 1024), (65536, 8192), (20011, 4096)][int(r2.integers(0, 3))]
     return w, ks, sizes, bcb, extra
 
 
