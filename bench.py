@@ -8,11 +8,14 @@ with reads + contigs already resident in HBM; at N > 1 the step ends with the ga
 polished sequences on rank 0 (RCCL).  W untimed warm-up steps, then exactly K timed steps
 between barrier + synchronize; max over ranks; rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[1]): one synthetic 10 Mbp contig (41 % GC, 1 % draft error)
-+ 30x ONT-like reads (6 % error), k = 32 only, bsize = 1, per GPU (weak scaling: every rank
-polishes its own 10 Mbp contig).  `--workload goldenpath` instead cuts the same 10 Mbp into
-25 kbp contigs (the regime GoldPolish's fixed 10 MiB / 512 KiB filters are sized for) and runs
-the full k cascade; its figures are reported under "aux" by default.
+Workload = the configuration BASELINE.json's metric is quoted on (full k cascade
+{32,28,24,20}) that fits one GPU: configs[2], a synthetic 100 Mbp assembly + 40x ONT-like reads
+(6 % error) per GPU, bsize = 1 (weak scaling: every rank polishes its own 100 Mbp).  The
+assembly is 4000 contigs of 25 kbp: the regime GoldPolish's fixed 10 MiB / 512 KiB filters are
+sized for (the reference's own fixture, tests/goldrush_test_golden_path.fa, holds contigs of
+2-43 kbp); substitutions, indels and gap fills really happen there.  `aux` reports
+configs[1] beside it (one 10 Mbp contig, k = 32 only: its filters saturate, so it measures the
+filter build alone).  --workload picks another one (see WORKLOADS).
 """
 import argparse
 import json
@@ -28,19 +31,49 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ATOMIC_CEILING_GPS = 27.0  # scattered device-scope atomics per ns, measured (tools/probes/atomic_probe.hip)
+RANDOM_RMW_CEILING_GPS = 19.9  # random 1-byte load + store pairs per ns over 16 GiB, measured (tools/probes/random_rmw_probe.hip)
+METRIC = "polished Mbp/sec (whole node), k={32,28,24,20}, 1/2/4/8 MI355X"
+
+WORKLOADS = {
+    # name: (contig lengths, coverage, k list, description)
+    "config3": ([25_000] * 4000, 40, [32, 28, 24, 20],
+                "BASELINE.json configs[2]: synthetic 100 Mbp assembly (4000 x 25 kbp contigs, one per "
+                "batch) + 40x ONT-error reads per GPU, k=32,28,24,20, bsize=1"),
+    "config2": ([10_000_000], 30, [32],
+                "BASELINE.json configs[1]: one synthetic 10 Mbp contig + 30x ONT-error reads per GPU, "
+                "k=32 only, bsize=1"),
+    "goldenpath": ([25_000] * 400, 30, [32, 28, 24, 20],
+                   "10 Mbp as 400 x 25 kbp contigs + 30x reads, k=32,28,24,20"),
+    "tiny": ([200_000], 30, [32], "one 200 kbp contig + 30x reads, k=32"),
+}
+
+
+def fixture_like_lengths(total_bp, seed):
+    """contig lengths with the shape of the reference's fixture (tests/goldrush_test_golden_path.fa:
+    152 contigs, 2 kbp .. 43 kbp, median 7 kbp): log-normal, median 7 kbp, sigma 0.75, clipped"""
+    rng = np.random.default_rng(seed)
+    out, got = [], 0
+    while got < total_bp:
+        n = int(np.clip(rng.lognormal(np.log(7000.0), 0.75), 2000, 45000))
+        out.append(n)
+        got += n
+    return out
 
 
 def make_workload(kind, seed):
     from goldpolish_amd import synth
-    if kind == "config2":
-        return synth.make_workload([10_000_000], 30, seed=seed), [32]
-    if kind == "goldenpath":
-        return synth.make_workload([25_000] * 400, 30, seed=seed), [32, 28, 24, 20]
-    if kind == "config3":   # BASELINE.json configs[2]: 100 Mbp assembly, 40x reads, full cascade
-        return synth.make_workload([25_000] * 4000, 40, seed=seed), [32, 28, 24, 20]
-    if kind == "tiny":
-        return synth.make_workload([200_000], 30, seed=seed), [32]
-    raise SystemExit(f"unknown workload {kind}")
+    if kind == "ragged":   # 20 Mbp of fixture-shaped contigs: thousands of short, ragged batches
+        lens, cov, ks = fixture_like_lengths(20_000_000, seed), 40, [32, 28, 24, 20]
+        desc = "20 Mbp in contigs shaped like the reference's fixture (2-45 kbp, median 7 kbp) + 40x reads, full cascade"
+    elif kind in WORKLOADS:
+        lens, cov, ks, desc = WORKLOADS[kind]
+    else:
+        raise SystemExit(f"unknown workload {kind}")
+    if len(lens) >= 200:
+        w = synth.make_workload_chunked(lens, cov, seed=seed, chunk=50)
+    else:
+        w = synth.make_workload(lens, cov, seed=seed)
+    return w, ks, desc
 
 
 def algorithmic_bytes_per_bp(n_k, hash_num, coverage):
@@ -48,18 +81,16 @@ def algorithmic_bytes_per_bp(n_k, hash_num, coverage):
     return coverage * (1 + n_k * 2 * hash_num) + 6 * n_k + 2
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command, see
-    tools/make_profiles.sh; FETCH_SIZE calibrated 1:1 on classify_kernel's 16 B/lane stream)."""
-    files = sorted((ROOT / "profiles").glob("r*_config2_pmc_traffic.json"))
-    if not files:
-        return None, None
-    t = json.loads(files[-1].read_text()).get("gp::" + kernel)
-    if not t or "FETCH_SIZE" not in t or "WRITE_SIZE" not in t:
-        return None, None
-    per_launch = (t["FETCH_SIZE"]["per_launch_KB"] + t["WRITE_SIZE"]["per_launch_KB"]) * 1024
-    return int(per_launch), f"profiles/{files[-1].name}"
+def pmc_traffic(workload, kernel):
+    """HBM-side bytes per launch of `kernel` from the COMMITTED rocprofv3 PMC passes of this
+    workload (FETCH_SIZE and WRITE_SIZE need separate runs of the command, tools/make_profiles.sh;
+    nothing here is measured by this process).  Newest round first."""
+    for f in sorted((ROOT / "profiles").glob(f"r*_{workload}_pmc_traffic.json"), reverse=True):
+        t = json.loads(f.read_text()).get("gp::" + kernel)
+        if t and "FETCH_SIZE" in t and "WRITE_SIZE" in t:
+            per_launch = (t["FETCH_SIZE"]["per_launch_KB"] + t["WRITE_SIZE"]["per_launch_KB"]) * 1024
+            return int(per_launch), f"profiles/{f.name}"
+    return None, None
 
 
 def gather_to_rank0(lens, payload, rank, world):
@@ -100,27 +131,38 @@ def split_records(lens, payload):
     return out
 
 
-def cpu_baseline(seed):
-    """The oracle (a scalar C port of the reference path) timed on this box's host cores, on a
-    bounded sample of the same kind of workload."""
+def cpu_baseline(w, ks, desc):
+    """The oracle (a C port of the reference path, oracle/) timed on this box's host cores on
+    a bounded sample of the SAME workload: its first contigs, batches in parallel over every
+    core the process may use -- one OpenMP task per batch, each batch serial, which is how the
+    reference spreads batches over threads (goldpolish_targeted_bfs.cpp:189-246,
+    scripts/goldpolish:496-514).  The reference itself cannot be built on this box (btllib,
+    boost); its per-batch process / Python / file overhead is NOT in this number."""
     sys.path.insert(0, str(ROOT / "tests"))
     import subprocess
     import oracle_lib
-    from goldpolish_amd import synth
     so = ROOT / "oracle" / "libgpo.so"
     if not so.exists():
         subprocess.check_call(["make", "-C", str(ROOT / "oracle"), "libgpo.so"])
     O = oracle_lib.Oracle(str(so))
-    sample_bp = 10_000_000      # the whole configs[1] contig: about 20 s of one host core
-    w = synth.make_workload([sample_bp], 30, seed=seed)
-    params = O.batch_params(k_values=(32,))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # about 15 s: a 25 kbp batch of the full cascade costs one core about half a second, a
+    # single long contig (one batch: no batch parallelism to be had) is taken whole
+    n = w.n_contigs if w.n_contigs <= 4 else min(w.n_contigs, 30 * cores)
+    names = w.names[:n]
+    seqs = [w.contig(i) for i in range(n)]
+    reads = [w.reads_of(i) for i in range(n)]
+    thr = [int(x) for x in w.kmer_threshold[:n]]
+    params = O.batch_params(k_values=tuple(ks))
     t = time.perf_counter()
-    O.polish_batch(w.names, [w.contig(0)], [w.reads_of(0)], [int(w.kmer_threshold[0])], params)
+    _, used = O.polish_batches(names, seqs, reads, thr, list(range(n + 1)), params, n_threads=cores)
     dt = time.perf_counter() - t
+    bp = sum(len(s) for s in seqs)
     return {
-        "value": round(w.total_bp / dt / 1e6, 4), "unit": "Mbp/s", "cores": 1, "kind": "port",
-        "sample": f"one {sample_bp} bp contig + 30x reads, k=32, whole path, {dt:.1f} s of the "
-                  "single-threaded C oracle",
+        "value": round(bp / dt / 1e6, 4), "unit": "Mbp/s", "cores": int(min(used, n)), "kind": "port",
+        "sample": f"the first {n} of {w.n_contigs} batches of this workload ({bp} bp + their reads), whole path, "
+                  f"k={','.join(map(str, ks))}, {dt:.1f} s: the C oracle, one OpenMP task per batch on "
+                  f"{used} threads",
     }
 
 
@@ -129,7 +171,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="config2")
+    ap.add_argument("--workload", default="config3")
     ap.add_argument("--no-aux", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl",
@@ -139,6 +181,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    # Synthetic inputs first: the generator forks worker processes, which must happen before
+    # anything in this process touches the GPU.
+    w_main, ks_main, desc_main = make_workload(args.workload, seed=2 + rank)
+    want_aux = world == 1 and rank == 0 and not args.no_aux and args.workload == "config3"
+    aux_in = make_workload("config2", seed=2) if want_aux else None
+
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the polishing core has no CPU fallback")
@@ -152,8 +201,7 @@ def main():
     on_gpu = args.backend == "nccl"
     from goldpolish_amd import core
 
-    def run(kind, steps, warmup, want_roofline):
-        w, ks = make_workload(kind, seed=2 + rank)
+    def run(w, ks, steps, warmup, want_cold):
         params = core.default_params(k_values=ks)
         ctx = core.Context(device_index)
         job = core.Job.from_workload(ctx, params, w)
@@ -190,15 +238,15 @@ def main():
             dt = float(t.item())
         res = {"bp_per_rank": w.total_bp, "dt": dt, "steps": steps, "counters": job.counters(),
                "coverage": float(w.read_off[-1]) / max(w.total_bp, 1), "n_k": len(ks),
-               "n_contigs": w.n_contigs}
-        if want_roofline:
-            kt = {}
-            for name in ("cbf_first_pass", "cbf_round", "cbf_local", "ntedit_scan", "ntedit_walk", "mask", "sealer_bfs", "upper"):
-                ms, n, units = job.kernel_time(name)
-                kt[name] = {"ms": ms, "launches": n, "units": units}
-            res["kernels"] = kt
+               "n_contigs": w.n_contigs, "device_bytes": core.device_bytes_in_use()}
+        kt = {}
+        for name in ("cbf_first_pass", "cbf_round", "cbf_local", "ntedit_scan", "ntedit_walk", "mask",
+                     "sealer_bfs", "upper"):
+            ms, n, units = job.kernel_time(name)
+            kt[name] = {"ms": ms, "launches": n, "units": units}
+        res["kernels"] = kt
         job.close()
-        if want_roofline and rank == 0 and world == 1:
+        if want_cold:
             # the same step with the hand-over included: host buffers -> pinned staging -> HBM
             # (gp_job_create), the path, and the polished bytes copied back to host memory.
             # Reported beside `value`, never as it.
@@ -217,78 +265,91 @@ def main():
         ctx.close()
         return res
 
-    main_res = run(args.workload, args.steps, args.warmup, True)
+    def roofline(res, workload):
+        """SURVEY.md 8d's streaming model for the stage-A kernel the step spends most time in:
+        one launch covers `units` (read base, k) pairs, each priced at 1 B of sequence + H counter
+        reads + H counter writes.  HIP events on the library's stream give the launch time."""
+        k = res["kernels"]
+        H = 4
+        name = max(("cbf_local", "cbf_first_pass"), key=lambda n: k[n]["ms"])
+        kk = k[name]
+        out = {"bound": "hbm", "kernel": name, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        if kk["launches"]:
+            bytes_per_launch = (1 + 2 * H) * kk["units"] / kk["launches"]
+            avg_s = kk["ms"] / kk["launches"] / 1e3
+            achieved = bytes_per_launch / avg_s / 1e9
+        else:
+            bytes_per_launch, avg_s, achieved = 0, 0.0, 0.0
+        traffic, src = pmc_traffic(workload, name)
+        out.update({
+            "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": traffic,
+            "traffic_source": (src + " (committed rocprofv3 PMC passes of this workload; not collected by this run)"
+                               if src else None),
+            "traffic_GBps": (round(traffic / avg_s / 1e9, 1) if traffic and avg_s else None),
+            "alg_bytes_per_launch": int(bytes_per_launch),
+            "avg_launch_ms": round(kk["ms"] / max(kk["launches"], 1), 4),
+            "largest_by_time": max(k, key=lambda n: k[n]["ms"]),
+            "whole_path_alg_GBps": round(
+                algorithmic_bytes_per_bp(res["n_k"], H, res["coverage"]) * res["bp_per_rank"] * res["steps"]
+                / res["dt"] / 1e9, 2),
+            "kernel_ms_per_run": {n: round(v["ms"], 3) for n, v in k.items()},
+        })
+        c = res["counters"]
+        if name == "cbf_local" and kk["ms"]:
+            # what bounds this kernel: every counter touch is a random 1-byte read-modify-write
+            # in a 10 MiB array nobody else shares; the probe gives the chip's rate for that
+            touches = c["a_ops"] * H
+            rate = touches / (kk["ms"] / 1e3) / 1e9
+            out["random_rmw"] = {"counter_touches_per_step": touches, "achieved_G_per_s": round(rate, 2),
+                                 "measured_ceiling_G_per_s": RANDOM_RMW_CEILING_GPS,
+                                 "frac": round(rate / RANDOM_RMW_CEILING_GPS, 3)}
+        resv = c.get("a_reservations", 0)
+        span_ms = k["cbf_round"]["ms"]
+        if resv and span_ms:
+            # the grid-wide schedule is bound by scattered device-scope atomics (27 G/s on this
+            # chip whatever their width, scope or target: tools/probes/atomic_probe.hip)
+            rate = resv / (span_ms / 1e3) / 1e9
+            out["atomics"] = {"reservation_atomics_per_step": resv, "stage_a_ms": round(span_ms, 3),
+                              "achieved_G_per_s": round(rate, 2), "measured_ceiling_G_per_s": ATOMIC_CEILING_GPS,
+                              "frac": round(rate / ATOMIC_CEILING_GPS, 3)}
+        return out
+
+    main_res = run(w_main, ks_main, args.steps, args.warmup, rank == 0 and world == 1)
     total_bp = main_res["bp_per_rank"] * world
     value = total_bp * args.steps / main_res["dt"] / 1e6
     line = {
-        "metric": "polished Mbp/sec (whole node), k={32,28,24,20}, 1/2/4/8 MI355X",
+        "metric": METRIC,
         "value": round(value, 3), "unit": "Mbp/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(main_res["dt"] / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
         "data": "synthetic",
         "config": {
-            "workload": ("BASELINE.json configs[1]: one synthetic 10 Mbp contig + 30x ONT-error "
-                         "reads per GPU, k=32 only, bsize=1" if args.workload == "config2"
-                         else args.workload),
+            "workload": desc_main,
             "contigs_per_gpu": main_res["n_contigs"], "bp_per_gpu": main_res["bp_per_rank"],
-            "read_coverage": round(main_res["coverage"], 2), "k": "32" if main_res["n_k"] == 1 else "32,28,24,20",
+            "read_coverage": round(main_res["coverage"], 2), "k": ",".join(map(str, ks_main)),
             "parallelism": f"batches sharded over {world} GPU(s), gather to rank 0",
+            "device_GiB_in_use": round(main_res["device_bytes"] / 2**30, 1),
         },
     }
     if rank == 0:
-        # roofline of the dominant kernel: stage A's streaming pass (cbf_first_pass).  One
-        # launch covers `units` (read base, k) pairs; SURVEY 8d prices each at 1 B of sequence
-        # + 2H B of counter traffic.
-        k = main_res["kernels"]
-        dom = max(k, key=lambda n: k[n]["ms"])
-        fp = k["cbf_first_pass"]
-        H = 4
-        if fp["launches"]:
-            bytes_per_launch = (1 + 2 * H) * fp["units"] / fp["launches"]
-            avg_s = fp["ms"] / fp["launches"] / 1e3
-            achieved = bytes_per_launch / avg_s / 1e9
-        else:
-            bytes_per_launch, achieved = 0, 0.0
-        traffic, traffic_src = pmc_traffic("cbf_first_pass")
-        line["roofline"] = {
-            "bound": "hbm", "kernel": "cbf_first_pass", "achieved": round(achieved, 2),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": traffic, "traffic_source": traffic_src,
-            "traffic_GBps": (round(traffic / avg_s / 1e9, 1) if traffic and fp["launches"] else None),
-            "alg_bytes_per_launch": int(bytes_per_launch),
-            "avg_launch_ms": round(fp["ms"] / max(fp["launches"], 1), 4),
-            "largest_by_time": dom,
-            "whole_path_alg_GBps": round(
-                algorithmic_bytes_per_bp(main_res["n_k"], H, main_res["coverage"]) * value * 1e6 / 1e9, 2),
-            "kernel_ms_per_run": {n: round(v["ms"], 3) for n, v in k.items()},
-        }
-        # what actually bounds the filter build: scattered device-scope atomics, which this
-        # chip retires at 27 G/s whatever their width, scope or target (tools/probes/
-        # atomic_probe.hip, measured; 64 M atomicMin over 2^16..2^24 slots)
-        resv = main_res["counters"].get("a_reservations", 0)
-        span_ms = k["cbf_round"]["ms"]
-        if resv and span_ms:
-            rate = resv / (span_ms / 1e3) / 1e9
-            line["roofline"]["atomics"] = {
-                "reservation_atomics_per_step": resv, "stage_a_ms": round(span_ms, 3),
-                "achieved_G_per_s": round(rate, 2), "measured_ceiling_G_per_s": ATOMIC_CEILING_GPS,
-                "frac": round(rate / ATOMIC_CEILING_GPS, 3)}
+        line["roofline"] = roofline(main_res, args.workload)
         line["counters"] = main_res["counters"]
         if "pcie_inclusive" in main_res:
             line["pcie_inclusive"] = main_res["pcie_inclusive"]
-    if world == 1 and not args.no_aux and args.workload == "config2":
-        aux = run("goldenpath", max(1, min(args.steps, 3)), 1, True)
-        if rank == 0:
-            line["aux"] = {
-                "workload": "10 Mbp as 400 x 25 kbp contigs + 30x reads, k=32,28,24,20 "
-                            "(filters in their design regime: edits and gap fills happen)",
-                "value": round(aux["bp_per_rank"] * aux["steps"] / aux["dt"] / 1e6, 3),
-                "unit": "Mbp/s", "ms_per_step": round(aux["dt"] / aux["steps"] * 1e3, 2),
-                "counters": aux["counters"],
-                "kernel_ms_per_run": {n: round(v["ms"], 3) for n, v in aux["kernels"].items()},
-            }
+    if want_aux:
+        w_aux, ks_aux, desc_aux = aux_in
+        aux = run(w_aux, ks_aux, max(1, min(args.steps, 5)), 1, False)
+        r = roofline(aux, "config2")
+        line["aux"] = {
+            "workload": desc_aux + " (its one pair of 10 MiB / 512 KiB filters saturates, as the "
+                        "reference's would: ntEdit and Sealer find nothing to do, the step is the filter build)",
+            "value": round(aux["bp_per_rank"] * aux["steps"] / aux["dt"] / 1e6, 3),
+            "unit": "Mbp/s", "ms_per_step": round(aux["dt"] / aux["steps"] * 1e3, 2),
+            "roofline": r, "counters": aux["counters"],
+        }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(seed=2)
+        line["cpu_baseline"] = cpu_baseline(w_main, ks_main, desc_main)
     if rank == 0:
         print(json.dumps(line))
     if dist:

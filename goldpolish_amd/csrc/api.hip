@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -405,8 +406,16 @@ try {
     }
 
     // ---- filters
+    // Bloom filters: one per (batch, k), they are results.  Counting filters: an arena of slots,
+    // scratch of the filter build (1024 slots = 10 GiB at GoldPolish's 10 MiB; GP_STAGE_A_SLOTS)
     const uint64_t streams = (uint64_t)set->n_batches * params->n_k;
-    if ((rc = j->d_cbf.alloc(streams * ((params->cbf_bytes + 15) / 16 * 16) + 64)) != GP_OK ||
+    {
+        const char* e = getenv("GP_STAGE_A_SLOTS");
+        uint64_t want = e && *e ? strtoull(e, nullptr, 10) : 1024;
+        want = std::max<uint64_t>(want, params->n_k); // one batch at least
+        j->cbf_slots = (uint32_t)std::min<uint64_t>(streams, want);
+    }
+    if ((rc = j->d_cbf.alloc((uint64_t)j->cbf_slots * ((params->cbf_bytes + 15) / 16 * 16) + 64)) != GP_OK ||
         (rc = j->d_bf.alloc(streams * (params->bf_bytes / 4))) != GP_OK)
         return fail(rc);
     if ((rc = stage_a_prepare(j)) != GP_OK)

@@ -119,7 +119,8 @@ struct gp_job {
     std::vector<uint64_t> h_contig_off;
 
     // ---- filters
-    gp::DevBuf<uint8_t> d_cbf;            // [n_batches][n_k][cbf_bytes]
+    gp::DevBuf<uint8_t> d_cbf;            // arena of cbf_slots counting filters (scratch of stage A, see stage_a.hip)
+    uint32_t cbf_slots = 0;
     gp::DevBuf<uint32_t> d_bf;            // [n_batches][n_k][bf_bytes/4]
 
     // ---- stage A work buffers
@@ -129,6 +130,8 @@ struct gp_job {
     gp::DevBuf<uint32_t> d_sat, d_batch_thr_max; // saturation flags per (batch, k); max threshold per batch
     gp::DevBuf<uint64_t> d_batch_pos;     // [n_batches+1] first read position of each batch
     gp::DevBuf<uint32_t> d_batch_order;   // [n_batches] batches as stage A takes them
+    gp::DevBuf<uint32_t> d_batch_slot;    // [n_batches] first arena slot of a batch of the grid-wide schedule
+    gp::DevBuf<uint32_t> d_queue;         // cbf_local's pair counter
     gp::DevBuf<uint32_t> d_counts;        // ring of per-step list lengths, one 128-B line each
     gp::DevBuf<unsigned long long> d_stats; // device-side gp_counters
     uint64_t window = 0;

@@ -80,7 +80,9 @@ struct AArgs {
     uint32_t* bf;
     uint32_t n_k, hash_num;
     uint64_t cbf_bytes;
-    uint64_t cbf_stride; // bytes per (batch, k) counter array in memory
+    uint64_t cbf_stride; // bytes per counter array (one arena slot) in memory
+    const uint32_t* batch_slot; // per batch: first arena slot of its n_k counter arrays while its group is worked on
+    uint32_t* queue;     // cbf_local: next (batch, k) pair to replay
     uint32_t nib;        // 1: two 4-bit counters per byte (every threshold <= 15)
     uint32_t bf_words;
     FastMod cbf_mod, bf_mod;
@@ -119,6 +121,17 @@ __device__ inline uint32_t resv_slot(const AArgs& a, uint32_t bits, uint32_t str
 {
     uint64_t key = (uint64_t)stream * a.cbf_bytes + idx;
     return (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> (64 - bits));
+}
+
+// The counting filters live in an ARENA of slots, not one array per (batch, k) pair for the whole
+// job: only the Bloom filters are results, a counting filter is scratch for as long as its pair
+// is being replayed (the reference frees its own at the end of serve_batch).  A group of the
+// grid-wide schedule holds n_k slots per batch (batch_slot); a cbf_local workgroup owns one slot
+// for the whole launch.  100 Mbp in 25 kbp contigs = 16 000 pairs = 168 GB of counters at once
+// before; 10 GiB of slots now, whatever the job's size.
+__device__ inline uint8_t* cbf_of(const AArgs& a, uint32_t batch, uint32_t ki)
+{
+    return a.cbf + (uint64_t)(a.batch_slot[batch] + ki) * a.cbf_stride;
 }
 
 // Counters never pass their stream's threshold, and GoldPolish's thresholds are <= 14, so
@@ -328,7 +341,7 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
             op_seg[j] = seg;
             op_state[j] = (sat & 1u) ? 2u : 1u; // 2: counters saturated, only the filter is left
             if (op_state[j] == 1u) {
-                const uint8_t* cb = a.cbf + (uint64_t)stream * a.cbf_stride;
+                const uint8_t* cb = cbf_of(a, a.seg_batch[seg], ki);
                 uint32_t m = a.all_wait ? 0u : 255u;
                 for (uint32_t h = 0; h < a.hash_num; h++) {
                     const uint64_t hv = h ? ext_hash(op_base[j], k, h) : op_base[j];
@@ -409,7 +422,7 @@ __global__ __launch_bounds__(1024) void cbf_check_sat(AArgs a)
     const uint32_t batch = stream / a.n_k, ki = stream % a.n_k;
     const uint32_t need = a.batch_thr_max[batch] - 2 + ki - 1; // thr - 1
     if (!(cur & 1u)) {
-        const uint8_t* cb = a.cbf + (uint64_t)stream * a.cbf_stride;
+        const uint8_t* cb = cbf_of(a, batch, ki);
         uint32_t bad = 0;
         if (a.nib) {
             const uint64_t nbytes = a.cbf_bytes / 2; // whole bytes; an odd last counter below
@@ -497,7 +510,7 @@ __device__ inline bool round_op(const AArgs& a, const uint4 rec, const uint4 rix
     for (uint32_t h = 0; h < a.hash_num; h++)
         mine &= (ld<FRESH>(&resv_in[resv_slot(a, bits_in, stream, idx[h])]) == want);
 
-    uint8_t* cb = a.cbf + (uint64_t)stream * a.cbf_stride;
+    uint8_t* cb = cbf_of(a, batch, ki);
     uint32_t c[kMaxHash], m = 255;
     for (uint32_t h = 0; h < a.hash_num; h++) {
         c[h] = ctr_load<FRESH>(a, cb, idx[h]);
@@ -665,6 +678,19 @@ __global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
 // operation of its tile on any of its counters, so the values loaded for the settle test
 // are still the current ones: in a sparse filter an operation costs its four counter
 // loads and the stores, nothing else.  The kernel is bound by those random line fetches.
+// A fresh counting filter for the pair a cbf_local workgroup takes next.  The slot is that
+// workgroup's alone; its stores are visible to its own waves after the next workgroup barrier
+// (one CU, one L1).  Kept out of line, and the statistics flushed per pair: inlined, or with
+// counters alive across it, the kernel needs 133 VGPRs instead of 127 and loses its fourth
+// workgroup per CU (-15 % on 400 x 25 kbp).
+__device__ __attribute__((noinline)) void zero_slot(uint8_t* cb, uint64_t bytes)
+{
+    uint4* z = reinterpret_cast<uint4*>(cb);
+    const uint64_t n16 = bytes / 16;
+    for (uint64_t i = threadIdx.x; i < n16; i += blockDim.x)
+        z[i] = make_uint4(0, 0, 0, 0);
+}
+
 constexpr int kLTile = 512;            // positions per tile: with the 32 KB table four workgroups share a CU,
 constexpr int kLPer = 2;               // each in another phase (hash / load / order / store); 1024-position
 constexpr int kLBlock = kLTile / kLPer; // tiles with a 64 KB table (two workgroups per CU) ran 5 % slower
@@ -672,25 +698,39 @@ constexpr int kLocalSlotBits = 12;
 constexpr int kLocalSlots = 1 << kLocalSlotBits; // >= 2 x the counter touches of a tile (hash_num <= 4)
 constexpr uint32_t kLocalEmpty = 0xFFFFFFFFu;
 
-__global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, uint32_t n_local)
+__global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, uint32_t n_pairs) // 4 workgroups per CU: <= 128 VGPRs
 {
     __shared__ uint8_t codes[kLTile + kHalo];
     __shared__ uint32_t keys[kLocalSlots]; // counter index held by the slot
     __shared__ uint32_t vals[kLocalSlots]; // earliest waiting operation of the tile on that counter
     __shared__ unsigned long long s_stats[4];
-    const uint32_t b = a.batch_order[first + blockIdx.x / a.n_k];
-    const uint32_t ki = blockIdx.x % a.n_k;
+    // This workgroup's arena slot for the whole launch: the counting filter of whichever pair it
+    // is replaying.  Pairs come from a queue (longest batches first), so the grid is as large as
+    // the chip holds and no larger, and a short pair's workgroup goes on to the next one instead
+    // of leaving its CU idle.  Every workgroup reaches the end of the queue and exits.
+    uint8_t* const cb = a.cbf + (uint64_t)blockIdx.x * a.cbf_stride;
+    __shared__ uint32_t s_pair;
+    if (threadIdx.x < 4)
+        s_stats[threadIdx.x] = 0;
+    const int t0 = threadIdx.x * kLPer;
+
+    for (;;) {
+    uint32_t n_ops = 0, n_ordered = 0, n_positions = 0, n_rounds = 0;
+    __syncthreads(); // the previous pair is finished by every wave
+    if (threadIdx.x == 0)
+        s_pair = atomicAdd(a.queue, 1u);
+    __syncthreads();
+    const uint32_t pair = s_pair;
+    if (pair >= n_pairs)
+        break;
+    const uint32_t b = a.batch_order[first + pair / a.n_k];
+    const uint32_t ki = pair % a.n_k;
     const KConsts& kc = a.kc[ki];
     const uint32_t k = kc.k;
     const uint32_t stream = b * a.n_k + ki;
-    uint8_t* cb = a.cbf + (uint64_t)stream * a.cbf_stride;
     const uint64_t b_start = a.batch_pos[b], b_end = a.batch_pos[b + 1];
     const uint32_t thr_max = a.batch_thr_max[b] - 2 + ki; // what settling needs, see the top of the file
-
-    if (threadIdx.x < 4)
-        s_stats[threadIdx.x] = 0;
-    uint32_t n_ops = 0, n_ordered = 0, n_positions = 0, n_rounds = 0;
-    const int t0 = threadIdx.x * kLPer;
+    zero_slot(cb, a.cbf_stride);
 
     for (uint64_t tile0 = b_start; tile0 < b_end; tile0 += kLTile) {
         const uint64_t tile_end = min(b_end, tile0 + (uint64_t)kLTile);
@@ -866,6 +906,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     atomicAdd(&s_stats[1], (unsigned long long)n_ops);
     atomicAdd(&s_stats[2], (unsigned long long)n_ordered);
     atomicAdd(&s_stats[3], (unsigned long long)n_rounds);
+    } // next pair
     __syncthreads();
     if (threadIdx.x < 4 && s_stats[threadIdx.x])
         atomicAdd(&a.stats[threadIdx.x], s_stats[threadIdx.x]);
@@ -962,7 +1003,8 @@ int stage_a_prepare(gp_job* job)
         (rc = job->d_batch_order.alloc(job->n_batches)) != GP_OK)
         return rc;
     if ((rc = job->d_sat.alloc((uint64_t)job->n_batches * p.n_k)) != GP_OK ||
-        (rc = job->d_batch_thr_max.alloc(job->n_batches)) != GP_OK)
+        (rc = job->d_batch_thr_max.alloc(job->n_batches)) != GP_OK ||
+        (rc = job->d_batch_slot.alloc(job->n_batches)) != GP_OK || (rc = job->d_queue.alloc(32)) != GP_OK)
         return rc;
     {
         std::vector<uint32_t> tm(job->n_batches, 4);
@@ -1040,6 +1082,8 @@ int stage_a_run(gp_job* job)
     a.stats = job->d_stats.p;
     a.sat = job->d_sat.p;
     a.batch_thr_max = job->d_batch_thr_max.p;
+    a.batch_slot = job->d_batch_slot.p;
+    a.queue = job->d_queue.p;
     a.host_ring = job->h_count_pinned;
     a.tail_max = (uint32_t)env_u64("GP_STAGE_A_TAIL", 4096);
 
@@ -1048,10 +1092,10 @@ int stage_a_run(gp_job* job)
     job->t_local.reset();
     job->counters.a_rounds = 0;
 
-    // fresh filters + free reservation tables
-    GP_HIP(hipMemsetAsync(job->d_cbf.p, 0,
-                          std::min<uint64_t>(job->d_cbf.n, (uint64_t)job->n_batches * p.n_k * a.cbf_stride + 8), s));
+    // fresh filters + free reservation tables (the counting-filter arena is cleared slot by slot,
+    // by whoever takes a slot: cbf_local's workgroups, and every group of the grid-wide schedule)
     GP_HIP(hipMemsetAsync(job->d_bf.p, 0, job->d_bf.n * sizeof(uint32_t), s));
+    GP_HIP(hipMemsetAsync(job->d_queue.p, 0, job->d_queue.n * sizeof(uint32_t), s));
     GP_HIP(hipMemsetAsync(job->d_stats.p, 0, 16 * sizeof(unsigned long long), s));
     GP_HIP(hipMemsetAsync(job->d_sat.p, 0, job->d_sat.n * sizeof(uint32_t), s));
     GP_HIP(hipMemsetAsync(job->d_counts.p, 0, job->d_counts.n * sizeof(uint32_t), s));
@@ -1105,11 +1149,30 @@ int stage_a_run(gp_job* job)
                 order.push_back(bi);
         }
         n_big = (uint32_t)order.size();
+        // the queue of cbf_local hands out the longest batches first: the last workgroups to
+        // finish then work on short ones
+        std::stable_sort(small.begin(), small.end(), [&](uint32_t x, uint32_t y) {
+            return batch_pos[x + 1] - batch_pos[x] > batch_pos[y + 1] - batch_pos[y];
+        });
         order.insert(order.end(), small.begin(), small.end());
     }
     GP_HIP(hipMemcpyAsync(job->d_batch_order.p, order.data(), order.size() * sizeof(uint32_t),
                           hipMemcpyHostToDevice, s));
-    GP_HIP(hipStreamSynchronize(s)); // batch_pos and order are locals
+    // Arena slots of the grid-wide groups: a group is a run of consecutive entries of `order`,
+    // batch i of the group holds slots [i * n_k, (i + 1) * n_k).  The grouping below depends on
+    // nothing but these sizes, so the whole table is known now.
+    const uint32_t group_cap = (uint32_t)std::max<uint64_t>(
+        1, std::min<uint64_t>({ std::max<uint64_t>(1, env_u64("GP_STAGE_A_GROUP", 2048)),
+                                std::max<uint64_t>(1, job->window / kTile),
+                                std::max<uint64_t>(1, job->cbf_slots / p.n_k) }));
+    {
+        std::vector<uint32_t> slot(job->n_batches, 0);
+        for (uint32_t i = 0; i < n_big; i++)
+            slot[order[i]] = (i % group_cap) * p.n_k;
+        GP_HIP(hipMemcpyAsync(job->d_batch_slot.p, slot.data(), slot.size() * sizeof(uint32_t),
+                              hipMemcpyHostToDevice, s));
+        GP_HIP(hipStreamSynchronize(s)); // batch_pos, order and slot are locals
+    }
     a.batch_order = job->d_batch_order.p;
     const uint32_t n_local = job->n_batches - n_big;
     if (n_local) {
@@ -1119,7 +1182,15 @@ int stage_a_run(gp_job* job)
         int rc0 = job->t_local.begin(s, units);
         if (rc0 != GP_OK)
             return rc0;
-        hipLaunchKernelGGL(cbf_local, dim3(n_local * p.n_k), dim3(kLBlock), 0, s, a, n_big, n_local);
+        // as many workgroups as the chip holds at once (each owns one arena slot), never more than
+        // there are slots or pairs
+        int per_cu = 0;
+        GP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cbf_local, kLBlock, 0));
+        per_cu = std::max(1, std::min<int>(per_cu, (int)env_u64("GP_STAGE_A_LOCAL_PER_CU", 8)));
+        const uint64_t n_pairs = (uint64_t)n_local * p.n_k;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(
+            { n_pairs, (uint64_t)per_cu * (uint64_t)job->ctx->prop.multiProcessorCount, (uint64_t)job->cbf_slots });
+        hipLaunchKernelGGL(cbf_local, dim3(grid), dim3(kLBlock), 0, s, a, n_big, (uint32_t)n_pairs);
         GP_HIP(hipGetLastError());
         if ((rc0 = job->t_local.end(s)) != GP_OK)
             return rc0;
@@ -1135,7 +1206,6 @@ int stage_a_run(gp_job* job)
     const double wait_cap = (double)env_u64("GP_STAGE_A_WAITCAP", 3000000); // operations expected to wait, per step
     const double slot_mul = (double)env_u64("GP_STAGE_A_SLOTS_PER_RESV", 8);
     const bool allow_skip = env_u64("GP_STAGE_A_SKIP_LOOKUP", 1) != 0;
-    const uint32_t group_max = (uint32_t)std::max<uint64_t>(1, env_u64("GP_STAGE_A_GROUP", 2048));
     const uint64_t max_pending = job->window * p.n_k; // list capacity, operations
     const uint64_t tag_max = 0xFFFFFFFFull, tail_span = 1ull << 22;
 
@@ -1238,8 +1308,10 @@ int stage_a_run(gp_job* job)
     // sees only a sliver of its reads per step, yet a step still holds enough operations to
     // fill the chip.  A group of one batch degenerates to consecutive slices of that batch.
     for (uint32_t g_first = 0; g_first < n_big;) {
-        uint32_t g_n = std::min<uint32_t>(group_max, n_big - g_first);
-        g_n = (uint32_t)std::min<uint64_t>(g_n, std::max<uint64_t>(1, job->window / kTile));
+        const uint32_t g_n = std::min<uint32_t>(group_cap, n_big - g_first);
+        // the group's counting filters start from zero; stream `s` is behind the previous
+        // group's tail (and behind cbf_local) here, and every later step waits for `s`
+        GP_HIP(hipMemsetAsync(job->d_cbf.p, 0, (uint64_t)g_n * p.n_k * a.cbf_stride, s));
         uint64_t longest = 0;
         for (uint32_t gi = g_first; gi < g_first + g_n; gi++)
             longest = std::max(longest, batch_pos[order[gi] + 1] - batch_pos[order[gi]]);

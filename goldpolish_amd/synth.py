@@ -148,3 +148,54 @@ def make_workload(contig_lens, coverage: float, seed: int, draft_err: float = 0.
         kmer_threshold=np.asarray(thresholds, dtype=np.uint32),
         truth=truths if keep_truth else None,
     )
+
+
+def _chunk_job(args):
+    lens, coverage, seed, kw = args
+    return make_workload(lens, coverage, seed, **kw)
+
+
+def concat_workloads(parts) -> Workload:
+    """Several workloads as one (contigs renumbered in order); every contig stays its own batch."""
+    names, n_reads = [], 0
+    cbuf, rbuf, coff, roff, crb, thr = [], [], [np.zeros(1, np.uint64)], [np.zeros(1, np.uint64)], \
+        [np.zeros(1, np.uint32)], []
+    c_at = r_at = 0
+    for w in parts:
+        for _ in w.names:
+            names.append(f"contig{len(names):06d}")
+        cbuf.append(w.contig_buf)
+        rbuf.append(w.read_buf)
+        coff.append(w.contig_off[1:] + np.uint64(c_at))
+        roff.append(w.read_off[1:] + np.uint64(r_at))
+        crb.append(w.contig_read_begin[1:] + np.uint32(n_reads))
+        thr.append(w.kmer_threshold)
+        c_at += int(w.contig_off[-1])
+        r_at += int(w.read_off[-1])
+        n_reads += len(w.read_off) - 1
+    return Workload(names=names, contig_buf=np.concatenate(cbuf) if cbuf else np.zeros(0, np.uint8),
+                    contig_off=np.concatenate(coff), read_buf=np.concatenate(rbuf) if rbuf else np.zeros(0, np.uint8),
+                    read_off=np.concatenate(roff), contig_read_begin=np.concatenate(crb),
+                    kmer_threshold=np.concatenate(thr) if thr else np.zeros(0, np.uint32))
+
+
+def make_workload_chunked(contig_lens, coverage: float, seed: int, chunk: int = 100, workers: int = 0,
+                          **kw) -> Workload:
+    """make_workload for large assemblies: the contigs are cut into runs of `chunk`, each run is
+    generated by make_workload with its own seed (seed * 1000003 + run), in `workers` processes
+    (0 = one per core the process may use; started by fork, so call this BEFORE anything touches
+    the GPU).  The result depends on (contig_lens, coverage, seed, chunk) only, never on the
+    number of workers."""
+    import multiprocessing as mp
+    import os
+    lens = [int(x) for x in contig_lens]
+    jobs = [(lens[i:i + chunk], coverage, seed * 1000003 + i // chunk, kw) for i in range(0, len(lens), chunk)]
+    if workers <= 0:
+        workers = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    workers = max(1, min(workers, len(jobs)))
+    if workers == 1:
+        parts = [_chunk_job(j) for j in jobs]
+    else:
+        with mp.get_context("fork").Pool(workers) as pool:
+            parts = pool.map(_chunk_job, jobs, chunksize=1)
+    return concat_workloads(parts)

@@ -167,6 +167,18 @@ int gpo_polish_batch(const gpo_batch_params* bp, unsigned n_contigs, const char*
                      const uint64_t* read_lens, const uint32_t* kmer_threshold /* per contig */,
                      char** out_seq, uint64_t* out_len, uint8_t** out_bfs /* nk, optional */,
                      gpo_batch_stats* st);
+/* Many batches the way the reference runs them on a multi-core host: one OpenMP task per batch
+ * in the filter server (serve, goldpolish_targeted_bfs.cpp:189-246) and one polishing worker per
+ * batch (scripts/goldpolish:496-514), i.e. batches in parallel, each batch serial.  Batch b holds
+ * contigs [batch_contig_begin[b], batch_contig_begin[b+1]); read_begin indexes the one global
+ * read list.  n_threads <= 0: every core OpenMP sees.  Returns 0, or the first failing batch's
+ * code; *threads_used reports the team size.  This is bench.py's `cpu_baseline` leg. */
+int gpo_polish_batches(const gpo_batch_params* bp, unsigned n_batches,
+                       const uint32_t* batch_contig_begin, const char* const* names,
+                       const char* const* seqs, const uint64_t* lens, const uint32_t* read_begin,
+                       const char* const* read_seqs, const uint64_t* read_lens,
+                       const uint32_t* kmer_threshold, char** out_seq, uint64_t* out_len,
+                       int n_threads, int* threads_used);
 void gpo_free(void* p);
 
 #ifdef __cplusplus

@@ -12,6 +12,9 @@
 
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 void gpo_batch_default_params(gpo_batch_params* p)
 {
@@ -170,4 +173,53 @@ int gpo_polish_batch(const gpo_batch_params* bp, unsigned n_contigs, const char*
     free(cur_len);
     free(dropped);
     return 0;
+}
+
+int gpo_polish_batches(const gpo_batch_params* bp, unsigned n_batches,
+                       const uint32_t* batch_contig_begin, const char* const* names,
+                       const char* const* seqs, const uint64_t* lens, const uint32_t* read_begin,
+                       const char* const* read_seqs, const uint64_t* read_lens,
+                       const uint32_t* kmer_threshold, char** out_seq, uint64_t* out_len,
+                       int n_threads, int* threads_used)
+{
+    int rc_all = 0, team = 1;
+#ifdef _OPENMP
+    if (n_threads <= 0)
+        n_threads = omp_get_max_threads();
+#pragma omp parallel num_threads(n_threads)
+    {
+#pragma omp single
+        team = omp_get_num_threads();
+#pragma omp for schedule(dynamic, 1)
+        for (unsigned b = 0; b < n_batches; b++) {
+            const uint32_t c0 = batch_contig_begin[b], c1 = batch_contig_begin[b + 1];
+            if (c1 == c0)
+                continue;
+            /* read_begin holds indices into the global read list, so the sub-arrays line up */
+            int rc = gpo_polish_batch(bp, c1 - c0, names + c0, seqs + c0, lens + c0, read_begin + c0,
+                                      read_seqs, read_lens, kmer_threshold + c0, out_seq + c0,
+                                      out_len + c0, NULL, NULL);
+            if (rc != 0) {
+#pragma omp critical
+                if (rc_all == 0)
+                    rc_all = rc;
+            }
+        }
+    }
+#else
+    (void)n_threads;
+    for (unsigned b = 0; b < n_batches; b++) {
+        const uint32_t c0 = batch_contig_begin[b], c1 = batch_contig_begin[b + 1];
+        if (c1 == c0)
+            continue;
+        int rc = gpo_polish_batch(bp, c1 - c0, names + c0, seqs + c0, lens + c0, read_begin + c0,
+                                  read_seqs, read_lens, kmer_threshold + c0, out_seq + c0,
+                                  out_len + c0, NULL, NULL);
+        if (rc != 0 && rc_all == 0)
+            rc_all = rc;
+    }
+#endif
+    if (threads_used)
+        *threads_used = team;
+    return rc_all;
 }

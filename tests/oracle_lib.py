@@ -104,6 +104,11 @@ class Oracle:
             u32p, C.POINTER(C.c_char_p), u64p, u32p, C.POINTER(C.c_void_p), u64p,
             C.POINTER(u8p), C.POINTER(BatchStats)]
         L.gpo_free.argtypes = [C.c_void_p]
+        L.gpo_polish_batches.restype = C.c_int
+        L.gpo_polish_batches.argtypes = [
+            C.POINTER(BatchParams), C.c_uint, u32p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+            u64p, u32p, C.POINTER(C.c_char_p), u64p, u32p, C.POINTER(C.c_void_p), u64p, C.c_int,
+            C.POINTER(C.c_int)]
 
     # ---- ntHash
     def nthash_all(self, seq, k):
@@ -238,3 +243,39 @@ class Oracle:
             else:
                 outs.append(None)
         return outs, st, bfs
+
+    def polish_batches(self, names, seqs, reads_per_contig, thresholds, batch_contig_begin,
+                       params=None, n_threads=0):
+        """Many batches in parallel (one OpenMP task per batch, each batch serial), as the reference
+        runs them on a multi-core host.  Returns (sequences or None per contig, threads used)."""
+        p = params or self.batch_params()
+        n = len(seqs)
+        seqs = [_b(s) for s in seqs]
+        flat = [_b(r) for rs in reads_per_contig for r in rs]
+        begin = np.zeros(n + 1, dtype=np.uint32)
+        for i, rs in enumerate(reads_per_contig):
+            begin[i + 1] = begin[i] + len(rs)
+        bcb = np.ascontiguousarray(batch_contig_begin, dtype=np.uint32)
+        cn = (C.c_char_p * max(n, 1))(*[_b(x) for x in names])
+        cs = (C.c_char_p * max(n, 1))(*seqs)
+        cl = (C.c_uint64 * max(n, 1))(*[len(s) for s in seqs])
+        nr = len(flat)
+        rs_ = (C.c_char_p * max(nr, 1))(*flat)
+        rl = (C.c_uint64 * max(nr, 1))(*[len(r) for r in flat])
+        th = (C.c_uint32 * max(n, 1))(*thresholds)
+        oseq = (C.c_void_p * max(n, 1))()
+        olen = (C.c_uint64 * max(n, 1))()
+        used = C.c_int(0)
+        rc = self.L.gpo_polish_batches(C.byref(p), len(bcb) - 1, bcb.ctypes.data_as(u32p), cn, cs, cl,
+                                       begin.ctypes.data_as(u32p), rs_, rl, th, oseq, olen,
+                                       int(n_threads), C.byref(used))
+        if rc != 0:
+            raise RuntimeError(f"gpo_polish_batches failed: {rc}")
+        outs = []
+        for i in range(n):
+            if oseq[i]:
+                outs.append(C.string_at(oseq[i], olen[i]))
+                self.L.gpo_free(oseq[i])
+            else:
+                outs.append(None)
+        return outs, used.value

@@ -73,3 +73,24 @@ def test_nothing_is_thrown_across_the_boundary(gplib):
     got = L.gp_rank_reads(1 << 62, ids, ph, ln, 1000, 40.0, order, C.byref(bases))
     assert got == 0 and bases.value == 0
     assert b"gp_rank_reads" in L.gp_last_error()
+
+
+def test_bad_batch_sets_are_refused_without_touching_a_device(gplib):
+    """gp_job_create checks every array before it reads one and before its first HIP call, so
+    the refusals can be exercised here with a stand-in context; a valid set gets past them and
+    fails at the device (no GPU in this container)"""
+    import ctypes as C
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: tests/test_gpu_api.py runs the same list with a real context")
+    import test_gpu_api as t
+    from goldpolish_amd import synth
+
+    class FakeCtx:
+        _mem = C.create_string_buffer(1 << 14)
+        _h = C.cast(_mem, C.c_void_p)
+
+    w = t.check_refusals(gplib, FakeCtx)
+    bs, keep = t._batch_set(gplib, w)
+    rc, msg = t._create(gplib, FakeCtx, bs)
+    assert rc in (-2, -3) and "hipSetDevice" in msg
