@@ -33,7 +33,7 @@ SYMBOLS = [
     "gp_seqindex_entry", "gp_seqindex_find", "gp_seqindex_read", "gp_seqindex_destroy",
     "gp_mappings_load", "gp_mappings_get", "gp_mappings_destroy", "gp_job_create_from_files",
     "gp_target_extract", "gp_target_update_paf", "gp_target_reinsert",
-    "gp_filter_save", "gp_filter_load", "gp_job_write_fasta",
+    "gp_filter_save", "gp_filter_save_btllib", "gp_filter_load", "gp_job_write_fasta",
 ]
 
 
@@ -159,6 +159,7 @@ def load_library(path=None):
     L.gp_target_reinsert.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
     L.gp_job_write_fasta.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_char_p, C.c_int]
     L.gp_filter_save.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64, u8p]
+    L.gp_filter_save_btllib.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64, u8p]
     L.gp_filter_load.argtypes = [C.c_char_p, u32p, u32p, u64p, u8p, C.c_uint64]
     return L
 
@@ -249,9 +250,10 @@ def _bytes(x):
     return x if isinstance(x, bytes) else str(x).encode()
 
 
-def filter_save(path, k, hash_num, data: np.ndarray):
+def filter_save(path, k, hash_num, data: np.ndarray, btllib_header=False):
     d = _arr(data, np.uint8)
-    _check(lib().gp_filter_save(_bytes(path), k, hash_num, d.size, d.ctypes.data_as(u8p)))
+    f = lib().gp_filter_save_btllib if btllib_header else lib().gp_filter_save
+    _check(f(_bytes(path), k, hash_num, d.size, d.ctypes.data_as(u8p)))
 
 
 def filter_load(path):

@@ -471,24 +471,51 @@ void gp_mappings_destroy(gp_mappings* m) { delete m; }
  * subprojects/ntedit/ntedit.cpp:2013-2022 -- in this build's OWN container, not btllib's (that
  * header cannot be pinned here): the line "GPBF1 <k> <hash_num> <bytes>\n", then the
  * filter bytes (bit n -> byte n/8, mask 1 << n%8, the order btllib uses in memory). */
+// header + payload into a new file; every write checked, a file that could not be written whole is removed
+static int write_filter_file(const char* path, const std::string& header, uint64_t bytes, const uint8_t* data)
+{
+    FILE* f = std::fopen(path, "wb");
+    if (!f) {
+        set_error(std::string("cannot open ") + path + " for writing: " + std::strerror(errno));
+        return GP_ERR_IO;
+    }
+    bool ok = std::fwrite(header.data(), 1, header.size(), f) == header.size() &&
+              std::fwrite(data, 1, bytes, f) == bytes && std::fflush(f) == 0;
+    const int e = errno;
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) {
+        (void)std::remove(path);
+        set_error(std::string("writing ") + path + " failed: " + std::strerror(e));
+        return GP_ERR_IO;
+    }
+    return GP_OK;
+}
+
 int gp_filter_save(const char* path, uint32_t k, uint32_t hash_num, uint64_t bytes, const uint8_t* data)
 try {
     if (!path || !data)
         return GP_ERR_INVALID_ARG;
-    FILE* f = std::fopen(path, "wb");
-    if (!f) {
-        set_error(std::string("cannot write ") + path);
-        return GP_ERR_INVALID_ARG;
-    }
-    std::fprintf(f, "GPBF1 %u %u %llu\n", k, hash_num, (unsigned long long)bytes);
-    const bool ok = std::fwrite(data, 1, bytes, f) == bytes;
-    std::fclose(f);
-    if (!ok) {
-        set_error(std::string("short write to ") + path);
-        return GP_ERR_INVALID_ARG;
-    }
-    return GP_OK;
+    return write_filter_file(path, "GPBF1 " + std::to_string(k) + " " + std::to_string(hash_num) + " " +
+                                       std::to_string(bytes) + "\n", bytes, data);
 } GP_CATCH("gp_filter_save")
+
+/* The same filter under the header layout btllib publishes for KmerBloomFilter::save (SURVEY.md
+ * 8a-A7): "[BTLKmerBloomFilter_v2]", the keys bytes / hash_fn / hash_num / k, "[HeaderEnd]", then
+ * the raw bytes (bit n of the filter = byte n/8, mask 1 << n%8, which is how gp_job_get_filter
+ * returns them).  UNPINNED like the reader below: written from the published layout, no btllib
+ * here to read it back. */
+int gp_filter_save_btllib(const char* path, uint32_t k, uint32_t hash_num, uint64_t bytes, const uint8_t* data)
+try {
+    if (!path || !data)
+        return GP_ERR_INVALID_ARG;
+    std::string h = "[BTLKmerBloomFilter_v2]\n";
+    h += "bytes = " + std::to_string(bytes) + "\n";
+    h += "hash_fn = \"ntHash_v2\"\n";
+    h += "hash_num = " + std::to_string(hash_num) + "\n";
+    h += "k = " + std::to_string(k) + "\n";
+    h += "[HeaderEnd]\n";
+    return write_filter_file(path, h, bytes, data);
+} GP_CATCH("gp_filter_save_btllib")
 
 /* Reader for the header SURVEY.md 8a-A7 describes for btllib's own files: a first line
  * "[BTLKmerBloomFilter_v<n>]", then "key = value" lines in any order (bytes, hash_num, k are needed,

@@ -14,18 +14,21 @@
 //   * "position in the concatenated read buffer" IS the serial order, so an
 //     operation's identity is (k index, position).
 //   * Counters never decrease, and no operation lifts a counter past its own
-//     threshold.  Let thr_max be the largest threshold any operation on this
-//     (batch, k) filter uses (contigs of one batch may differ: serve_batch works
-//     the threshold out per target, goldpolish_targeted_bfs.cpp:126-127).  A
-//     minimum of thr_max-1 or thr_max means "insert" for every operation, and
-//     no later decision can tell the two apart, so an operation that sees all
-//     of its counters >= thr_max-1 -- at ANY time, even ahead of its turn, even
-//     from a stale read: a read never shows the future -- inserts its k-mer and
-//     writes nothing ("settled").  With one threshold per filter (bsize = 1)
-//     thr_max is the operation's own threshold.  An operation whose minimum
-//     reaches its OWN thr-1 but not thr_max-1 is not settled: the serial update
-//     lifts those counters to thr, and a later operation with a larger
-//     threshold would see the difference, so it takes its turn like the rest.
+//     threshold.  Contigs of one batch share the filters but not the threshold
+//     (serve_batch works it out per target, goldpolish_targeted_bfs.cpp:126-127), so for
+//     an operation let thr be its own threshold and S the largest threshold of itself and
+//     every LATER operation on the same filter (seg_smax: suffix maximum over the batch's
+//     contigs that have reads; S = thr when bsize = 1).  An operation is "settled" -- its
+//     k-mer goes in, nothing is written, no turn is needed -- when it sees, at ANY time,
+//     even ahead of its turn, even from a stale read (a read never shows the future, and
+//     values only grow), either
+//       (a) all its counters >= thr: that is what the serial update does with them, or
+//       (b) all its counters >= S-1: it and every later operation insert whatever happens,
+//           and the only writes left are lifts from S-1 to S, which no decision of a
+//           later operation (all of them have thresholds <= S) can tell apart.
+//     An operation whose minimum is exactly its own thr-1 while a later contig has a larger
+//     threshold is NOT settled: the serial update lifts those counters to thr and the later
+//     contig's operations see the difference; it takes its turn like everything below thr-1.
 //   * Every other operation takes a deterministic reservation: atomicMin of
 //     (step tag, position) into a hashed slot for each of its counters; in the
 //     next step the operations that hold all their slots are exactly those
@@ -94,7 +97,8 @@ struct AArgs {
     uint64_t tag_cur;    // 32-bit tag the incoming list reserved with
     uint64_t tag_next;   // tag for reservations made by this launch (always smaller: newer wins)
     uint32_t* sat;       // per (batch, k): bit 0 = every counter >= max thr-1, bit 1 = filter all ones
-    const uint32_t* batch_thr_max; // per batch: largest kmer_threshold of its contigs
+    const uint32_t* batch_thr_max; // per batch: largest kmer_threshold of its contigs that have reads
+    const uint32_t* seg_smax;      // per contig: largest kmer_threshold of it and the later contigs of its batch (with reads)
     uint32_t tail_max;   // while draining: lists up to this long are left to the tail kernel
     uint32_t bits_in;    // log2 slots of the table being checked (what the previous step reserved with)
     uint32_t bits_out;   // log2 slots this step reserves with (<= the allocation), see stage_a_run
@@ -362,8 +366,8 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
             const uint32_t seg_j = op_seg[j];
             const uint32_t batch_j = a.seg_batch[seg_j];
             const uint32_t stream = batch_j * a.n_k + ki;
-            const uint32_t thr_max = a.batch_thr_max[batch_j] - 2 + ki;
-            if (op_state[j] == 2u || op_min[j] + 1 >= thr_max) { // settled, see the top of the file
+            const uint32_t thr = a.seg_thr[seg_j] - 2 + ki, smax = a.seg_smax[seg_j] - 2 + ki;
+            if (op_state[j] == 2u || op_min[j] >= thr || op_min[j] + 1 >= smax) { // settled, see the top of the file
                 uint64_t hv[kMaxHash];
                 hv[0] = op_base[j];
                 for (uint32_t i = 1; i < a.hash_num; i++)
@@ -499,7 +503,7 @@ __device__ inline bool round_op(const AArgs& a, const uint4 rec, const uint4 rix
     const uint32_t batch = a.seg_batch[seg];
     const uint32_t stream = batch * a.n_k + ki;
     const uint32_t thr = a.seg_thr[seg] - 2 + ki;
-    const uint32_t thr_max = a.batch_thr_max[batch] - 2 + ki;
+    const uint32_t smax = a.seg_smax[seg] - 2 + ki;
     uint32_t idx[kMaxHash] = { rix.x, rix.y, rix.z, rix.w };
     // only four indices travel with the record; the rest are recomputed
     for (uint32_t h = 4; h < a.hash_num; h++)
@@ -530,7 +534,7 @@ __device__ inline bool round_op(const AArgs& a, const uint4 rec, const uint4 rix
             m++;
         }
         insert = m >= thr;
-    } else if (m + 1 >= thr_max) {
+    } else if (m >= thr || m + 1 >= smax) {
         insert = true; // settled (top of the file): no counter needs writing
     } else {
         const unsigned long long w = resv_word(tag_next, pos);
@@ -729,7 +733,6 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     const uint32_t k = kc.k;
     const uint32_t stream = b * a.n_k + ki;
     const uint64_t b_start = a.batch_pos[b], b_end = a.batch_pos[b + 1];
-    const uint32_t thr_max = a.batch_thr_max[b] - 2 + ki; // what settling needs, see the top of the file
     zero_slot(cb, a.cbf_stride);
 
     for (uint64_t tile0 = b_start; tile0 < b_end; tile0 += kLTile) {
@@ -792,7 +795,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
                 }
                 n_ops++;
                 op_base[j] = fh + rh;
-                op_thr[j] = a.seg_thr[seg] - 2 + ki;
+                op_thr[j] = (a.seg_thr[seg] - 2 + ki) | ((a.seg_smax[seg] - 2 + ki) << 16); // own threshold | S
                 op_state[j] = 1;
                 uint32_t pack = 0;
                 for (uint32_t h = 0; h < 4; h++) { // hash_num <= 4 on this path (stage_a_run)
@@ -825,7 +828,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
                                                       : ctr_load<false>(a, cb, op_idx[j][h]);
                         m = min(m, c);
                     }
-                    if (m + 1 >= thr_max) {
+                    if (m >= (op_thr[j] & 0xFFFFu) || m + 1 >= (op_thr[j] >> 16)) {
                         uint64_t hv[kMaxHash];
                         hv[0] = op_base[j];
                         for (uint32_t i = 1; i < a.hash_num; i++)
@@ -879,7 +882,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
                     c[h] = round == 0 ? (op_c[j] >> (8 * h)) & 255u : ctr_load<false>(a, cb, op_idx[j][h]);
                     m = min(m, c[h]);
                 }
-                const uint32_t thr = op_thr[j];
+                const uint32_t thr = op_thr[j] & 0xFFFFu;
                 if (m < thr) {
                     for (uint32_t h = 0; h < a.hash_num; h++) {
                         bool first = c[h] == m;
@@ -1007,13 +1010,23 @@ int stage_a_prepare(gp_job* job)
         (rc = job->d_batch_slot.alloc(job->n_batches)) != GP_OK || (rc = job->d_queue.alloc(32)) != GP_OK)
         return rc;
     {
-        std::vector<uint32_t> tm(job->n_batches, 4);
-        for (uint32_t bi = 0; bi < job->n_batches; bi++)
-            for (uint32_t c = job->h_batch_contig_begin[bi]; c < job->h_batch_contig_begin[bi + 1]; c++)
-                tm[bi] = std::max(tm[bi], job->h_contig_thr[c]);
+        // thresholds that matter are those of contigs whose reads reach the filter
+        std::vector<uint32_t> tm(job->n_batches, 4), smax(std::max<uint32_t>(job->n_contigs, 1), 4);
+        for (uint32_t bi = 0; bi < job->n_batches; bi++) {
+            uint32_t run = 4;
+            for (uint32_t c = job->h_batch_contig_begin[bi + 1]; c-- > job->h_batch_contig_begin[bi];) {
+                if (job->h_seg_start[c + 1] > job->h_seg_start[c])
+                    run = std::max(run, job->h_contig_thr[c]);
+                smax[c] = run;
+            }
+            tm[bi] = run;
+        }
         if (job->n_batches)
             GP_HIP(hipMemcpy(job->d_batch_thr_max.p, tm.data(), tm.size() * sizeof(uint32_t),
                              hipMemcpyHostToDevice));
+        if ((rc = job->d_seg_smax.alloc(smax.size())) != GP_OK)
+            return rc;
+        GP_HIP(hipMemcpy(job->d_seg_smax.p, smax.data(), smax.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     GP_HIP(hipHostMalloc((void**)&job->h_count_pinned, 4 * kRing * sizeof(uint32_t)));
     for (uint32_t i = 0; i < kRing; i++) {
@@ -1082,6 +1095,7 @@ int stage_a_run(gp_job* job)
     a.stats = job->d_stats.p;
     a.sat = job->d_sat.p;
     a.batch_thr_max = job->d_batch_thr_max.p;
+    a.seg_smax = job->d_seg_smax.p;
     a.batch_slot = job->d_batch_slot.p;
     a.queue = job->d_queue.p;
     a.host_ring = job->h_count_pinned;

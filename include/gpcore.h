@@ -246,6 +246,10 @@ int gp_job_create_from_files(gp_ctx* ctx, const gp_params* params, const gp_seqi
  * "[HeaderEnd]" header as SURVEY.md 8a-A7 lays it out, UNPINNED (no btllib-written file here,
  * SURVEY.md 8f-1).  buf == NULL: header only. */
 int gp_filter_save(const char* path, uint32_t k, uint32_t hash_num, uint64_t bytes, const uint8_t* data);
+/* The same bytes under btllib's published header ("[BTLKmerBloomFilter_v2]" / bytes, hash_fn =
+ * "ntHash_v2", hash_num, k / "[HeaderEnd]"): what a reference-built ntedit-gr / sealer-gr would be
+ * handed as <batch>-k<k>.bf (scripts/goldpolish:36,391-396).  UNPINNED, as the reader is. */
+int gp_filter_save_btllib(const char* path, uint32_t k, uint32_t hash_num, uint64_t bytes, const uint8_t* data);
 int gp_filter_load(const char* path, uint32_t* k, uint32_t* hash_num, uint64_t* bytes, uint8_t* buf,
                    uint64_t buf_bytes);
 

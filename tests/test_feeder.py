@@ -225,3 +225,71 @@ def test_filter_file_btl_style_header(tmp_path):
         (tmp_path / "bad.bf").write_bytes(bad)
         with pytest.raises(core.GpError):
             core.filter_load(tmp_path / "bad.bf")
+
+
+def test_filter_file_written_under_the_btllib_header(tmp_path):
+    """gp_filter_save_btllib: the published layout (UNPINNED), read back by gp_filter_load; and a
+    filter file that cannot be written whole is an error that leaves no file behind"""
+    import resource
+    core = _core()
+    rng = np.random.default_rng(11)
+    data = rng.integers(0, 256, size=70000, dtype=np.uint8)
+    core.filter_save(tmp_path / "7-k32.bf", 32, 4, data, btllib_header=True)
+    raw = (tmp_path / "7-k32.bf").read_bytes()
+    hdr = b'[BTLKmerBloomFilter_v2]\nbytes = 70000\nhash_fn = "ntHash_v2"\nhash_num = 4\nk = 32\n[HeaderEnd]\n'
+    assert raw == hdr + data.tobytes()
+    k, h, got = core.filter_load(tmp_path / "7-k32.bf")
+    assert (k, h) == (32, 4) and np.array_equal(got, data)
+    soft, hard = resource.getrlimit(resource.RLIMIT_FSIZE)
+    try:
+        resource.setrlimit(resource.RLIMIT_FSIZE, (10000, hard))   # write() fails with EFBIG
+        for btl in (False, True):
+            with pytest.raises(core.GpError) as e:
+                core.filter_save(tmp_path / "full.bf", 32, 4, data, btllib_header=btl)
+            assert e.value.code == -10 and not (tmp_path / "full.bf").exists()
+    finally:
+        resource.setrlimit(resource.RLIMIT_FSIZE, (soft, hard))
+
+
+@pytest.mark.gpu
+def test_cpp_host_program_over_the_c_abi(tmp_path):
+    """examples/gp_polish_files.cpp (C++ above include/gpcore.h: index, mappings, batches of -b
+    contigs, polish, FASTA out) writes what the same calls made through the ctypes binding write;
+    jobs cut by -j are appended in input order"""
+    import pathlib
+    import subprocess
+    core = _core()
+    exe = pathlib.Path(core.LIB_PATH).parent / "gp_polish_files"
+    if not exe.exists():
+        subprocess.check_call(["make", "-C", str(pathlib.Path(core.LIB_PATH).parent / "csrc")])
+    w = synth.make_workload([5000, 7000, 250, 3000, 4500], 20, seed=78)
+    fa, fq, paf = tmp_path / "t.fa", tmp_path / "r.fq", tmp_path / "m.paf"
+    rng = np.random.default_rng(6)
+    with open(fa, "wb") as f:
+        for c in range(w.n_contigs):
+            f.write(b">" + w.names[c].encode() + (b" a comment" if c % 2 else b"") + b"\n" + w.contig(c) + b"\n")
+    rows = []
+    with open(fq, "wb") as f:
+        for c in range(w.n_contigs):
+            for j, r in enumerate(w.reads_of(c)):
+                rid = b"r%d_%d" % (c, j)
+                q = bytes(rng.integers(33 + 5, 33 + 30, size=len(r), dtype=np.uint8))
+                f.write(b"@" + rid + b"\n" + r + b"\n+\n" + q + b"\n")
+                rows.append(b"\t".join([rid, b"1", b"0", b"1", b"+", w.names[c].encode(), b"1", b"0", b"1", b"1", b"1", b"60"]))
+    paf.write_bytes(b"\n".join(rows) + b"\n")
+    p = core.default_params(k_values=[32, 24])
+    batches = [[w.names[0], w.names[1]], [w.names[2], w.names[3]], [w.names[4]]]   # -b 2
+    with core.Context(0) as ctx, core.SeqIndex(fa) as ti, core.SeqIndex(fq) as ri, core.Mappings(paf, ti) as m:
+        with core.Job.from_files(ctx, p, ti, ri, m, batches, 40.0) as job:
+            job.polish()
+            job.write_fasta(tmp_path / "py.fa")
+    for extra in ([], ["-j", "0"]):   # -j 0: every batch its own job, appended
+        out = tmp_path / "cpp.fa"
+        r = subprocess.run([str(exe), "-k", "32", "-k", "24", "-b", "2", *extra, str(fa), str(fq), str(paf), str(out)],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert out.read_bytes() == (tmp_path / "py.fa").read_bytes()
+        assert "Gaps closed = " in r.stderr and "No start/goal kmer: " in r.stderr
+    r = subprocess.run([str(exe), str(fa), str(fq), str(tmp_path / "missing.paf"), str(tmp_path / "x.fa")],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "loading the mappings failed" in r.stderr

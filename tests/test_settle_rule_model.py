@@ -5,24 +5,23 @@ takes c = min of its counters; if c < thr the counters equal to c become c + 1 a
 c + 1; the k-mer goes into the Bloom filter iff c >= thr.  Operations of different contigs of a
 batch use different thresholds on the same counters (goldpolish_targeted_bfs.cpp:126-131).
 
-Device shortcut ("settled", goldpolish_amd/csrc/stage_a.hip, top of the file): an operation
-whose counters are all >= S - 1 inserts and writes nothing.  The model shows that S has to be
-the LARGEST threshold used on the filter: with S = the operation's own threshold the set of
-inserted operations differs from the serial one as soon as thresholds are mixed and counters
-collide; with S = the largest it never does."""
+Device shortcut ("settled", goldpolish_amd/csrc/stage_a.hip, top of the file): an operation that
+sees all its counters >= its own thr, or >= S - 1 with S the largest threshold of itself and every
+later operation, inserts and writes nothing.  The model replays random operation streams with that
+shortcut taken whenever it applies and compares the insert decisions with the serial replay; the
+round-1 rule (all counters >= own thr - 1) is shown to fail as soon as thresholds are mixed."""
 import numpy as np
 
 
-def replay(ops, thrs, n_counters, settle):
-    """ops[i] = counter indices, thrs[i] = threshold; settle(i) -> S or None (no shortcut).
+def replay(ops, thrs, n_counters, settled):
+    """ops[i] = counter indices, thrs[i] = threshold; settled(i, c) -> take the shortcut?
     Returns the tuple of insert decisions."""
     cnt = np.zeros(n_counters, dtype=np.int64)
     out = []
     for i, (idx, thr) in enumerate(zip(ops, thrs)):
         c = cnt[idx].min()
-        s = settle(i)
-        if s is not None and c + 1 >= s:
-            out.append(True)          # settled: no counter written
+        if settled(i, c):
+            out.append(True)          # no counter written
             continue
         if c < thr:
             for j in set(idx.tolist()):
@@ -49,21 +48,40 @@ def random_case(rng, n_thr):
     return [kmers[w] for w in which], thrs, n_counters
 
 
-def test_settling_on_the_largest_threshold_equals_the_serial_replay():
+def never(i, c):
+    return False
+
+
+def test_the_device_rule_equals_the_serial_replay():
     rng = np.random.default_rng(1)
-    for _ in range(400):
+    taken = 0
+    for _ in range(600):
+        ops, thrs, n = random_case(rng, int(rng.integers(1, 5)))
+        smax = np.maximum.accumulate(thrs[::-1])[::-1]   # largest threshold from here on
+
+        def rule(i, c):
+            nonlocal taken
+            hit = c >= thrs[i] or c + 1 >= smax[i]
+            taken += hit
+            return hit
+        assert replay(ops, thrs, n, rule) == replay(ops, thrs, n, never)
+    assert taken > 20000   # the shortcut really is exercised
+
+
+def test_the_batch_maximum_alone_is_right_but_settles_less():
+    rng = np.random.default_rng(3)
+    for _ in range(300):
         ops, thrs, n = random_case(rng, int(rng.integers(1, 4)))
-        serial = replay(ops, thrs, n, lambda i: None)
-        assert replay(ops, thrs, n, lambda i: int(thrs.max())) == serial
+        assert replay(ops, thrs, n, lambda i, c: c + 1 >= thrs.max()) == replay(ops, thrs, n, never)
 
 
-def test_settling_on_the_own_threshold_is_only_right_for_one_threshold():
+def test_settling_on_the_own_threshold_minus_one_is_only_right_for_one_threshold():
     rng = np.random.default_rng(2)
     diverged = 0
     for _ in range(300):
         ops, thrs, n = random_case(rng, 1)
-        assert replay(ops, thrs, n, lambda i: int(thrs[i])) == replay(ops, thrs, n, lambda i: None)
+        assert replay(ops, thrs, n, lambda i, c: c + 1 >= thrs[i]) == replay(ops, thrs, n, never)
     for _ in range(300):
         ops, thrs, n = random_case(rng, 2)
-        diverged += replay(ops, thrs, n, lambda i: int(thrs[i])) != replay(ops, thrs, n, lambda i: None)
-    assert diverged > 30   # why the shortcut must not use the operation's own threshold
+        diverged += replay(ops, thrs, n, lambda i, c: c + 1 >= thrs[i]) != replay(ops, thrs, n, never)
+    assert diverged > 30   # round 1's rule: wrong as soon as a batch mixes thresholds

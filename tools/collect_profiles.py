@@ -9,14 +9,14 @@ import pathlib
 import shutil
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 raw = pathlib.Path("gpurun_out/profiles_raw")
 out = pathlib.Path("profiles")
 out.mkdir(exist_ok=True)
-for name in ("config2", "goldenpath"):
+for name in ("config3", "config2", "goldenpath", "probe"):
     for f in glob.glob(str(raw / f"{name}_trace" / "*" / "*kernel_stats.csv")):
         shutil.copy(f, out / f"{rnd}_{name}_kernel_stats.csv")
-for name in ("config2", "goldenpath"):
+for name in ("config3", "config2", "goldenpath", "probe"):
     traffic = {}
     for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         for f in glob.glob(str(raw / f"{name}_{kind}" / "*" / "*counter_collection.csv")):

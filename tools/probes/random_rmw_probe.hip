@@ -43,12 +43,15 @@ void run(const char* name, uint8_t* buf, uint32_t bits, uint64_t n)
     printf("%-22s table 2^%-2u B  %8.3f ms  %7.2f G accesses/s\n", name, bits, best, n / best / 1e6);
 }
 
-int main()
+int main(int argc, char** argv)
 {
+    const uint32_t only = argc > 1 ? (uint32_t)atoi(argv[1]) : 0; // one table size only (the PMC calibration pass uses 34)
     uint8_t* buf; CK(hipMalloc(&buf, (size_t)1 << 34));
     CK(hipMemset(buf, 0, (size_t)1 << 34));
     const uint64_t n = 256ull << 20;
     for (uint32_t bits : {26u, 28u, 30u, 32u, 34u}) {
+        if (only && bits != only)
+            continue;
         run<0>("byte load", buf, bits, n);
         run<1>("byte load + store", buf, bits, n);
     }
