@@ -145,7 +145,10 @@ def cpu_baseline(w, ks, desc):
     if not so.exists():
         subprocess.check_call(["make", "-C", str(ROOT / "oracle"), "libgpo.so"])
     O = oracle_lib.Oracle(str(so))
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # A GPU box hands one GPU's job 16 host cores (the node shows all of them: 256 threads on
+    # the whole job made it slower per thread, 0.43 Mbp/s in 230 s); GP_BENCH_CPU_THREADS overrides.
+    seen = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = int(os.environ.get("GP_BENCH_CPU_THREADS", "0")) or min(seen, 16)
     # about 15 s: a 25 kbp batch of the full cascade costs one core about half a second, a
     # single long contig (one batch: no batch parallelism to be had) is taken whole
     n = w.n_contigs if w.n_contigs <= 4 else min(w.n_contigs, 30 * cores)
@@ -172,6 +175,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="config3")
+    ap.add_argument("--jobs-per-gpu", type=int, default=-1,
+                    help="jobs a rank cuts its batches into and keeps in flight (gp_jobs_polish pipelines the "
+                         "filter build of one behind the rest of another); default: by workload")
     ap.add_argument("--no-aux", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl",
@@ -201,24 +207,33 @@ def main():
     on_gpu = args.backend == "nccl"
     from goldpolish_amd import core
 
-    def run(w, ks, steps, warmup, want_cold):
+    def run(w, ks, steps, warmup, want_cold, n_jobs):
+        """the timed loop over one rank's batches, cut into n_jobs jobs of consecutive contigs"""
         params = core.default_params(k_values=ks)
-        ctx = core.Context(device_index)
-        job = core.Job.from_workload(ctx, params, w)
+        n_jobs = max(1, min(n_jobs, w.n_contigs))
+        cuts = [w.n_contigs * i // n_jobs for i in range(n_jobs + 1)]
+        ctxs = [core.Context(device_index) for _ in range(n_jobs)]
+        jobs = [core.Job(ctxs[i], params, **core.slice_workload(w, cuts[i], cuts[i + 1])) for i in range(n_jobs)]
 
         def step():
-            job.polish(sync=True)
-            # the polished records, packed back to back in one HBM buffer: what rank 0 ends a
-            # step with at every N (at N > 1 the other ranks' buffers arrive next to it)
-            lens, _ = job.lengths()
-            payload = torch.empty(max(int(lens.sum()), 1), dtype=torch.uint8, device="cuda")
-            job.sequences_into_device(payload.data_ptr(), payload.numel())
+            core.polish_jobs(jobs)
+            # the polished records, packed back to back in one HBM buffer in input order: what
+            # rank 0 ends a step with at every N (at N > 1 the other ranks' buffers arrive next to it)
+            lens = [j.lengths()[0] for j in jobs]
+            sizes = [int(l.sum()) for l in lens]
+            payload = torch.empty(max(sum(sizes), 1), dtype=torch.uint8, device="cuda")
+            at = 0
+            for j, n in zip(jobs, sizes):
+                if n:
+                    j.sequences_into_device(payload.data_ptr() + at, n)
+                at += n
             if world > 1:
                 # device-to-device: packed on the GPU, sent from HBM over xGMI
-                lens_t = torch.from_numpy(lens.astype(np.int64)).cuda()
+                all_lens = np.concatenate(lens)
+                lens_t = torch.from_numpy(all_lens.astype(np.int64)).cuda()
                 if not on_gpu:   # rehearsal: the same exchange over host memory
                     lens_t, payload = lens_t.cpu(), payload.cpu()
-                gather_to_rank0(lens_t, payload[:int(lens.sum())], rank, world)
+                gather_to_rank0(lens_t, payload[:sum(sizes)], rank, world)
 
         for _ in range(warmup):
             step()
@@ -236,40 +251,59 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        res = {"bp_per_rank": w.total_bp, "dt": dt, "steps": steps, "counters": job.counters(),
+        counters = {}
+        for j in jobs:
+            for name, v in j.counters().items():
+                counters[name] = counters.get(name, 0) + v
+        res = {"bp_per_rank": w.total_bp, "dt": dt, "steps": steps, "counters": counters,
                "coverage": float(w.read_off[-1]) / max(w.total_bp, 1), "n_k": len(ks),
-               "n_contigs": w.n_contigs, "device_bytes": core.device_bytes_in_use()}
-        kt = {}
-        for name in ("cbf_first_pass", "cbf_round", "cbf_local", "ntedit_scan", "ntedit_walk", "mask",
-                     "sealer_bfs", "upper"):
-            ms, n, units = job.kernel_time(name)
-            kt[name] = {"ms": ms, "launches": n, "units": units}
-        res["kernels"] = kt
-        job.close()
+               "n_contigs": w.n_contigs, "device_bytes": core.device_bytes_in_use(), "n_jobs": n_jobs}
+        names = ("cbf_first_pass", "cbf_round", "cbf_local", "ntedit_scan", "ntedit_walk", "mask", "sealer_bfs", "upper")
+
+        def kernel_times():
+            kt = {n: {"ms": 0.0, "launches": 0, "units": 0} for n in names}
+            for j in jobs:
+                for name in names:
+                    ms, n, units = j.kernel_time(name)
+                    kt[name]["ms"] += ms
+                    kt[name]["launches"] += n
+                    kt[name]["units"] += units
+            return kt
+        res["kernels"] = kernel_times()          # the last timed step, kernels of several jobs side by side
+        if n_jobs > 1:
+            # every job once more, ONE AT A TIME: a launch's own duration with the chip to itself
+            for j in jobs:
+                j.polish(sync=True)
+            res["kernels_alone"] = kernel_times()
+        for j in jobs:
+            j.close()
         if want_cold:
             # the same step with the hand-over included: host buffers -> pinned staging -> HBM
             # (gp_job_create), the path, and the polished bytes copied back to host memory.
             # Reported beside `value`, never as it.
             t0 = time.perf_counter()
-            job2 = core.Job.from_workload(ctx, params, w)
+            jobs2 = [core.Job(ctxs[i], params, **core.slice_workload(w, cuts[i], cuts[i + 1])) for i in range(n_jobs)]
             t1 = time.perf_counter()
-            job2.polish(sync=True)
-            job2.sequences()
+            core.polish_jobs(jobs2)
+            for j in jobs2:
+                j.sequences()
             t2 = time.perf_counter()
-            job2.close()
+            for j in jobs2:
+                j.close()
             res["pcie_inclusive"] = {"value": round(w.total_bp / (t2 - t0) / 1e6, 3), "unit": "Mbp/s",
                                      "upload_ms": round((t1 - t0) * 1e3, 2),
                                      "path_and_download_ms": round((t2 - t1) * 1e3, 2),
                                      "note": "one cold run: job creation (pinned staging + device "
                                              "allocations + PCIe upload) + path + download"}
-        ctx.close()
+        for c in ctxs:
+            c.close()
         return res
 
     def roofline(res, workload):
         """SURVEY.md 8d's streaming model for the stage-A kernel the step spends most time in:
         one launch covers `units` (read base, k) pairs, each priced at 1 B of sequence + H counter
         reads + H counter writes.  HIP events on the library's stream give the launch time."""
-        k = res["kernels"]
+        k = res.get("kernels_alone") or res["kernels"]
         H = 4
         name = max(("cbf_local", "cbf_first_pass"), key=lambda n: k[n]["ms"])
         kk = k[name]
@@ -295,6 +329,13 @@ def main():
                 / res["dt"] / 1e9, 2),
             "kernel_ms_per_run": {n: round(v["ms"], 3) for n, v in k.items()},
         })
+        if "kernels_alone" in res:
+            ks_ = res["kernels"][name]
+            out["measured_on"] = (f"each of the rank's {res['n_jobs']} jobs polished once more, one at a time, after the "
+                                  "timed steps: a launch's duration with the chip to itself (in the timed steps "
+                                  "kernels of different jobs and stages run side by side)")
+            out["avg_launch_ms_in_step"] = round(ks_["ms"] / max(ks_["launches"], 1), 4)
+            out["kernel_ms_in_step"] = {n: round(v["ms"], 3) for n, v in res["kernels"].items()}
         c = res["counters"]
         if name == "cbf_local" and kk["ms"]:
             # what bounds this kernel: every counter touch is a random 1-byte read-modify-write
@@ -315,7 +356,9 @@ def main():
                               "frac": round(rate / ATOMIC_CEILING_GPS, 3)}
         return out
 
-    main_res = run(w_main, ks_main, args.steps, args.warmup, rank == 0 and world == 1)
+    # jobs in flight per GPU: one per ~1000 batches, at most 4 (a job holds 13 GiB of Sealer arenas)
+    n_jobs = args.jobs_per_gpu if args.jobs_per_gpu > 0 else max(1, min(4, w_main.n_contigs // 1000))
+    main_res = run(w_main, ks_main, args.steps, args.warmup, rank == 0 and world == 1, n_jobs)
     total_bp = main_res["bp_per_rank"] * world
     value = total_bp * args.steps / main_res["dt"] / 1e6
     line = {
@@ -328,7 +371,8 @@ def main():
             "workload": desc_main,
             "contigs_per_gpu": main_res["n_contigs"], "bp_per_gpu": main_res["bp_per_rank"],
             "read_coverage": round(main_res["coverage"], 2), "k": ",".join(map(str, ks_main)),
-            "parallelism": f"batches sharded over {world} GPU(s), gather to rank 0",
+            "parallelism": f"batches sharded over {world} GPU(s), {main_res['n_jobs']} job(s) in flight per GPU "
+                           "(gp_jobs_polish), gather to rank 0",
             "device_GiB_in_use": round(main_res["device_bytes"] / 2**30, 1),
         },
     }
@@ -339,7 +383,7 @@ def main():
             line["pcie_inclusive"] = main_res["pcie_inclusive"]
     if want_aux:
         w_aux, ks_aux, desc_aux = aux_in
-        aux = run(w_aux, ks_aux, max(1, min(args.steps, 5)), 1, False)
+        aux = run(w_aux, ks_aux, max(1, min(args.steps, 5)), 1, False, 1)
         r = roofline(aux, "config2")
         line["aux"] = {
             "workload": desc_aux + " (its one pair of 10 MiB / 512 KiB filters saturates, as the "

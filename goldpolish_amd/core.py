@@ -33,7 +33,7 @@ SYMBOLS = [
     "gp_seqindex_entry", "gp_seqindex_find", "gp_seqindex_read", "gp_seqindex_destroy",
     "gp_mappings_load", "gp_mappings_get", "gp_mappings_destroy", "gp_job_create_from_files",
     "gp_target_extract", "gp_target_update_paf", "gp_target_reinsert",
-    "gp_filter_save", "gp_filter_save_btllib", "gp_filter_load", "gp_job_write_fasta",
+    "gp_jobs_polish", "gp_filter_save", "gp_filter_save_btllib", "gp_filter_load", "gp_job_write_fasta",
 ]
 
 
@@ -129,6 +129,7 @@ def load_library(path=None):
                  "gp_job_sealer", "gp_job_upper"):
         getattr(L, name).argtypes = [C.c_void_p, C.c_int]
     L.gp_job_ntedit_pass.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+    L.gp_jobs_polish.argtypes = [C.POINTER(C.c_void_p), C.c_uint32]
     L.gp_job_sync.argtypes = [C.c_void_p]
     L.gp_job_get_filter.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, u8p]
     L.gp_job_set_filters.argtypes = [C.c_void_p, u8p]
@@ -356,6 +357,24 @@ class Mappings:
 
     def __exit__(self, *a):
         self.close()
+
+
+def polish_jobs(jobs):
+    """gp_jobs_polish: every job polished, all of them in flight at once (one context per job)"""
+    arr = (C.c_void_p * max(len(jobs), 1))(*[j._h for j in jobs])
+    _check(lib().gp_jobs_polish(arr, len(jobs)))
+
+
+def slice_workload(w, c0, c1):
+    """keyword arguments of Job() for contigs [c0, c1) of a synth.Workload (one batch per contig)"""
+    r0, r1 = int(w.contig_read_begin[c0]), int(w.contig_read_begin[c1])
+    return dict(contig_buf=w.contig_buf[int(w.contig_off[c0]):int(w.contig_off[c1])],
+                contig_off=w.contig_off[c0:c1 + 1] - w.contig_off[c0],
+                contig_read_begin=w.contig_read_begin[c0:c1 + 1] - w.contig_read_begin[c0],
+                kmer_threshold=w.kmer_threshold[c0:c1],
+                read_buf=w.read_buf[int(w.read_off[r0]):int(w.read_off[r1])],
+                read_off=w.read_off[r0:r1 + 1] - w.read_off[r0],
+                name_len=[len(n) for n in w.names[c0:c1]])
 
 
 class Job:

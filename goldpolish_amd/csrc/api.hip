@@ -4,11 +4,14 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace gp {
@@ -303,6 +306,12 @@ try {
     gp_job* j = new (std::nothrow) gp_job();
     if (!j)
         return GP_ERR_OOM;
+    if (hipHostMalloc((void**)&j->h_readback, 64 * sizeof(unsigned long long)) != hipSuccess) {
+        j->h_readback = nullptr;
+        delete j;
+        set_error("gp_job_create: pinned read-back block allocation failed");
+        return GP_ERR_OOM;
+    }
     j->ctx = ctx;
     j->prm = *params;
     j->n_batches = set->n_batches;
@@ -407,11 +416,11 @@ try {
 
     // ---- filters
     // Bloom filters: one per (batch, k), they are results.  Counting filters: an arena of slots,
-    // scratch of the filter build (1024 slots = 10 GiB at GoldPolish's 10 MiB; GP_STAGE_A_SLOTS)
+    // scratch of the filter build (512 slots = 5 GiB at GoldPolish's 10 MiB; GP_STAGE_A_SLOTS)
     const uint64_t streams = (uint64_t)set->n_batches * params->n_k;
     {
         const char* e = getenv("GP_STAGE_A_SLOTS");
-        uint64_t want = e && *e ? strtoull(e, nullptr, 10) : 1024;
+        uint64_t want = e && *e ? strtoull(e, nullptr, 10) : 512;
         want = std::max<uint64_t>(want, params->n_k); // one batch at least
         j->cbf_slots = (uint32_t)std::min<uint64_t>(streams, want);
     }
@@ -437,6 +446,8 @@ void gp_job_destroy(gp_job* job)
     }
     stage_a_release(job);
     stage_bc_release(job);
+    if (job->h_readback)
+        (void)hipHostFree(job->h_readback);
     job->t_first_pass.destroy();
     job->t_round.destroy();
     job->t_local.destroy();
@@ -546,15 +557,11 @@ try {
     return finish(job, stage_upper(job), sync);
 } GP_CATCH("gp_job_upper")
 
-int gp_job_polish(gp_job* job, int sync)
-try {
-    if (!job)
-        return GP_ERR_INVALID_ARG;
-    GP_HIP(hipSetDevice(job->ctx->device));
-    if (int rcb = need_bc(job, "gp_job_polish"))
-        return rcb;
-    int rc = stage_a_run(job);
-    for (int attempt = 0; rc == GP_OK; attempt++) {
+// everything behind the filter build: ntEdit cascade + guard, mask, Sealer, upper
+static int polish_back(gp_job* job)
+{
+    int rc = GP_OK;
+    for (int attempt = 0;; attempt++) {
         for (uint32_t ki = 0; rc == GP_OK && ki < job->prm.n_k; ki++) {
             if (ki == 0)
                 rc = stage_b_reset(job);
@@ -581,8 +588,112 @@ try {
             break;
         }
     }
+    return rc;
+}
+
+int gp_job_polish(gp_job* job, int sync)
+try {
+    if (!job)
+        return GP_ERR_INVALID_ARG;
+    GP_HIP(hipSetDevice(job->ctx->device));
+    if (int rcb = need_bc(job, "gp_job_polish"))
+        return rcb;
+    int rc = stage_a_run(job);
+    if (rc == GP_OK)
+        rc = polish_back(job);
     return finish(job, rc, sync);
 } GP_CATCH("gp_job_polish")
+
+/* Several jobs (SURVEY.md 8e has batches independent by construction) as a two-stage pipeline.
+ * The stages of the path lean on different parts of the chip -- the filter build on random
+ * memory transactions (it runs at the same speed with two, three or four workgroups per CU), the
+ * ntEdit walk and the Sealer search on latency -- so the filter build of job i + 1 runs beside
+ * the rest of job i.  GP_JOBS_MODE=parallel starts all jobs together on a thread each instead. */
+int gp_jobs_polish(gp_job* const* jobs, uint32_t n_jobs)
+try {
+    if (!jobs || n_jobs == 0) {
+        set_error("gp_jobs_polish: no jobs");
+        return GP_ERR_INVALID_ARG;
+    }
+    for (uint32_t i = 0; i < n_jobs; i++) {
+        if (!jobs[i]) {
+            set_error("gp_jobs_polish: NULL job");
+            return GP_ERR_INVALID_ARG;
+        }
+        for (uint32_t j = 0; j < i; j++)
+            if (jobs[j] == jobs[i] || jobs[j]->ctx == jobs[i]->ctx) {
+                // a context is one stream and may be used by one thread at a time
+                set_error("gp_jobs_polish: every job needs a context of its own");
+                return GP_ERR_INVALID_ARG;
+            }
+    }
+    if (n_jobs == 1)
+        return gp_job_polish(jobs[0], 1);
+    std::vector<int> rc(n_jobs, GP_OK);
+    std::vector<std::string> msg(n_jobs);
+    const char* mode = getenv("GP_JOBS_MODE");
+    if (mode && !std::strcmp(mode, "parallel")) {
+        // every job on a thread of its own, all started together
+        std::vector<std::thread> threads;
+        threads.reserve(n_jobs);
+        for (uint32_t i = 0; i < n_jobs; i++)
+            threads.emplace_back([&, i] {
+                rc[i] = gp_job_polish(jobs[i], 1);
+                if (rc[i] != GP_OK)
+                    msg[i] = gp_last_error(); // the message is per thread: carry it over
+            });
+        for (auto& t : threads)
+            t.join();
+    } else {
+        // Two-stage pipeline over the jobs: one thread builds the filters of job i + 1 while this
+        // one runs everything behind them for job i, each on its job's own stream.
+        std::mutex mu;
+        std::condition_variable cv;
+        uint32_t built = 0;
+        std::thread front([&] {
+            for (uint32_t i = 0; i < n_jobs; i++) {
+                int r = need_bc(jobs[i], "gp_jobs_polish");
+                if (r == GP_OK && hipSetDevice(jobs[i]->ctx->device) != hipSuccess) {
+                    set_error("gp_jobs_polish: hipSetDevice failed");
+                    r = GP_ERR_HIP;
+                }
+                if (r == GP_OK)
+                    r = stage_a_run(jobs[i]); // returns with the filters complete
+                if (r != GP_OK) {
+                    rc[i] = r;
+                    msg[i] = gp_last_error();
+                }
+                {
+                    std::lock_guard<std::mutex> g(mu);
+                    built = i + 1;
+                }
+                cv.notify_all();
+            }
+        });
+        for (uint32_t i = 0; i < n_jobs; i++) {
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return built > i; });
+            }
+            if (rc[i] != GP_OK)
+                continue;
+            int r = hipSetDevice(jobs[i]->ctx->device) == hipSuccess ? polish_back(jobs[i]) : GP_ERR_HIP;
+            if (r == GP_OK)
+                r = gp_job_sync(jobs[i]);
+            if (r != GP_OK) {
+                rc[i] = r;
+                msg[i] = gp_last_error();
+            }
+        }
+        front.join();
+    }
+    for (uint32_t i = 0; i < n_jobs; i++)
+        if (rc[i] != GP_OK) {
+            set_error("job " + std::to_string(i) + ": " + msg[i]);
+            return rc[i];
+        }
+    return GP_OK;
+} GP_CATCH("gp_jobs_polish")
 
 int gp_job_get_filter(gp_job* job, uint32_t batch, uint32_t k_index, uint8_t* out)
 try {

@@ -145,6 +145,11 @@ struct gp_job {
     gp::StageBC* bc = nullptr;
     uint32_t bc_slack = 1; // sequence slots hold len + (len/2 + 4 KiB) * bc_slack bytes
 
+    // small pinned host block the per-stage statistics are read back into: with several jobs in
+    // flight, copies to pageable memory from two host threads went through the runtime's staging
+    // path at the same time; pinned memory is written by the device directly
+    unsigned long long* h_readback = nullptr; // 64 words
+
     gp::KernelTimer t_first_pass, t_round, t_local, t_scan, t_walk, t_bfs, t_mask, t_upper;
     gp_counters counters{};
     bool filters_ready = false;

@@ -1200,10 +1200,20 @@ int stage_a_run(gp_job* job)
         // there are slots or pairs
         int per_cu = 0;
         GP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cbf_local, kLBlock, 0));
-        per_cu = std::max(1, std::min<int>(per_cu, (int)env_u64("GP_STAGE_A_LOCAL_PER_CU", 8)));
+        // Two per CU by default: the kernel is bound by random memory transactions and runs at the
+        // same speed with two, three or four (measured), and two leave LDS and wave slots for the
+        // ntEdit / Sealer kernels of another job (gp_jobs_polish) to run beside it.
+        per_cu = std::max(1, std::min<int>(per_cu, (int)env_u64("GP_STAGE_A_LOCAL_PER_CU", 2)));
         const uint64_t n_pairs = (uint64_t)n_local * p.n_k;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(
+        uint32_t grid = (uint32_t)std::min<uint64_t>(
             { n_pairs, (uint64_t)per_cu * (uint64_t)job->ctx->prop.multiProcessorCount, (uint64_t)job->cbf_slots });
+        {
+            // Pairs of similar length finish in waves of `grid`: a last wave of a few workgroups
+            // would leave the chip idle for a whole pair's time.  Cut the grid so that the waves
+            // are equally full (a workgroup alone runs faster, so fewer at a time cost nothing).
+            const uint64_t waves = (n_pairs + grid - 1) / grid;
+            grid = (uint32_t)((n_pairs + waves - 1) / waves);
+        }
         hipLaunchKernelGGL(cbf_local, dim3(grid), dim3(kLBlock), 0, s, a, n_big, (uint32_t)n_pairs);
         GP_HIP(hipGetLastError());
         if ((rc0 = job->t_local.end(s)) != GP_OK)
@@ -1509,11 +1519,12 @@ int stage_a_run(gp_job* job)
     // the rest of the pipeline (stream `s`) continues behind the last tail
     GP_HIP(hipEventRecord(job->a_ev_init, s2));
     GP_HIP(hipStreamWaitEvent(s, job->a_ev_init, 0));
-    unsigned long long st[5];
-    uint32_t tail_err = 0;
-    GP_HIP(hipMemcpyAsync(st, job->d_stats.p, sizeof st, hipMemcpyDeviceToHost, s));
-    GP_HIP(hipMemcpyAsync(&tail_err, err_flag, sizeof tail_err, hipMemcpyDeviceToHost, s));
+    unsigned long long* const st = job->h_readback;   // pinned: [0..4] statistics, [8] the tail's error flag
+    st[8] = 0;
+    GP_HIP(hipMemcpyAsync(st, job->d_stats.p, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    GP_HIP(hipMemcpyAsync(st + 8, err_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     GP_HIP(hipStreamSynchronize(s));
+    const uint32_t tail_err = (uint32_t)st[8];
     job->counters.a_positions = st[0];
     job->counters.a_ops = st[1];
     job->counters.a_ordered_ops = st[2];

@@ -1174,8 +1174,13 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
     const uint64_t trip_trap = 8ull * ((uint64_t)len + c.node_cap) + 4096ull;
     for (uint64_t trip = 0;; trip++) {
         if (trip > trip_trap) {
-            if (tid == 0)
+            if (tid == 0) {
                 atomicOr(a.err, 4u);
+                if (atomicCAS(a.err + 1, 0u, cid + 1) == 0u) { // the first one leaves a note (words 1..3 of err)
+                    a.err[2] = (uint32_t)S.request;
+                    a.err[3] = S.hi;
+                }
+            }
             break;
         }
         // ---------------- thread 0: decide how to reach the next untested k-mer
@@ -2533,11 +2538,12 @@ int stage_b_reset(gp_job* job)
 static int pull_stats(gp_job* job)
 {
     StageBC* b = job->bc;
-    unsigned long long st[16];
-    uint32_t err = 0;
-    GP_HIP(hipMemcpyAsync(st, b->stats.p, sizeof st, hipMemcpyDeviceToHost, job->ctx->stream));
-    GP_HIP(hipMemcpyAsync(&err, b->err.p, sizeof err, hipMemcpyDeviceToHost, job->ctx->stream));
+    unsigned long long* const st = job->h_readback;   // pinned: [0..15] statistics, [16..17] the four error words
+    GP_HIP(hipMemcpyAsync(st, b->stats.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, job->ctx->stream));
+    GP_HIP(hipMemcpyAsync(st + 16, b->err.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, job->ctx->stream));
     GP_HIP(hipStreamSynchronize(job->ctx->stream));
+    const uint32_t* const errw = reinterpret_cast<const uint32_t*>(st + 16);
+    const uint32_t err = errw[0];
     job->counters.b_scan_kmers = st[0];
     job->counters.b_sites = st[1];
     job->counters.b_probes = st[2];
@@ -2567,7 +2573,10 @@ static int pull_stats(gp_job* job)
         return GP_ERR_CAPACITY;
     }
     if (err) {
-        set_error("device work buffer overflow (code " + std::to_string(err) + ")");
+        // bug traps; the walker's (4) leaves which contig it was and where it stood
+        set_error("device work buffer overflow (code " + std::to_string(err) + "; walker trap: contig " +
+                  std::to_string((long long)errw[1] - 1) + ", request " + std::to_string(errw[2]) + ", head " +
+                  std::to_string(errw[3]) + ")");
         return GP_ERR_STATE;
     }
     return GP_OK;

@@ -192,7 +192,7 @@ def make_workload_chunked(contig_lens, coverage: float, seed: int, chunk: int = 
     jobs = [(lens[i:i + chunk], coverage, seed * 1000003 + i // chunk, kw) for i in range(0, len(lens), chunk)]
     if workers <= 0:
         workers = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    workers = max(1, min(workers, len(jobs)))
+    workers = max(1, min(workers, len(jobs), 32))   # a GPU box shows every core of its node
     if workers == 1:
         parts = [_chunk_job(j) for j in jobs]
     else:

@@ -166,6 +166,13 @@ void gp_job_destroy(gp_job* job);
  * -> mask -> Sealer -> upper.  Asynchronous on gp_ctx_stream unless sync != 0.
  * May be called again: it restarts from the uploaded inputs. */
 int gp_job_polish(gp_job* job, int sync);
+/* gp_job_polish(job, 1) for several jobs, pipelined: the filter build of job i + 1 runs beside
+ * the ntEdit cascade, mask, Sealer and upper of job i (two host threads, every job on its own
+ * stream), so the memory-bound stage hides the latency-bound ones -- what the reference gets
+ * from running polishing batches beside its filter server (scripts/goldpolish:496-514).  Every
+ * job must have been created on a gp_ctx of its own (contexts may share a device).  Returns the
+ * first failing job's status, its message prefixed with the job's index. */
+int gp_jobs_polish(gp_job* const* jobs, uint32_t n_jobs);
 /* Individual stages, in order, for tests and profiling. */
 int gp_job_build_filters(gp_job* job, int sync);          /* stage A */
 int gp_job_ntedit_pass(gp_job* job, uint32_t k_index, int sync); /* stage B, one k */

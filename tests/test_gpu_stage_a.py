@@ -171,6 +171,23 @@ def test_mixed_thresholds_in_one_batch_with_colliding_counters(gp, oracle):
             run_and_compare(core, ctx, oracle, w, p, batch_contig_begin=[0, 2, 6])
 
 
+def test_more_pairs_than_arena_slots(gp, oracle, monkeypatch):
+    """the counting filters are scratch in an arena of slots: with 8 slots for 22 batches x 4 k the
+    grid-wide schedule works through groups of two batches, and cbf_local's workgroups replay
+    several pairs each in the slot they own, clearing it in between"""
+    core, ctx = gp
+    monkeypatch.setenv("GP_STAGE_A_SLOTS", "8")
+    lens = [3000, 1200, 5000, 800, 2500, 4000, 600, 3500, 1500, 2000, 4500,
+            1000, 700, 2600, 3100, 900, 5200, 1100, 2300, 1700, 2900, 400]
+    w = synth.make_workload(lens, 20, seed=23)
+    run_and_compare(core, ctx, oracle, w, core.default_params())
+    run_and_compare(core, ctx, oracle, w, core.default_params(k_values=[32, 20], cbf_bytes=20011, bf_bytes=4096))
+    # shared batches too: three contigs per batch
+    bcb = list(range(0, 22, 3)) + [22]
+    run_and_compare(core, ctx, oracle, w, core.default_params(k_values=[28, 24], cbf_bytes=70001, bf_bytes=8192),
+                    batch_contig_begin=bcb)
+
+
 def test_threshold_below_4_is_refused(gp):
     core, ctx = gp
     w = _custom_workload([b"ACGT" * 100], [[b"ACGT" * 100]], [3])
