@@ -215,6 +215,8 @@ def main():
         ctxs = [core.Context(device_index) for _ in range(n_jobs)]
         jobs = [core.Job(ctxs[i], params, **core.slice_workload(w, cuts[i], cuts[i + 1])) for i in range(n_jobs)]
 
+        sums = []
+
         def step():
             core.polish_jobs(jobs)
             # the polished records, packed back to back in one HBM buffer in input order: what
@@ -227,6 +229,8 @@ def main():
                 if n:
                     j.sequences_into_device(payload.data_ptr() + at, n)
                 at += n
+            # every step must give the same bytes: a cheap checksum of the packed records on the GPU
+            sums.append((sum(sizes), int(payload[:sum(sizes)].sum(dtype=torch.int64).item())))
             if world > 1:
                 # device-to-device: packed on the GPU, sent from HBM over xGMI
                 all_lens = np.concatenate(lens)
@@ -251,13 +255,16 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        if len(set(sums)) != 1:
+            raise SystemExit(f"bench.py: the polished output changed between steps: {sorted(set(sums))}")
         counters = {}
         for j in jobs:
             for name, v in j.counters().items():
                 counters[name] = counters.get(name, 0) + v
         res = {"bp_per_rank": w.total_bp, "dt": dt, "steps": steps, "counters": counters,
                "coverage": float(w.read_off[-1]) / max(w.total_bp, 1), "n_k": len(ks),
-               "n_contigs": w.n_contigs, "device_bytes": core.device_bytes_in_use(), "n_jobs": n_jobs}
+               "n_contigs": w.n_contigs, "device_bytes": core.device_bytes_in_use(), "n_jobs": n_jobs,
+               "output_checksum": {"bytes": sums[0][0], "byte_sum": sums[0][1], "steps_compared": len(sums)}}
         names = ("cbf_first_pass", "cbf_round", "cbf_local", "ntedit_scan", "ntedit_walk", "mask", "sealer_bfs", "upper")
 
         def kernel_times():
@@ -379,6 +386,7 @@ def main():
     if rank == 0:
         line["roofline"] = roofline(main_res, args.workload)
         line["counters"] = main_res["counters"]
+        line["output_checksum"] = main_res["output_checksum"]   # identical in every warm-up and timed step
         if "pcie_inclusive" in main_res:
             line["pcie_inclusive"] = main_res["pcie_inclusive"]
     if want_aux:

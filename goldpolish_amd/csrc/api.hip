@@ -608,7 +608,7 @@ try {
  * The stages of the path lean on different parts of the chip -- the filter build on random
  * memory transactions (it runs at the same speed with two, three or four workgroups per CU), the
  * ntEdit walk and the Sealer search on latency -- so the filter build of job i + 1 runs beside
- * the rest of job i.  GP_JOBS_MODE=parallel starts all jobs together on a thread each instead. */
+ * the rest of job i. */
 int gp_jobs_polish(gp_job* const* jobs, uint32_t n_jobs)
 try {
     if (!jobs || n_jobs == 0) {
@@ -626,27 +626,28 @@ try {
                 set_error("gp_jobs_polish: every job needs a context of its own");
                 return GP_ERR_INVALID_ARG;
             }
+        if (jobs[i]->ctx->device != jobs[0]->ctx->device) {
+            set_error("gp_jobs_polish: the jobs must be on one device");
+            return GP_ERR_INVALID_ARG;
+        }
     }
     if (n_jobs == 1)
         return gp_job_polish(jobs[0], 1);
     std::vector<int> rc(n_jobs, GP_OK);
     std::vector<std::string> msg(n_jobs);
-    const char* mode = getenv("GP_JOBS_MODE");
-    if (mode && !std::strcmp(mode, "parallel")) {
-        // every job on a thread of its own, all started together
-        std::vector<std::thread> threads;
-        threads.reserve(n_jobs);
-        for (uint32_t i = 0; i < n_jobs; i++)
-            threads.emplace_back([&, i] {
-                rc[i] = gp_job_polish(jobs[i], 1);
-                if (rc[i] != GP_OK)
-                    msg[i] = gp_last_error(); // the message is per thread: carry it over
-            });
-        for (auto& t : threads)
-            t.join();
-    } else {
+    {
         // Two-stage pipeline over the jobs: one thread builds the filters of job i + 1 while this
-        // one runs everything behind them for job i, each on its job's own stream.
+        // one runs everything behind them for job i.  TWO streams for any number of jobs: every
+        // filter build goes to the first job's stream, everything else to the second job's (a
+        // job's own stream is put back before this returns).  One stream per job had kernels that
+        // use scratch memory (ntedit_walk: 3 KB per lane) arrive on three, four, ... queues in turn,
+        // and with that the walker's state was corrupted now and then (its pass-count trap, once a
+        // silently different output, 4 of 40 runs with HSA_ENABLE_SCRATCH_ASYNC_RECLAIM=0); with
+        // all of them on one queue it has not been seen.
+        const hipStream_t front_stream = jobs[0]->ctx->stream, back_stream = jobs[1]->ctx->stream;
+        std::vector<hipStream_t> own(n_jobs);
+        for (uint32_t i = 0; i < n_jobs; i++)
+            own[i] = jobs[i]->ctx->stream;
         std::mutex mu;
         std::condition_variable cv;
         uint32_t built = 0;
@@ -657,8 +658,10 @@ try {
                     set_error("gp_jobs_polish: hipSetDevice failed");
                     r = GP_ERR_HIP;
                 }
-                if (r == GP_OK)
+                if (r == GP_OK) {
+                    jobs[i]->ctx->stream = front_stream;
                     r = stage_a_run(jobs[i]); // returns with the filters complete
+                }
                 if (r != GP_OK) {
                     rc[i] = r;
                     msg[i] = gp_last_error();
@@ -675,15 +678,17 @@ try {
                 std::unique_lock<std::mutex> g(mu);
                 cv.wait(g, [&] { return built > i; });
             }
-            if (rc[i] != GP_OK)
-                continue;
-            int r = hipSetDevice(jobs[i]->ctx->device) == hipSuccess ? polish_back(jobs[i]) : GP_ERR_HIP;
-            if (r == GP_OK)
-                r = gp_job_sync(jobs[i]);
-            if (r != GP_OK) {
-                rc[i] = r;
-                msg[i] = gp_last_error();
+            if (rc[i] == GP_OK) {
+                jobs[i]->ctx->stream = back_stream;
+                int r = hipSetDevice(jobs[i]->ctx->device) == hipSuccess ? polish_back(jobs[i]) : GP_ERR_HIP;
+                if (r == GP_OK)
+                    r = gp_job_sync(jobs[i]);
+                if (r != GP_OK) {
+                    rc[i] = r;
+                    msg[i] = gp_last_error();
+                }
             }
+            jobs[i]->ctx->stream = own[i];
         }
         front.join();
     }

@@ -695,6 +695,40 @@ __device__ __attribute__((noinline)) void zero_slot(uint8_t* cb, uint64_t bytes)
         z[i] = make_uint4(0, 0, 0, 0);
 }
 
+// The cheap way back to a clean slot after a SHORT pair (a GoldPolish-Target window is a few
+// hundred bases with a handful of reads): walk its positions once more and store a zero at every
+// counter a k-mer of it hashes to.  A pair of 4 k positions touches 16 k counters; clearing the
+// whole 10 MiB slot would write 164 k lines for it.  One position per lane, hashed from scratch.
+// (scalars by value: a reference to the kernel's argument block would force a copy of it into scratch)
+__device__ __attribute__((noinline)) void unwind_slot(const uint8_t* reads, uint64_t n_pos, uint8_t* cb, uint32_t k,
+                                                      uint32_t hash_num, FastMod cbf_mod, uint32_t nib,
+                                                      uint64_t b_start, uint64_t b_end)
+{
+    for (uint64_t p0 = b_start; p0 < b_end; p0 += blockDim.x) {
+        const uint64_t pos = p0 + threadIdx.x;
+        if (pos >= b_end || pos + k > n_pos)
+            continue;
+        uint64_t fh = 0, rh = 0;
+        bool bad = false;
+        for (uint32_t i = 0; i < k; i++) {
+            const uint32_t cf = base_code(reads[pos + i]);
+            bad |= cf >= 4;
+            fh = srol1(fh) ^ (cf < 4 ? seed_of_code(cf) : 0ULL);
+        }
+        if (bad)
+            continue;
+        for (uint32_t i = 0; i < k; i++) {
+            const uint32_t cr = base_code(reads[pos + k - 1 - i]);
+            rh = srol1(rh) ^ seed_of_code(cr ^ 2);
+        }
+        const uint64_t base = fh + rh;
+        for (uint32_t h = 0; h < hash_num; h++) {
+            const uint32_t ix = (uint32_t)fastmod(h ? ext_hash(base, k, h) : base, cbf_mod);
+            cb[nib ? ix >> 1 : ix] = 0; // (packed: the neighbour nibble is on its way to zero too)
+        }
+    }
+}
+
 constexpr int kLTile = 512;            // positions per tile: with the 32 KB table four workgroups share a CU,
 constexpr int kLPer = 2;               // each in another phase (hash / load / order / store); 1024-position
 constexpr int kLBlock = kLTile / kLPer; // tiles with a 64 KB table (two workgroups per CU) ran 5 % slower
@@ -717,6 +751,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     if (threadIdx.x < 4)
         s_stats[threadIdx.x] = 0;
     const int t0 = threadIdx.x * kLPer;
+    bool slot_clean = false; // uniform: the previous pair was short and has been unwound
 
     for (;;) {
     uint32_t n_ops = 0, n_ordered = 0, n_positions = 0, n_rounds = 0;
@@ -733,7 +768,8 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     const uint32_t k = kc.k;
     const uint32_t stream = b * a.n_k + ki;
     const uint64_t b_start = a.batch_pos[b], b_end = a.batch_pos[b + 1];
-    zero_slot(cb, a.cbf_stride);
+    if (!slot_clean)
+        zero_slot(cb, a.cbf_stride);
 
     for (uint64_t tile0 = b_start; tile0 < b_end; tile0 += kLTile) {
         const uint64_t tile_end = min(b_end, tile0 + (uint64_t)kLTile);
@@ -909,6 +945,12 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     atomicAdd(&s_stats[1], (unsigned long long)n_ops);
     atomicAdd(&s_stats[2], (unsigned long long)n_ordered);
     atomicAdd(&s_stats[3], (unsigned long long)n_rounds);
+    // fewer counter lines touched than a quarter of the slot holds: unwind instead of clearing
+    slot_clean = (b_end - b_start) * a.hash_num * 64 * 4 < a.cbf_stride;
+    if (slot_clean) {
+        __syncthreads(); // the pair's last stores are done
+        unwind_slot(a.reads, a.n_pos, cb, k, a.hash_num, a.cbf_mod, a.nib, b_start, b_end);
+    }
     } // next pair
     __syncthreads();
     if (threadIdx.x < 4 && s_stats[threadIdx.x])
@@ -1115,9 +1157,10 @@ int stage_a_run(gp_job* job)
     GP_HIP(hipMemsetAsync(job->d_counts.p, 0, job->d_counts.n * sizeof(uint32_t), s));
     GP_HIP(hipMemsetAsync(job->d_resv.p, 0xFF, job->d_resv.n * sizeof(unsigned long long), s));
     // stream `s` runs the first passes, stream `s2` the rounds and tails
+    // (`s2` is touched only when a batch really takes the grid-wide schedule: a job of short
+    // batches then keeps to one stream, and gp_jobs_polish to two for any number of jobs)
     hipStream_t s2 = job->a_stream2;
     GP_HIP(hipEventRecord(job->a_ev_init, s));
-    GP_HIP(hipStreamWaitEvent(s2, job->a_ev_init, 0));
 
     if (job->read_positions == 0 || job->n_contigs == 0) {
         job->filters_ready = true;
@@ -1331,6 +1374,8 @@ int stage_a_run(gp_job* job)
     // every batch of the group.  Many small batches therefore advance in lockstep: each filter
     // sees only a sliver of its reads per step, yet a step still holds enough operations to
     // fill the chip.  A group of one batch degenerates to consecutive slices of that batch.
+    if (n_big)
+        GP_HIP(hipStreamWaitEvent(s2, job->a_ev_init, 0)); // behind the memsets above
     for (uint32_t g_first = 0; g_first < n_big;) {
         const uint32_t g_n = std::min<uint32_t>(group_cap, n_big - g_first);
         // the group's counting filters start from zero; stream `s` is behind the previous
@@ -1517,8 +1562,10 @@ int stage_a_run(gp_job* job)
                 (unsigned long long)n_first_pass, host_ms, all_ms);
     }
     // the rest of the pipeline (stream `s`) continues behind the last tail
-    GP_HIP(hipEventRecord(job->a_ev_init, s2));
-    GP_HIP(hipStreamWaitEvent(s, job->a_ev_init, 0));
+    if (n_big) {
+        GP_HIP(hipEventRecord(job->a_ev_init, s2));
+        GP_HIP(hipStreamWaitEvent(s, job->a_ev_init, 0));
+    }
     unsigned long long* const st = job->h_readback;   // pinned: [0..4] statistics, [8] the tail's error flag
     st[8] = 0;
     GP_HIP(hipMemcpyAsync(st, job->d_stats.p, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

@@ -170,8 +170,10 @@ int gp_job_polish(gp_job* job, int sync);
  * the ntEdit cascade, mask, Sealer and upper of job i (two host threads, every job on its own
  * stream), so the memory-bound stage hides the latency-bound ones -- what the reference gets
  * from running polishing batches beside its filter server (scripts/goldpolish:496-514).  Every
- * job must have been created on a gp_ctx of its own (contexts may share a device).  Returns the
- * first failing job's status, its message prefixed with the job's index. */
+ * job must have been created on a gp_ctx of its own, all on one device (for the duration of the
+ * call the filter builds share the first job's stream and everything else the second job's: two
+ * queues whatever the number of jobs).  Returns the first failing job's status, its message
+ * prefixed with the job's index. */
 int gp_jobs_polish(gp_job* const* jobs, uint32_t n_jobs);
 /* Individual stages, in order, for tests and profiling. */
 int gp_job_build_filters(gp_job* job, int sync);          /* stage A */

@@ -1,5 +1,5 @@
 """gp_jobs_polish: several jobs of one GPU pipelined (filter build of job i + 1 beside the rest of
-job i) or side by side give exactly what one job over all the batches gives."""
+job i) give exactly what one job over all the batches gives."""
 import numpy as np
 import pytest
 
@@ -8,10 +8,8 @@ from goldpolish_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode", ["pipeline", "parallel"])
-def test_jobs_in_flight_equal_one_job(oracle, monkeypatch, mode):
+def test_jobs_in_flight_equal_one_job(oracle):
     from goldpolish_amd import core
-    monkeypatch.setenv("GP_JOBS_MODE", mode)
     w = synth.make_workload([9000, 4000, 12000, 300, 7000, 5000, 90, 6000], 25, seed=31)
     p = core.default_params()
     with core.Context(0) as ctx, core.Job.from_workload(ctx, p, w) as one:
@@ -19,7 +17,7 @@ def test_jobs_in_flight_equal_one_job(oracle, monkeypatch, mode):
         want = one.sequences()
         want_counters = one.counters()
     assert sum(x is not None and x != w.contig(i).upper() for i, x in enumerate(want)) >= 4   # real edits
-    for parts in (2, 3):
+    for parts in (2, 3, 5):
         cuts = [w.n_contigs * i // parts for i in range(parts + 1)]
         ctxs = [core.Context(0) for _ in range(parts)]
         jobs = [core.Job(ctxs[i], p, **core.slice_workload(w, cuts[i], cuts[i + 1])) for i in range(parts)]

@@ -182,6 +182,14 @@ def test_more_pairs_than_arena_slots(gp, oracle, monkeypatch):
     w = synth.make_workload(lens, 20, seed=23)
     run_and_compare(core, ctx, oracle, w, core.default_params())
     run_and_compare(core, ctx, oracle, w, core.default_params(k_values=[32, 20], cbf_bytes=20011, bf_bytes=4096))
+    # short pairs are unwound (zeros stored at the counters their k-mers hash to) instead of the
+    # slot being cleared: windows of a few hundred bases between longer contigs, every workgroup
+    # replaying several of them in its one slot
+    tiny = [300, 5000, 450, 800, 260, 2500, 1200, 350, 700, 9000, 500, 640, 1500, 420, 980, 310, 3300, 560, 770, 290,
+            1100, 480, 6100, 330, 900, 610, 2700, 370, 1300, 520]
+    w2 = synth.make_workload(tiny, 30, seed=24, read_mean=600.0, read_min=60, s_per_10kbp=400.0)
+    run_and_compare(core, ctx, oracle, w2, core.default_params())
+    run_and_compare(core, ctx, oracle, w2, core.default_params(k_values=[32, 24], cbf_bytes=1 << 20, bf_bytes=1 << 16))
     # shared batches too: three contigs per batch
     bcb = list(range(0, 22, 3)) + [22]
     run_and_compare(core, ctx, oracle, w, core.default_params(k_values=[28, 24], cbf_bytes=70001, bf_bytes=8192),
