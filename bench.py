@@ -31,7 +31,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ATOMIC_CEILING_GPS = 27.0  # scattered device-scope atomics per ns, measured (tools/probes/atomic_probe.hip)
-RANDOM_RMW_CEILING_GPS = 19.9  # random 1-byte load + store pairs per ns over 16 GiB, measured (tools/probes/random_rmw_probe.hip)
+RANDOM_RMW_CEILING_GPS = 20.7  # random 1-byte load + store pairs per ns over 4 GiB (19.9 over 16 GiB, 24.2 over 1 GiB), measured (tools/probes/random_rmw_probe.hip)
 METRIC = "polished Mbp/sec (whole node), k={32,28,24,20}, 1/2/4/8 MI355X"
 
 WORKLOADS = {
@@ -211,7 +211,13 @@ def main():
         """the timed loop over one rank's batches, cut into n_jobs jobs of consecutive contigs"""
         params = core.default_params(k_values=ks)
         n_jobs = max(1, min(n_jobs, w.n_contigs))
-        cuts = [w.n_contigs * i // n_jobs for i in range(n_jobs + 1)]
+        # shrinking jobs (4 : 3 : 2 : 1 ...): only the last job's back half is not hidden behind a
+        # filter build, so the last job is the smallest; each build still outlasts the back half before it
+        weights = np.arange(n_jobs, 0, -1, dtype=np.float64)
+        cuts = [0] + [int(round(w.n_contigs * x)) for x in np.cumsum(weights) / weights.sum()]
+        cuts[-1] = w.n_contigs
+        for i in range(1, n_jobs):     # never an empty job, whatever the rounding did
+            cuts[i] = min(max(cuts[i], cuts[i - 1] + 1), w.n_contigs - (n_jobs - i))
         ctxs = [core.Context(device_index) for _ in range(n_jobs)]
         jobs = [core.Job(ctxs[i], params, **core.slice_workload(w, cuts[i], cuts[i + 1])) for i in range(n_jobs)]
 
