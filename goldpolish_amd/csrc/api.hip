@@ -648,6 +648,8 @@ try {
         std::vector<hipStream_t> own(n_jobs);
         for (uint32_t i = 0; i < n_jobs; i++)
             own[i] = jobs[i]->ctx->stream;
+        const char* own_env = getenv("GP_JOBS_OWN_STREAMS"); // dev knob: every job on its own stream
+        const bool share = !(own_env && own_env[0] == '1');
         std::mutex mu;
         std::condition_variable cv;
         uint32_t built = 0;
@@ -659,7 +661,8 @@ try {
                     r = GP_ERR_HIP;
                 }
                 if (r == GP_OK) {
-                    jobs[i]->ctx->stream = front_stream;
+                    if (share)
+                        jobs[i]->ctx->stream = front_stream;
                     r = stage_a_run(jobs[i]); // returns with the filters complete
                 }
                 if (r != GP_OK) {
@@ -679,7 +682,8 @@ try {
                 cv.wait(g, [&] { return built > i; });
             }
             if (rc[i] == GP_OK) {
-                jobs[i]->ctx->stream = back_stream;
+                if (share)
+                    jobs[i]->ctx->stream = back_stream;
                 int r = hipSetDevice(jobs[i]->ctx->device) == hipSuccess ? polish_back(jobs[i]) : GP_ERR_HIP;
                 if (r == GP_OK)
                     r = gp_job_sync(jobs[i]);

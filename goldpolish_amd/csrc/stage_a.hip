@@ -86,6 +86,10 @@ struct AArgs {
     uint64_t cbf_stride; // bytes per counter array (one arena slot) in memory
     const uint32_t* batch_slot; // per batch: first arena slot of its n_k counter arrays while its group is worked on
     uint32_t* queue;     // cbf_local: next (batch, k) pair to replay
+    // census (see census_scatter): per queue entry of cbf_local
+    const uint32_t* pair_mode;              // 1: only the operations marked in `cand` are replayed, thresholds one lower
+    const uint64_t* pair_bit_off;           // first bit of the pair in `cand` (multiple of 64)
+    const unsigned long long* cand;         // bit (pair_bit_off + position in the batch's reads)
     uint32_t nib;        // 1: two 4-bit counters per byte (every threshold <= 15)
     uint32_t bf_words;
     FastMod cbf_mod, bf_mod;
@@ -668,6 +672,207 @@ __global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
 }
 
 
+// ------------------------------------------------------------------ census
+// Most operations of a sparse filter are the FIRST to touch one of their counters: that counter
+// is 0, so the operation's minimum is 0, it lifts its zero counters to 1 and inserts nothing
+// (every threshold is >= 2).  Which counters those are needs no order beyond "first": a counter is
+// 0 exactly until its first touch.  Everything else -- the operations NONE of whose counters they
+// touch first ("candidates": repeats of true k-mers, 15 % of the operations at k = 32, 33 % at
+// k = 20 on 25 kbp contigs with 40x reads) -- sees only counters >= 1 and only moves them among
+// levels >= 1, so it is an ordinary conservative-update replay of the candidates alone with every
+// counter starting at level 1: thresholds one lower on a zero array.  The census finds the
+// candidates without random memory traffic: every counter touch goes as an 8-byte record into
+// the bucket of its counter range (1024 ranges per pair, coalesced runs), a workgroup per bucket
+// takes the earliest position per counter in LDS and marks the touches that are not it, and an
+// operation with all its touches marked is a candidate.  cbf_local then replays a fifth to a
+// third of the operations.  A bucket that overflows its room (a long run of one k-mer) sends its
+// pair back to the plain replay.
+constexpr int kCSuper = 4;                // tiles of kTile positions per census_scatter workgroup
+constexpr uint32_t kCBuckets = 1024;      // counter ranges per pair
+constexpr uint32_t kCMaxBucketW = 16384;  // counters per range the LDS table of census_mark holds
+
+struct CensusArgs {
+    const uint32_t* wg_pair;       // [workgroups] pair (cohort-local) of a 4096-position stretch
+    const uint64_t* wg_pos0;       // [workgroups] its first read position
+    uint32_t n_wg;
+    const uint32_t* pair_batch;    // [pairs]
+    const uint32_t* pair_ki;       // [pairs]
+    const uint32_t* pair_cap;      // [pairs] records a bucket of the pair has room for
+    const uint64_t* pair_rec_off;  // [pairs] first record of the pair's buckets
+    const uint64_t* pair_flag_off; // [pairs] first position of the pair in `flags`
+    const uint64_t* pair_bit_off;  // [pairs] first bit of the pair in `cand` (multiple of 64)
+    const uint32_t* pair_queue;    // [pairs] index of the pair in cbf_local's queue (for pair_mode)
+    uint32_t* cursor;              // [pairs][kCBuckets] records written
+    unsigned long long* rec;       // (position in the batch << 32) | (counter in its range << 2) | hash number
+    uint32_t* flags;               // one byte per (position, hash): 1 = that touch is not the counter's first
+    uint32_t* overflow;            // [pairs]
+    uint32_t* pair_mode;           // [queue entries] cleared for pairs that overflowed
+    unsigned long long* cand;
+    uint32_t bucket_w;
+};
+
+// hashes of the lane's kPerThread consecutive positions of a staged tile (as cbf_first_pass does it)
+struct LaneOps {
+    uint64_t base[kPerThread];
+    uint32_t valid; // bit j: position j of the lane holds a k-mer
+};
+
+__device__ inline LaneOps lane_hashes(const uint8_t* codes, int t0, const KConsts& kc, uint64_t pos0, uint64_t tile_end,
+                                      uint64_t n_pos)
+{
+    LaneOps o;
+    o.valid = 0;
+    const uint32_t k = kc.k;
+    if (pos0 >= tile_end)
+        return o;
+    uint64_t fh = 0, rh = 0;
+    int last_bad = -1;
+    for (uint32_t i = 0; i < k; i++) {
+        uint32_t cf = codes[t0 + i];
+        uint32_t cr = codes[t0 + k - 1 - i];
+        fh = srol1(fh) ^ (cf < 4 ? seed_of_code(cf) : 0ULL);
+        rh = srol1(rh) ^ (cr < 4 ? seed_of_code(cr ^ 2) : 0ULL);
+        if (cf >= 4)
+            last_bad = (int)i;
+    }
+#pragma unroll
+    for (int j = 0; j < kPerThread; j++) {
+        const uint64_t pos = pos0 + j;
+        if (pos >= tile_end)
+            break;
+        if (j > 0) {
+            uint32_t out = codes[t0 + j - 1], in = codes[t0 + j + k - 1];
+            uint64_t s_in = in < 4 ? seed_of_code(in) : 0ULL;
+            uint64_t s_outk = out < 4 ? kc.out_fwd[out] : 0ULL;
+            uint64_t r_ink = in < 4 ? kc.in_rev[in] : 0ULL;
+            uint64_t r_out = out < 4 ? seed_of_code(out ^ 2) : 0ULL;
+            fh = srol1(fh) ^ s_in ^ s_outk;
+            rh = sror1(rh ^ r_ink ^ r_out);
+            if (in >= 4)
+                last_bad = j + (int)k - 1;
+        }
+        o.base[j] = fh + rh;
+        if (last_bad < j && pos + k <= n_pos)
+            o.valid |= 1u << j;
+    }
+    return o;
+}
+
+// ---- census 1: every counter touch of a 4096-position stretch into the bucket of its counter range
+__global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
+{
+    __shared__ uint8_t codes[kTile + kHalo];
+    __shared__ uint32_t hist[kCBuckets], base[kCBuckets];
+    const uint32_t pair = c.wg_pair[blockIdx.x];
+    const uint32_t b = c.pair_batch[pair], ki = c.pair_ki[pair];
+    const KConsts& kc = a.kc[ki];
+    const uint32_t k = kc.k;
+    const uint64_t b_start = a.batch_pos[b], b_end = a.batch_pos[b + 1];
+    const uint64_t pos0 = c.wg_pos0[blockIdx.x];
+    const uint64_t stretch_end = min(b_end, pos0 + (uint64_t)kCSuper * kTile);
+    const uint32_t cap = c.pair_cap[pair];
+    unsigned long long* const rec = c.rec + c.pair_rec_off[pair];
+    const int t0 = threadIdx.x * kPerThread;
+    for (uint32_t i = threadIdx.x; i < kCBuckets; i += kBlock)
+        hist[i] = 0;
+    // pass 0 counts the touches per bucket, pass 1 writes them behind the room taken with one
+    // atomic per bucket: the runs of a workgroup are contiguous, so L2 merges the 8-byte stores
+    for (int pass = 0; pass < 2; pass++) {
+        for (int st = 0; st < kCSuper; st++) {
+            const uint64_t tile0 = pos0 + (uint64_t)st * kTile;
+            if (tile0 >= stretch_end)
+                break; // uniform
+            const uint64_t tile_end = min(stretch_end, tile0 + (uint64_t)kTile);
+            __syncthreads(); // codes free (and hist cleared / base written before the first use)
+            for (int i = threadIdx.x; i < kTile + kHalo; i += kBlock) {
+                const uint64_t p = tile0 + i;
+                codes[i] = base_code(p < a.n_pos ? a.reads[p] : (uint8_t)'\n');
+            }
+            __syncthreads();
+            const LaneOps o = lane_hashes(codes, t0, kc, tile0 + t0, tile_end, a.n_pos);
+#pragma unroll
+            for (int j = 0; j < kPerThread; j++) {
+                if (!((o.valid >> j) & 1u))
+                    continue;
+                const uint32_t t = (uint32_t)(tile0 + t0 + j - b_start);
+                for (uint32_t h = 0; h < a.hash_num; h++) {
+                    const uint32_t ix = (uint32_t)fastmod(h ? ext_hash(o.base[j], k, h) : o.base[j], a.cbf_mod);
+                    const uint32_t bucket = ix / c.bucket_w;
+                    const uint32_t rank = atomicAdd(&hist[bucket], 1u);
+                    if (pass == 1) {
+                        const uint32_t slot = base[bucket] + rank;
+                        if (slot < cap)
+                            rec[(uint64_t)bucket * cap + slot] =
+                                ((unsigned long long)t << 32) | ((ix - bucket * c.bucket_w) << 2) | h;
+                        else
+                            c.overflow[pair] = 1u;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (pass == 0)
+            for (uint32_t i = threadIdx.x; i < kCBuckets; i += kBlock) {
+                const uint32_t n = hist[i];
+                base[i] = n ? atomicAdd(&c.cursor[(uint64_t)pair * kCBuckets + i], n) : 0u;
+                hist[i] = 0;
+            }
+    }
+}
+
+// ---- census 2: per bucket, the earliest position per counter; every later touch is marked
+__global__ __launch_bounds__(256) void census_mark(CensusArgs c)
+{
+    __shared__ uint32_t first_t[kCMaxBucketW];
+    const uint32_t pair = blockIdx.x / kCBuckets, bucket = blockIdx.x % kCBuckets;
+    if (c.overflow[pair])
+        return;
+    const uint32_t cap = c.pair_cap[pair];
+    const uint32_t n = min(c.cursor[(uint64_t)pair * kCBuckets + bucket], cap);
+    if (n == 0)
+        return;
+    const unsigned long long* rec = c.rec + c.pair_rec_off[pair] + (uint64_t)bucket * cap;
+    for (uint32_t i = threadIdx.x; i < c.bucket_w; i += 256)
+        first_t[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const unsigned long long r = rec[i];
+        atomicMin(&first_t[((uint32_t)r >> 2) & 0xFFFFu], (uint32_t)(r >> 32));
+    }
+    __syncthreads();
+    uint8_t* const fl = reinterpret_cast<uint8_t*>(c.flags + c.pair_flag_off[pair]);
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const unsigned long long r = rec[i];
+        const uint32_t t = (uint32_t)(r >> 32);
+        if (first_t[((uint32_t)r >> 2) & 0xFFFFu] != t)
+            fl[(uint64_t)t * 4 + ((uint32_t)r & 3u)] = 1; // (a counter hit twice by one operation: both touches are its first)
+    }
+}
+
+// ---- census 3: operations with every touch marked -> one bit each
+__global__ __launch_bounds__(256) void census_pack(AArgs a, CensusArgs c)
+{
+    const uint32_t pair = c.wg_pair[blockIdx.x];
+    if (c.overflow[pair]) {
+        if (threadIdx.x == 0)
+            c.pair_mode[c.pair_queue[pair]] = 0u; // the plain replay for this pair
+        return;
+    }
+    const uint32_t b = c.pair_batch[pair];
+    const uint64_t b_start = a.batch_pos[b], b_end = a.batch_pos[b + 1];
+    const uint64_t pos0 = c.wg_pos0[blockIdx.x];
+    const uint64_t stretch_end = min(b_end, pos0 + (uint64_t)kCSuper * kTile);
+    const uint32_t all = a.hash_num >= 4 ? 0x01010101u : ((1u << (8 * a.hash_num)) - 1u) & 0x01010101u;
+    const uint32_t* fl = c.flags + c.pair_flag_off[pair];
+    for (uint64_t p0 = pos0; p0 < stretch_end; p0 += 256) {
+        const uint64_t p = p0 + threadIdx.x;
+        const bool is_cand = p < stretch_end && fl[p - b_start] == all;
+        const unsigned long long m = __ballot(is_cand);
+        if ((threadIdx.x & 63) == 0 && p < stretch_end)
+            c.cand[(c.pair_bit_off[pair] + (p - b_start)) >> 6] = m; // stretches and batches start on multiples of 64 bits
+    }
+}
+
 // ---- many small filters: one workgroup per (batch, k) pair replays its operations alone.
 // Nobody else touches the pair's counters, so the whole ordering problem stays inside the
 // workgroup: a tile of 512 consecutive positions is hashed, what is settled goes straight
@@ -742,6 +947,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     __shared__ uint32_t keys[kLocalSlots]; // counter index held by the slot
     __shared__ uint32_t vals[kLocalSlots]; // earliest waiting operation of the tile on that counter
     __shared__ unsigned long long s_stats[4];
+    __shared__ unsigned long long s_cand[kLTile / 64]; // the tile's candidate bits (census)
     // This workgroup's arena slot for the whole launch: the counting filter of whichever pair it
     // is replaying.  Pairs come from a queue (longest batches first), so the grid is as large as
     // the chip holds and no larger, and a short pair's workgroup goes on to the next one instead
@@ -768,6 +974,10 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     const uint32_t k = kc.k;
     const uint32_t stream = b * a.n_k + ki;
     const uint64_t b_start = a.batch_pos[b], b_end = a.batch_pos[b + 1];
+    // census: only the candidates are replayed, every counter they see is already at level 1, so
+    // the array holds level - 1 and every threshold is one lower (see census_scatter)
+    const uint32_t census = a.pair_mode ? a.pair_mode[pair] : 0u;
+    const unsigned long long* const cand_bits = census ? a.cand + (a.pair_bit_off[pair] >> 6) : nullptr;
     if (!slot_clean)
         zero_slot(cb, a.cbf_stride);
 
@@ -779,6 +989,8 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
             uint8_t c = p < a.n_pos ? a.reads[p] : (uint8_t)'\n';
             codes[i] = base_code(c);
         }
+        if (census && threadIdx.x < kLTile / 64)
+            s_cand[threadIdx.x] = cand_bits[((tile0 - b_start) >> 6) + threadIdx.x];
         __syncthreads();
 
         uint32_t op_state[kLPer] = {}, op_thr[kLPer] = {}, op_c[kLPer] = {};
@@ -830,8 +1042,10 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
                     seg_end = a.seg_start[seg + 1];
                 }
                 n_ops++;
+                if (census && !((s_cand[(t0 + j) >> 6] >> ((t0 + j) & 63)) & 1ULL))
+                    continue; // first on one of its counters: lifts zeros to one, inserts nothing
                 op_base[j] = fh + rh;
-                op_thr[j] = (a.seg_thr[seg] - 2 + ki) | ((a.seg_smax[seg] - 2 + ki) << 16); // own threshold | S
+                op_thr[j] = (a.seg_thr[seg] - 2 + ki - census) | ((a.seg_smax[seg] - 2 + ki - census) << 16); // own threshold | S
                 op_state[j] = 1;
                 uint32_t pack = 0;
                 for (uint32_t h = 0; h < 4; h++) { // hash_num <= 4 on this path (stage_a_run)

@@ -1595,8 +1595,15 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             continue;
         }
 
-        if (req == REQ_NEXT)
+        if (req == REQ_NEXT) {
+            // Everybody has read S.request before thread 0 may rewrite it at the top of the loop.
+            // Without this barrier a wave that fell behind (suspended while another job's kernel
+            // had its CU) read the NEXT request and took another branch than the rest of its
+            // workgroup: the walker's pass-count trap, once a silently different output, about one
+            // run in a hundred with a second job's filter build in flight; never seen alone.
+            __syncthreads();
             continue;
+        }
 
         // ------------------------------------------------------------ REQ_SITE
         if (tid == 0) {
