@@ -451,6 +451,7 @@ void gp_job_destroy(gp_job* job)
     job->t_first_pass.destroy();
     job->t_round.destroy();
     job->t_local.destroy();
+    job->t_census.destroy();
     job->t_scan.destroy();
     job->t_walk.destroy();
     job->t_bfs.destroy();
@@ -637,19 +638,13 @@ try {
     std::vector<std::string> msg(n_jobs);
     {
         // Two-stage pipeline over the jobs: one thread builds the filters of job i + 1 while this
-        // one runs everything behind them for job i.  TWO streams for any number of jobs: every
+        // one runs everything behind them for job i.  Two streams for any number of jobs: every
         // filter build goes to the first job's stream, everything else to the second job's (a
-        // job's own stream is put back before this returns).  One stream per job had kernels that
-        // use scratch memory (ntedit_walk: 3 KB per lane) arrive on three, four, ... queues in turn,
-        // and with that the walker's state was corrupted now and then (its pass-count trap, once a
-        // silently different output, 4 of 40 runs with HSA_ENABLE_SCRATCH_ASYNC_RECLAIM=0); with
-        // all of them on one queue it has not been seen.
+        // job's own stream is put back before this returns).
         const hipStream_t front_stream = jobs[0]->ctx->stream, back_stream = jobs[1]->ctx->stream;
         std::vector<hipStream_t> own(n_jobs);
         for (uint32_t i = 0; i < n_jobs; i++)
             own[i] = jobs[i]->ctx->stream;
-        const char* own_env = getenv("GP_JOBS_OWN_STREAMS"); // dev knob: every job on its own stream
-        const bool share = !(own_env && own_env[0] == '1');
         std::mutex mu;
         std::condition_variable cv;
         uint32_t built = 0;
@@ -661,8 +656,7 @@ try {
                     r = GP_ERR_HIP;
                 }
                 if (r == GP_OK) {
-                    if (share)
-                        jobs[i]->ctx->stream = front_stream;
+                    jobs[i]->ctx->stream = front_stream;
                     r = stage_a_run(jobs[i]); // returns with the filters complete
                 }
                 if (r != GP_OK) {
@@ -682,8 +676,7 @@ try {
                 cv.wait(g, [&] { return built > i; });
             }
             if (rc[i] == GP_OK) {
-                if (share)
-                    jobs[i]->ctx->stream = back_stream;
+                jobs[i]->ctx->stream = back_stream;
                 int r = hipSetDevice(jobs[i]->ctx->device) == hipSuccess ? polish_back(jobs[i]) : GP_ERR_HIP;
                 if (r == GP_OK)
                     r = gp_job_sync(jobs[i]);
@@ -781,6 +774,8 @@ try {
         t = &job->t_round;
     else if (!std::strcmp(kernel, "cbf_local"))
         t = &job->t_local;
+    else if (!std::strcmp(kernel, "cbf_census"))
+        t = &job->t_census;
     else if (!std::strcmp(kernel, "ntedit_scan"))
         t = &job->t_scan;
     else if (!std::strcmp(kernel, "ntedit_walk"))

@@ -49,6 +49,9 @@ struct DevBuf {
         track_device_bytes((long long)(count * sizeof(T)));
         return GP_OK;
     }
+    // at least `count` elements, keeping what is there when it is enough (work buffers that
+    // are sized per run: a job polished again does not allocate again)
+    int ensure(size_t count) { return (p && n >= count) ? GP_OK : alloc(count); }
     void release()
     {
         if (p) {
@@ -133,6 +136,10 @@ struct gp_job {
     gp::DevBuf<uint32_t> d_batch_order;   // [n_batches] batches as stage A takes them
     gp::DevBuf<uint32_t> d_batch_slot;    // [n_batches] first arena slot of a batch of the grid-wide schedule
     gp::DevBuf<uint32_t> d_queue;         // cbf_local's pair counter
+    // census of first touches (stage_a.hip): work buffers of a cohort, results for the whole job
+    gp::DevBuf<unsigned long long> d_census_rec, d_cand;
+    gp::DevBuf<uint32_t> d_census_cursor, d_census_flags, d_census_over, d_census_tab32, d_pair_mode;
+    gp::DevBuf<uint64_t> d_census_tab64, d_pair_bit_off;
     gp::DevBuf<uint32_t> d_counts;        // ring of per-step list lengths, one 128-B line each
     gp::DevBuf<unsigned long long> d_stats; // device-side gp_counters
     uint64_t window = 0;
@@ -150,7 +157,7 @@ struct gp_job {
     // path at the same time; pinned memory is written by the device directly
     unsigned long long* h_readback = nullptr; // 64 words
 
-    gp::KernelTimer t_first_pass, t_round, t_local, t_scan, t_walk, t_bfs, t_mask, t_upper;
+    gp::KernelTimer t_first_pass, t_round, t_local, t_census, t_scan, t_walk, t_bfs, t_mask, t_upper;
     gp_counters counters{};
     bool filters_ready = false;
 };

@@ -54,6 +54,7 @@
 #include "gp_internal.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
@@ -823,7 +824,7 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
 // ---- census 2: per bucket, the earliest position per counter; every later touch is marked
 __global__ __launch_bounds__(256) void census_mark(CensusArgs c)
 {
-    __shared__ uint32_t first_t[kCMaxBucketW];
+    extern __shared__ uint32_t first_t[]; // bucket_w words (40 KB at GoldPolish's 10 MiB: four workgroups per CU)
     const uint32_t pair = blockIdx.x / kCBuckets, bucket = blockIdx.x % kCBuckets;
     if (c.overflow[pair])
         return;
@@ -1360,6 +1361,7 @@ int stage_a_run(gp_job* job)
     job->t_first_pass.reset();
     job->t_round.reset();
     job->t_local.reset();
+    job->t_census.reset();
     job->counters.a_rounds = 0;
 
     // fresh filters + free reservation tables (the counting-filter arena is cleared slot by slot,
@@ -1446,13 +1448,19 @@ int stage_a_run(gp_job* job)
     }
     a.batch_order = job->d_batch_order.p;
     const uint32_t n_local = job->n_batches - n_big;
+    // census tables: host copies stay alive until the stream has been synchronised at the end
+    struct Cohort {
+        std::vector<uint32_t> wg_pair, pair_batch, pair_ki, pair_cap, pair_queue, tab32;
+        std::vector<uint64_t> wg_pos0, pair_rec_off, pair_flag_off, pair_bit_off, tab64;
+    };
+    std::vector<Cohort> cohorts;
+    std::vector<uint32_t> h_pair_mode;
+    std::vector<uint64_t> h_pair_bit_off;
     if (n_local) {
         uint64_t units = 0;
         for (uint32_t i = n_big; i < job->n_batches; i++)
             units += (batch_pos[order[i] + 1] - batch_pos[order[i]]) * p.n_k;
-        int rc0 = job->t_local.begin(s, units);
-        if (rc0 != GP_OK)
-            return rc0;
+        int rc0 = GP_OK;
         // as many workgroups as the chip holds at once (each owns one arena slot), never more than
         // there are slots or pairs
         int per_cu = 0;
@@ -1471,6 +1479,136 @@ int stage_a_run(gp_job* job)
             const uint64_t waves = (n_pairs + grid - 1) / grid;
             grid = (uint32_t)((n_pairs + waves - 1) / waves);
         }
+        // ---- census of first touches for the pairs it pays for (see census_scatter)
+        a.pair_mode = nullptr;
+        a.pair_bit_off = nullptr;
+        a.cand = nullptr;
+        const uint32_t bucket_w = (uint32_t)((p.cbf_bytes + kCBuckets - 1) / kCBuckets);
+        if (env_u64("GP_STAGE_A_CENSUS", 1) && p.hash_num <= 4 && bucket_w <= kCMaxBucketW) {
+            const uint64_t min_pos = env_u64("GP_STAGE_A_CENSUS_MIN", 65536);           // below: too few touches per bucket
+            const uint64_t rec_budget = (env_u64("GP_STAGE_A_CENSUS_MB", 8192) << 20) / 8; // records of a cohort
+            h_pair_mode.assign(n_pairs, 0);
+            h_pair_bit_off.assign(n_pairs, 0);
+            uint64_t bits = 0, max_rec = 0, max_flags = 0, max_pairs = 0, max_wg = 0;
+            Cohort cur;
+            uint64_t cur_rec = 0, cur_flags = 0;
+            auto close = [&]() {
+                if (cur.pair_batch.empty())
+                    return;
+                max_rec = std::max(max_rec, cur_rec);
+                max_flags = std::max(max_flags, cur_flags);
+                max_pairs = std::max<uint64_t>(max_pairs, cur.pair_batch.size());
+                max_wg = std::max<uint64_t>(max_wg, cur.wg_pair.size());
+                cohorts.push_back(std::move(cur));
+                cur = Cohort();
+                cur_rec = cur_flags = 0;
+            };
+            for (uint32_t i = 0; i < n_local; i++) {
+                const uint32_t b = order[n_big + i];
+                const uint64_t pos = batch_pos[b + 1] - batch_pos[b];
+                // every operation in a first touch when the filter is nearly empty, hardly any once
+                // it has seen a few times its size: the census pays up to about two touches per counter
+                if (pos < min_pos || pos >= (1ull << 32) || pos * p.hash_num > 2 * p.cbf_bytes)
+                    continue;
+                const double mu = (double)pos * p.hash_num / kCBuckets;
+                const uint32_t cap = (uint32_t)(mu + 8.0 * std::sqrt(mu) + 32.0);
+                const uint64_t recs = (uint64_t)cap * kCBuckets;
+                if (recs * p.n_k > rec_budget)
+                    continue; // a batch that would not fit a cohort by itself
+                if (cur_rec + recs * p.n_k > rec_budget)
+                    close();
+                for (uint32_t ki = 0; ki < p.n_k; ki++) {
+                    const uint32_t q = i * p.n_k + ki, lp = (uint32_t)cur.pair_batch.size();
+                    cur.pair_batch.push_back(b);
+                    cur.pair_ki.push_back(ki);
+                    cur.pair_cap.push_back(cap);
+                    cur.pair_queue.push_back(q);
+                    cur.pair_rec_off.push_back(cur_rec);
+                    cur.pair_flag_off.push_back(cur_flags);
+                    cur.pair_bit_off.push_back(bits);
+                    h_pair_mode[q] = 1;
+                    h_pair_bit_off[q] = bits;
+                    cur_rec += recs;
+                    cur_flags += pos;
+                    bits += (pos + 511) / 512 * 512 + 512; // whole tiles of cbf_local, and one of slack
+                    for (uint64_t p0 = 0; p0 < pos; p0 += (uint64_t)kCSuper * kTile) {
+                        cur.wg_pair.push_back(lp);
+                        cur.wg_pos0.push_back(batch_pos[b] + p0);
+                    }
+                }
+            }
+            close();
+            if (!cohorts.empty()) {
+                int rcc;
+                if ((rcc = job->d_census_rec.ensure(max_rec)) != GP_OK || (rcc = job->d_census_flags.ensure(max_flags)) != GP_OK ||
+                    (rcc = job->d_census_cursor.ensure(max_pairs * kCBuckets)) != GP_OK ||
+                    (rcc = job->d_census_over.ensure(max_pairs)) != GP_OK ||
+                    (rcc = job->d_census_tab32.ensure(max_wg + 4 * max_pairs)) != GP_OK ||
+                    (rcc = job->d_census_tab64.ensure(max_wg + 3 * max_pairs)) != GP_OK ||
+                    (rcc = job->d_cand.ensure(bits / 64)) != GP_OK || (rcc = job->d_pair_mode.ensure(n_pairs)) != GP_OK ||
+                    (rcc = job->d_pair_bit_off.ensure(n_pairs)) != GP_OK)
+                    return rcc;
+                GP_HIP(hipMemcpyAsync(job->d_pair_mode.p, h_pair_mode.data(), n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+                GP_HIP(hipMemcpyAsync(job->d_pair_bit_off.p, h_pair_bit_off.data(), n_pairs * sizeof(uint64_t),
+                                      hipMemcpyHostToDevice, s));
+                if ((rcc = job->t_census.begin(s, units)) != GP_OK)
+                    return rcc;
+                for (Cohort& co : cohorts) {
+                    const size_t np = co.pair_batch.size(), nw = co.wg_pair.size();
+                    // one table of 32-bit and one of 64-bit columns per cohort
+                    co.tab32.reserve(nw + 4 * np);
+                    co.tab32.insert(co.tab32.end(), co.wg_pair.begin(), co.wg_pair.end());
+                    co.tab32.insert(co.tab32.end(), co.pair_batch.begin(), co.pair_batch.end());
+                    co.tab32.insert(co.tab32.end(), co.pair_ki.begin(), co.pair_ki.end());
+                    co.tab32.insert(co.tab32.end(), co.pair_cap.begin(), co.pair_cap.end());
+                    co.tab32.insert(co.tab32.end(), co.pair_queue.begin(), co.pair_queue.end());
+                    co.tab64.reserve(nw + 3 * np);
+                    co.tab64.insert(co.tab64.end(), co.wg_pos0.begin(), co.wg_pos0.end());
+                    co.tab64.insert(co.tab64.end(), co.pair_rec_off.begin(), co.pair_rec_off.end());
+                    co.tab64.insert(co.tab64.end(), co.pair_flag_off.begin(), co.pair_flag_off.end());
+                    co.tab64.insert(co.tab64.end(), co.pair_bit_off.begin(), co.pair_bit_off.end());
+                    GP_HIP(hipMemcpyAsync(job->d_census_tab32.p, co.tab32.data(), co.tab32.size() * sizeof(uint32_t),
+                                          hipMemcpyHostToDevice, s));
+                    GP_HIP(hipMemcpyAsync(job->d_census_tab64.p, co.tab64.data(), co.tab64.size() * sizeof(uint64_t),
+                                          hipMemcpyHostToDevice, s));
+                    uint64_t flags_n = 0;
+                    for (size_t i = 0; i < np; i++)
+                        flags_n = std::max<uint64_t>(flags_n, co.pair_flag_off[i] + (batch_pos[co.pair_batch[i] + 1] - batch_pos[co.pair_batch[i]]));
+                    GP_HIP(hipMemsetAsync(job->d_census_cursor.p, 0, np * kCBuckets * sizeof(uint32_t), s));
+                    GP_HIP(hipMemsetAsync(job->d_census_over.p, 0, np * sizeof(uint32_t), s));
+                    GP_HIP(hipMemsetAsync(job->d_census_flags.p, 0, flags_n * sizeof(uint32_t), s));
+                    CensusArgs c{};
+                    c.wg_pair = job->d_census_tab32.p;
+                    c.pair_batch = c.wg_pair + nw;
+                    c.pair_ki = c.pair_batch + np;
+                    c.pair_cap = c.pair_ki + np;
+                    c.pair_queue = c.pair_cap + np;
+                    c.wg_pos0 = job->d_census_tab64.p;
+                    c.pair_rec_off = c.wg_pos0 + nw;
+                    c.pair_flag_off = c.pair_rec_off + np;
+                    c.pair_bit_off = c.pair_flag_off + np;
+                    c.n_wg = (uint32_t)nw;
+                    c.cursor = job->d_census_cursor.p;
+                    c.rec = job->d_census_rec.p;
+                    c.flags = job->d_census_flags.p;
+                    c.overflow = job->d_census_over.p;
+                    c.pair_mode = job->d_pair_mode.p;
+                    c.cand = job->d_cand.p;
+                    c.bucket_w = bucket_w;
+                    hipLaunchKernelGGL(census_scatter, dim3((unsigned)nw), dim3(kBlock), 0, s, a, c);
+                    hipLaunchKernelGGL(census_mark, dim3((unsigned)(np * kCBuckets)), dim3(256), bucket_w * sizeof(uint32_t), s, c);
+                    hipLaunchKernelGGL(census_pack, dim3((unsigned)nw), dim3(256), 0, s, a, c);
+                    GP_HIP(hipGetLastError());
+                }
+                if ((rcc = job->t_census.end(s)) != GP_OK)
+                    return rcc;
+                a.pair_mode = job->d_pair_mode.p;
+                a.pair_bit_off = job->d_pair_bit_off.p;
+                a.cand = job->d_cand.p;
+            }
+        }
+        if ((rc0 = job->t_local.begin(s, units)) != GP_OK)
+            return rc0;
         hipLaunchKernelGGL(cbf_local, dim3(grid), dim3(kLBlock), 0, s, a, n_big, (uint32_t)n_pairs);
         GP_HIP(hipGetLastError());
         if ((rc0 = job->t_local.end(s)) != GP_OK)
@@ -1798,7 +1936,8 @@ int stage_a_run(gp_job* job)
     int rc = job->t_first_pass.collect();
     if (rc != GP_OK)
         return rc;
-    if ((rc = job->t_round.collect()) != GP_OK || (rc = job->t_local.collect()) != GP_OK)
+    if ((rc = job->t_round.collect()) != GP_OK || (rc = job->t_local.collect()) != GP_OK ||
+        (rc = job->t_census.collect()) != GP_OK)
         return rc;
     job->filters_ready = true;
     return GP_OK;

@@ -11,11 +11,15 @@ from goldpolish_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["grid", "local"], autouse=True)
+@pytest.fixture(params=["grid", "local", "census"], autouse=True)
 def stage_a_path(request, monkeypatch):
-    """every case runs through both stage-A schedules: grid-wide reservation rounds
-    (GP_STAGE_A_LOCAL=0) and one workgroup per (batch, k) pair (GP_STAGE_A_LOCAL=1)"""
+    """every case runs through the stage-A schedules: grid-wide reservation rounds
+    (GP_STAGE_A_LOCAL=0), one workgroup per (batch, k) pair replaying every operation
+    (GP_STAGE_A_LOCAL=1, census off), and the same behind the census of first touches (forced
+    for batches of any length; pairs it does not apply to or whose buckets overflow fall back)"""
     monkeypatch.setenv("GP_STAGE_A_LOCAL", "0" if request.param == "grid" else "1")
+    monkeypatch.setenv("GP_STAGE_A_CENSUS", "1" if request.param == "census" else "0")
+    monkeypatch.setenv("GP_STAGE_A_CENSUS_MIN", "1")
     return request.param
 
 
@@ -194,6 +198,23 @@ def test_more_pairs_than_arena_slots(gp, oracle, monkeypatch):
     bcb = list(range(0, 22, 3)) + [22]
     run_and_compare(core, ctx, oracle, w, core.default_params(k_values=[28, 24], cbf_bytes=70001, bf_bytes=8192),
                     batch_contig_begin=bcb)
+
+
+def test_census_cohorts_and_bucket_overflow(gp, oracle, monkeypatch):
+    """the census in several cohorts (a tiny record budget), and pairs whose buckets overflow (long
+    runs of one k-mer) falling back to the plain replay beside pairs that do not"""
+    core, ctx = gp
+    monkeypatch.setenv("GP_STAGE_A_CENSUS_MB", "2")   # 256 k records: a cohort holds a pair or two
+    w = synth.make_workload([30000, 12000, 20000, 8000, 25000], 30, seed=26)
+    c = run_and_compare(core, ctx, oracle, w, core.default_params())
+    assert c["a_ordered_ops"] < c["a_ops"]
+    rng = np.random.default_rng(27)
+    g = synth.random_genome(20000, rng).tobytes()
+    reads = [g[i:i + 5000] for i in range(0, 15000, 700)] * 3
+    flood = [b"A" * 9000 + g[:500], b"ACACACAC" * 1200]           # thousands of touches on four counters
+    w2 = _custom_workload([g, g[:9000], g[5000:]], [reads + flood, reads, flood + reads], [6, 5, 7])
+    run_and_compare(core, ctx, oracle, w2, core.default_params())
+    run_and_compare(core, ctx, oracle, w2, core.default_params(k_values=[32, 20]), batch_contig_begin=[0, 2, 3])
 
 
 def test_threshold_below_4_is_refused(gp):

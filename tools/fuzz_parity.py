@@ -95,9 +95,17 @@ def random_case(seed):
     return w, ks, sizes, bcb, extra
 
 
+def set_schedule(mode):
+    """"0": grid-wide schedule; "1": cbf_local replaying every operation; "2": cbf_local behind the
+    census of first touches (forced for batches of any length)"""
+    os.environ["GP_STAGE_A_LOCAL"] = "0" if mode == "0" else "1"
+    os.environ["GP_STAGE_A_CENSUS"] = "1" if mode == "2" else "0"
+    os.environ["GP_STAGE_A_CENSUS_MIN"] = "1"
+
+
 def run_case(core, ctx, O, seed, local_mode):
     w, ks, (cbf, bf), bcb, extra = random_case(seed)
-    os.environ["GP_STAGE_A_LOCAL"] = local_mode
+    set_schedule(local_mode)
     p = core.default_params(k_values=ks, cbf_bytes=cbf, bf_bytes=bf, **extra)
     names = w.names
     with core.Job(ctx, p, contig_buf=w.contig_buf, contig_off=w.contig_off, contig_read_begin=w.contig_read_begin,
@@ -129,7 +137,7 @@ def run_staged(core, ctx, O, seed, local_mode):
     """step-wise API with random ntEdit / Sealer parameters, every stage against the oracle"""
     w, ks, (cbf, bf), bcb, extra = random_case(seed)
     rng = np.random.default_rng(seed + 77)
-    os.environ["GP_STAGE_A_LOCAL"] = local_mode
+    set_schedule(local_mode)
     nt = dict(max_insertions=int(rng.choice([0, 1, 3, 5])), max_deletions=int(rng.choice([0, 2, 5, 10])),
               jump=int(rng.choice([1, 2, 3, 5])), missing_ratio=extra["missing_ratio"], edit_ratio=extra["edit_ratio"],
               soft_mask=int(rng.integers(0, 2)), min_contig_len=int(rng.choice([100, 50, 500])))
@@ -193,7 +201,7 @@ def main():
     t0 = time.time()
     with core.Context(0) as ctx:
         for seed in range(first, first + n):
-            for mode in ("0", "1"):
+            for mode in ("0", "1", "2"):
                 try:
                     err = run_case(core, ctx, O, seed, mode) or run_staged(core, ctx, O, seed, mode)
                 except Exception as e:  # noqa: BLE001 -- a fuzz loop reports and goes on
@@ -203,7 +211,7 @@ def main():
                     print(f"seed {seed} local={mode}: {err}", flush=True)
             if (seed - first) % 10 == 9:
                 print(f"... {seed - first + 1} cases, {bad} failures, {time.time() - t0:.0f} s", flush=True)
-    print(f"fuzz: {n} cases x 2 schedules, {bad} failures")
+    print(f"fuzz: {n} cases x 3 schedules, {bad} failures")
     return 1 if bad else 0
 
 

@@ -8,5 +8,5 @@ from goldpolish_amd import core
 O = oracle_lib.Oracle(str(ROOT / "oracle" / "libgpo.so"))
 with core.Context(0) as ctx:
     for seed in map(int, sys.argv[1:]):
-        for mode in ("0", "1"):
+        for mode in ("0", "1", "2"):
             print(seed, mode, fuzz_parity.run_case(core, ctx, O, seed, mode) or "ok", flush=True)
