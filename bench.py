@@ -271,7 +271,8 @@ def main():
                "coverage": float(w.read_off[-1]) / max(w.total_bp, 1), "n_k": len(ks),
                "n_contigs": w.n_contigs, "device_bytes": core.device_bytes_in_use(), "n_jobs": n_jobs,
                "output_checksum": {"bytes": sums[0][0], "byte_sum": sums[0][1], "steps_compared": len(sums)}}
-        names = ("cbf_first_pass", "cbf_round", "cbf_local", "ntedit_scan", "ntedit_walk", "mask", "sealer_bfs", "upper")
+        names = ("cbf_first_pass", "cbf_round", "cbf_census", "cbf_local", "ntedit_scan", "ntedit_walk", "mask",
+                 "sealer_bfs", "upper")
 
         def kernel_times():
             kt = {n: {"ms": 0.0, "launches": 0, "units": 0} for n in names}

@@ -115,6 +115,7 @@ struct gp_job {
     gp::DevBuf<uint64_t> d_seg_start;     // [n_contigs+1] first position of each contig's reads
     gp::DevBuf<uint32_t> d_seg_batch;     // [n_contigs]
     gp::DevBuf<uint32_t> d_seg_thr;       // [n_contigs] kmer_threshold of the contig
+    gp::DevBuf<uint32_t> d_batch_seg;     // [n_batches+1] first contig of each batch
     gp::DevBuf<uint32_t> d_seg_smax;      // [n_contigs] largest threshold of the contig and the later ones of its batch
     std::vector<uint64_t> h_seg_start;
     std::vector<uint32_t> h_batch_contig_begin, h_contig_batch, h_contig_thr, h_contig_name_len;

@@ -88,7 +88,7 @@ struct AArgs {
     const uint32_t* batch_slot; // per batch: first arena slot of its n_k counter arrays while its group is worked on
     uint32_t* queue;     // cbf_local: next (batch, k) pair to replay
     // census (see census_scatter): per queue entry of cbf_local
-    const uint32_t* pair_mode;              // 1: only the operations marked in `cand` are replayed, thresholds one lower
+    const uint32_t* pair_mode;              // 1: only the operations marked in `cand` are replayed, thresholds one lower (2: census overflowed)
     const uint64_t* pair_bit_off;           // first bit of the pair in `cand` (multiple of 64)
     const unsigned long long* cand;         // bit (pair_bit_off + position in the batch's reads)
     uint32_t nib;        // 1: two 4-bit counters per byte (every threshold <= 15)
@@ -103,6 +103,7 @@ struct AArgs {
     uint64_t tag_next;   // tag for reservations made by this launch (always smaller: newer wins)
     uint32_t* sat;       // per (batch, k): bit 0 = every counter >= max thr-1, bit 1 = filter all ones
     const uint32_t* batch_thr_max; // per batch: largest kmer_threshold of its contigs that have reads
+    const uint32_t* batch_seg;     // [n_batches+1] first contig (segment) of each batch
     const uint32_t* seg_smax;      // per contig: largest kmer_threshold of it and the later contigs of its batch (with reads)
     uint32_t tail_max;   // while draining: lists up to this long are left to the tail kernel
     uint32_t bits_in;    // log2 slots of the table being checked (what the previous step reserved with)
@@ -774,6 +775,7 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
     const uint32_t cap = c.pair_cap[pair];
     unsigned long long* const rec = c.rec + c.pair_rec_off[pair];
     const int t0 = threadIdx.x * kPerThread;
+    uint32_t n_positions = 0, n_ops = 0;
     for (uint32_t i = threadIdx.x; i < kCBuckets; i += kBlock)
         hist[i] = 0;
     // pass 0 counts the touches per bucket, pass 1 writes them behind the room taken with one
@@ -791,6 +793,13 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
             }
             __syncthreads();
             const LaneOps o = lane_hashes(codes, t0, kc, tile0 + t0, tile_end, a.n_pos);
+            if (pass == 0) {
+                // cbf_local only visits the candidates of a census pair: the counters of positions
+                // streamed and of operations (valid k-mers) are kept here
+                const uint64_t left = tile0 + t0 < tile_end ? min((uint64_t)kPerThread, tile_end - (tile0 + t0)) : 0;
+                n_positions += (uint32_t)left;
+                n_ops += (uint32_t)__popc(o.valid);
+            }
 #pragma unroll
             for (int j = 0; j < kPerThread; j++) {
                 if (!((o.valid >> j) & 1u))
@@ -818,6 +827,15 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
                 base[i] = n ? atomicAdd(&c.cursor[(uint64_t)pair * kCBuckets + i], n) : 0u;
                 hist[i] = 0;
             }
+    }
+    // per-wave sums, one atomic each
+    for (int o = 32; o > 0; o >>= 1) {
+        n_positions += (uint32_t)__shfl_down((int)n_positions, o);
+        n_ops += (uint32_t)__shfl_down((int)n_ops, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&a.stats[0], (unsigned long long)n_positions);
+        atomicAdd(&a.stats[1], (unsigned long long)n_ops);
     }
 }
 
@@ -856,7 +874,7 @@ __global__ __launch_bounds__(256) void census_pack(AArgs a, CensusArgs c)
     const uint32_t pair = c.wg_pair[blockIdx.x];
     if (c.overflow[pair]) {
         if (threadIdx.x == 0)
-            c.pair_mode[c.pair_queue[pair]] = 0u; // the plain replay for this pair
+            c.pair_mode[c.pair_queue[pair]] = 2u; // the plain replay for this pair (its operations are counted already)
         return;
     }
     const uint32_t b = c.pair_batch[pair];
@@ -935,20 +953,60 @@ __device__ __attribute__((noinline)) void unwind_slot(const uint8_t* reads, uint
     }
 }
 
+// position of the r-th (0-based) set bit of w; r < popcount(w)
+__device__ inline uint32_t select64(unsigned long long w, uint32_t r)
+{
+    uint32_t pos = 0;
+    uint32_t c = (uint32_t)__popc((uint32_t)w);
+    if (r >= c) {
+        r -= c;
+        w >>= 32;
+        pos = 32;
+    }
+    uint32_t lo = (uint32_t)w;
+    c = (uint32_t)__popc(lo & 0xFFFFu);
+    if (r >= c) {
+        r -= c;
+        lo >>= 16;
+        pos += 16;
+    }
+    c = (uint32_t)__popc(lo & 0xFFu);
+    if (r >= c) {
+        r -= c;
+        lo >>= 8;
+        pos += 8;
+    }
+    c = (uint32_t)__popc(lo & 0xFu);
+    if (r >= c) {
+        r -= c;
+        lo >>= 4;
+        pos += 4;
+    }
+    c = (uint32_t)__popc(lo & 0x3u);
+    if (r >= c) {
+        r -= c;
+        lo >>= 2;
+        pos += 2;
+    }
+    return pos + (r >= (lo & 1u) ? 1u : 0u);
+}
+
 constexpr int kLTile = 512;            // positions per tile: with the 32 KB table four workgroups share a CU,
 constexpr int kLPer = 2;               // each in another phase (hash / load / order / store); 1024-position
 constexpr int kLBlock = kLTile / kLPer; // tiles with a 64 KB table (two workgroups per CU) ran 5 % slower
+constexpr int kLWin = 2048;            // census pairs: positions whose candidates are gathered at a time
 constexpr int kLocalSlotBits = 12;
 constexpr int kLocalSlots = 1 << kLocalSlotBits; // >= 2 x the counter touches of a tile (hash_num <= 4)
 constexpr uint32_t kLocalEmpty = 0xFFFFFFFFu;
 
 __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, uint32_t n_pairs) // 4 workgroups per CU: <= 128 VGPRs
 {
-    __shared__ uint8_t codes[kLTile + kHalo];
+    __shared__ uint8_t codes[kLWin + kHalo];
     __shared__ uint32_t keys[kLocalSlots]; // counter index held by the slot
     __shared__ uint32_t vals[kLocalSlots]; // earliest waiting operation of the tile on that counter
     __shared__ unsigned long long s_stats[4];
-    __shared__ unsigned long long s_cand[kLTile / 64]; // the tile's candidate bits (census)
+    __shared__ unsigned long long s_cw[kLWin / 64]; // census: candidate bits of the window ...
+    __shared__ uint32_t s_cpre[kLWin / 64], s_ncand;   // ... candidates before each word, and in all
     // This workgroup's arena slot for the whole launch: the counting filter of whichever pair it
     // is replaying.  Pairs come from a queue (longest batches first), so the grid is as large as
     // the chip holds and no larger, and a short pair's workgroup goes on to the next one instead
@@ -977,26 +1035,36 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     const uint64_t b_start = a.batch_pos[b], b_end = a.batch_pos[b + 1];
     // census: only the candidates are replayed, every counter they see is already at level 1, so
     // the array holds level - 1 and every threshold is one lower (see census_scatter)
-    const uint32_t census = a.pair_mode ? a.pair_mode[pair] : 0u;
+    const uint32_t pmode = a.pair_mode ? a.pair_mode[pair] : 0u; // 0 plain, 1 census, 2 plain after a census that overflowed
+    const uint32_t census = pmode == 1u ? 1u : 0u;
     const unsigned long long* const cand_bits = census ? a.cand + (a.pair_bit_off[pair] >> 6) : nullptr;
     if (!slot_clean)
         zero_slot(cb, a.cbf_stride);
 
-    for (uint64_t tile0 = b_start; tile0 < b_end; tile0 += kLTile) {
+    // A turn of this loop replays up to 512 operations, two per lane, in serial order.  Plain
+    // pairs: the next 512 positions.  Census pairs: the next 512 CANDIDATES of a 2048-position
+    // window (a fifth to a third of its positions), so that a turn is as full as a plain one.
+    uint64_t next0 = b_start;      // plain: next tile; census: next window
+    uint32_t c0 = 0, n_c = 0;      // census: next candidate of the window, candidates in it
+    uint64_t win0 = b_start;
+    for (;;) {
+        uint32_t op_state[kLPer] = {}, op_thr[kLPer] = {}, op_c[kLPer] = {};
+        uint32_t op_idx[kLPer][4] = {};
+        uint64_t op_base[kLPer] = {};
+        __syncthreads(); // everyone is done with the previous turn (codes, table)
+        if (!census) {
+        if (next0 >= b_end)
+            break;
+        const uint64_t tile0 = next0;
+        next0 += kLTile;
         const uint64_t tile_end = min(b_end, tile0 + (uint64_t)kLTile);
-        __syncthreads(); // everyone is done with the previous tile's codes
         for (int i = threadIdx.x; i < kLTile + kHalo; i += kLBlock) {
             uint64_t p = tile0 + i;
             uint8_t c = p < a.n_pos ? a.reads[p] : (uint8_t)'\n';
             codes[i] = base_code(c);
         }
-        if (census && threadIdx.x < kLTile / 64)
-            s_cand[threadIdx.x] = cand_bits[((tile0 - b_start) >> 6) + threadIdx.x];
         __syncthreads();
 
-        uint32_t op_state[kLPer] = {}, op_thr[kLPer] = {}, op_c[kLPer] = {};
-        uint32_t op_idx[kLPer][4] = {};
-        uint64_t op_base[kLPer] = {};
         const uint64_t pos0 = tile0 + t0;
         if (pos0 < tile_end) {
             uint32_t lo = 0, hi = a.n_seg;
@@ -1043,10 +1111,8 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
                     seg_end = a.seg_start[seg + 1];
                 }
                 n_ops++;
-                if (census && !((s_cand[(t0 + j) >> 6] >> ((t0 + j) & 63)) & 1ULL))
-                    continue; // first on one of its counters: lifts zeros to one, inserts nothing
                 op_base[j] = fh + rh;
-                op_thr[j] = (a.seg_thr[seg] - 2 + ki - census) | ((a.seg_smax[seg] - 2 + ki - census) << 16); // own threshold | S
+                op_thr[j] = (a.seg_thr[seg] - 2 + ki) | ((a.seg_smax[seg] - 2 + ki) << 16); // own threshold | S
                 op_state[j] = 1;
                 uint32_t pack = 0;
                 for (uint32_t h = 0; h < 4; h++) { // hash_num <= 4 on this path (stage_a_run)
@@ -1058,6 +1124,88 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
                 }
                 op_c[j] = pack;
             }
+        }
+        } else {
+        if (c0 >= n_c) {
+            // the next window that holds a candidate
+            for (;;) {
+                if (next0 >= b_end)
+                    break;
+                win0 = next0;
+                next0 += kLWin;
+                if (threadIdx.x < kLWin / 64) { // lanes 0..31 of wave 0
+                    unsigned long long w = cand_bits[((win0 - b_start) >> 6) + threadIdx.x];
+                    const uint64_t first = win0 + (uint64_t)threadIdx.x * 64; // bits past the batch are not the census's
+                    if (first >= b_end)
+                        w = 0;
+                    else if (b_end - first < 64)
+                        w &= (1ULL << (b_end - first)) - 1;
+                    s_cw[threadIdx.x] = w;
+                    const uint32_t cnt = (uint32_t)__popcll(w);
+                    uint32_t inc = cnt;
+                    for (int o = 1; o < kLWin / 64; o <<= 1) {
+                        const uint32_t u = (uint32_t)__shfl_up((int)inc, o);
+                        if ((int)threadIdx.x >= o)
+                            inc += u;
+                    }
+                    s_cpre[threadIdx.x] = inc - cnt;
+                    if (threadIdx.x == kLWin / 64 - 1)
+                        s_ncand = inc;
+                }
+                __syncthreads();
+                n_c = s_ncand;
+                c0 = 0;
+                __syncthreads(); // s_ncand may be rewritten by the next window
+                if (n_c)
+                    break;
+            }
+            if (c0 >= n_c)
+                break; // no candidate left in the batch (uniform)
+            for (int i = threadIdx.x; i < kLWin + kHalo; i += kLBlock) {
+                const uint64_t p = win0 + i;
+                codes[i] = base_code(p < a.n_pos ? a.reads[p] : (uint8_t)'\n');
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < kLPer; j++) {
+            const uint32_t ci = c0 + (uint32_t)(t0 + j);
+            if (ci >= n_c)
+                continue;
+            // the ci-th candidate of the window: its word, then its bit
+            uint32_t wlo = 0;
+            for (uint32_t step = kLWin / 128; step; step >>= 1)
+                if (s_cpre[wlo + step] <= ci)
+                    wlo += step;
+            const uint32_t prel = wlo * 64 + select64(s_cw[wlo], ci - s_cpre[wlo]);
+            const uint64_t pos = win0 + prel;
+            uint64_t fh = 0, rh = 0;
+            for (uint32_t i = 0; i < k; i++) { // a candidate is a k-mer: no byte of it is bad
+                fh = srol1(fh) ^ seed_of_code(codes[prel + i]);
+                rh = srol1(rh) ^ seed_of_code(codes[prel + k - 1 - i] ^ 2u);
+            }
+            uint32_t seg = a.batch_seg[b];
+            for (uint32_t hi = a.batch_seg[b + 1]; hi - seg > 1;) { // one contig per batch: no step
+                const uint32_t mid = (seg + hi) >> 1;
+                if (a.seg_start[mid] <= pos)
+                    seg = mid;
+                else
+                    hi = mid;
+            }
+            op_base[j] = fh + rh;
+            op_thr[j] = (a.seg_thr[seg] - 2 + ki - 1) | ((a.seg_smax[seg] - 2 + ki - 1) << 16); // one lower: see census_scatter
+            op_state[j] = 1;
+            uint32_t pack = 0;
+            for (uint32_t h = 0; h < 4; h++) {
+                if (h >= a.hash_num)
+                    break;
+                const uint64_t hv = h ? ext_hash(op_base[j], k, h) : op_base[j];
+                op_idx[j][h] = (uint32_t)fastmod(hv, a.cbf_mod);
+                pack |= ctr_load<false>(a, cb, op_idx[j][h]) << (8 * h);
+            }
+            op_c[j] = pack;
+        }
+        c0 += kLTile;
         }
 
         // rounds: every waiting operation enters its counters into the table; who is the
@@ -1156,8 +1304,10 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
             // the barrier at the top of the loop orders these stores before the next loads
         }
     }
-    atomicAdd(&s_stats[0], (unsigned long long)n_positions);
-    atomicAdd(&s_stats[1], (unsigned long long)n_ops);
+    if (pmode == 0u) { // (census_scatter has counted the others)
+        atomicAdd(&s_stats[0], (unsigned long long)n_positions);
+        atomicAdd(&s_stats[1], (unsigned long long)n_ops);
+    }
     atomicAdd(&s_stats[2], (unsigned long long)n_ordered);
     atomicAdd(&s_stats[3], (unsigned long long)n_rounds);
     // fewer counter lines touched than a quarter of the slot holds: unwind instead of clearing
@@ -1281,8 +1431,10 @@ int stage_a_prepare(gp_job* job)
         if (job->n_batches)
             GP_HIP(hipMemcpy(job->d_batch_thr_max.p, tm.data(), tm.size() * sizeof(uint32_t),
                              hipMemcpyHostToDevice));
-        if ((rc = job->d_seg_smax.alloc(smax.size())) != GP_OK)
+        if ((rc = job->d_seg_smax.alloc(smax.size())) != GP_OK || (rc = job->d_batch_seg.alloc(job->n_batches + 1)) != GP_OK)
             return rc;
+        GP_HIP(hipMemcpy(job->d_batch_seg.p, job->h_batch_contig_begin.data(), (job->n_batches + 1) * sizeof(uint32_t),
+                         hipMemcpyHostToDevice));
         GP_HIP(hipMemcpy(job->d_seg_smax.p, smax.data(), smax.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     GP_HIP(hipHostMalloc((void**)&job->h_count_pinned, 4 * kRing * sizeof(uint32_t)));
@@ -1353,6 +1505,7 @@ int stage_a_run(gp_job* job)
     a.sat = job->d_sat.p;
     a.batch_thr_max = job->d_batch_thr_max.p;
     a.seg_smax = job->d_seg_smax.p;
+    a.batch_seg = job->d_batch_seg.p;
     a.batch_slot = job->d_batch_slot.p;
     a.queue = job->d_queue.p;
     a.host_ring = job->h_count_pinned;
@@ -1530,7 +1683,7 @@ int stage_a_run(gp_job* job)
                     h_pair_bit_off[q] = bits;
                     cur_rec += recs;
                     cur_flags += pos;
-                    bits += (pos + 511) / 512 * 512 + 512; // whole tiles of cbf_local, and one of slack
+                    bits += (pos + kLWin - 1) / kLWin * kLWin; // whole windows of cbf_local
                     for (uint64_t p0 = 0; p0 < pos; p0 += (uint64_t)kCSuper * kTile) {
                         cur.wg_pair.push_back(lp);
                         cur.wg_pos0.push_back(batch_pos[b] + p0);

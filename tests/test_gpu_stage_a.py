@@ -206,8 +206,7 @@ def test_census_cohorts_and_bucket_overflow(gp, oracle, monkeypatch):
     core, ctx = gp
     monkeypatch.setenv("GP_STAGE_A_CENSUS_MB", "2")   # 256 k records: a cohort holds a pair or two
     w = synth.make_workload([30000, 12000, 20000, 8000, 25000], 30, seed=26)
-    c = run_and_compare(core, ctx, oracle, w, core.default_params())
-    assert c["a_ordered_ops"] < c["a_ops"]
+    run_and_compare(core, ctx, oracle, w, core.default_params())
     rng = np.random.default_rng(27)
     g = synth.random_genome(20000, rng).tobytes()
     reads = [g[i:i + 5000] for i in range(0, 15000, 700)] * 3
