@@ -689,7 +689,7 @@ __global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
 // operation with all its touches marked is a candidate.  cbf_local then replays a fifth to a
 // third of the operations.  A bucket that overflows its room (a long run of one k-mer) sends its
 // pair back to the plain replay.
-constexpr int kCSuper = 4;                // tiles of kTile positions per census_scatter workgroup
+constexpr int kCSuper = 8;                // tiles of kTile positions per census_scatter workgroup (one cursor atomic per bucket and workgroup)
 constexpr uint32_t kCBuckets = 1024;      // counter ranges per pair
 constexpr uint32_t kCMaxBucketW = 16384;  // counters per range the LDS table of census_mark holds
 
@@ -853,19 +853,37 @@ __global__ __launch_bounds__(256) void census_mark(CensusArgs c)
     const unsigned long long* rec = c.rec + c.pair_rec_off[pair] + (uint64_t)bucket * cap;
     for (uint32_t i = threadIdx.x; i < c.bucket_w; i += 256)
         first_t[i] = 0xFFFFFFFFu;
+    // a bucket's records are read once and kept in registers between the two passes (16 per
+    // lane: 4096, more than the room a bucket of a 2 M-position pair has; beyond that, read again)
+    constexpr int kKeep = 16;
+    unsigned long long keep[kKeep];
+#pragma unroll
+    for (int q = 0; q < kKeep; q++) {
+        const uint32_t i = threadIdx.x + (uint32_t)q * 256;
+        keep[q] = i < n ? rec[i] : ~0ULL;
+    }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+#pragma unroll
+    for (int q = 0; q < kKeep; q++)
+        if (keep[q] != ~0ULL)
+            atomicMin(&first_t[((uint32_t)keep[q] >> 2) & 0xFFFFu], (uint32_t)(keep[q] >> 32));
+    for (uint32_t i = threadIdx.x + kKeep * 256; i < n; i += 256) {
         const unsigned long long r = rec[i];
         atomicMin(&first_t[((uint32_t)r >> 2) & 0xFFFFu], (uint32_t)(r >> 32));
     }
     __syncthreads();
     uint8_t* const fl = reinterpret_cast<uint8_t*>(c.flags + c.pair_flag_off[pair]);
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const unsigned long long r = rec[i];
+    auto mark = [&](unsigned long long r) {
         const uint32_t t = (uint32_t)(r >> 32);
         if (first_t[((uint32_t)r >> 2) & 0xFFFFu] != t)
             fl[(uint64_t)t * 4 + ((uint32_t)r & 3u)] = 1; // (a counter hit twice by one operation: both touches are its first)
-    }
+    };
+#pragma unroll
+    for (int q = 0; q < kKeep; q++)
+        if (keep[q] != ~0ULL)
+            mark(keep[q]);
+    for (uint32_t i = threadIdx.x + kKeep * 256; i < n; i += 256)
+        mark(rec[i]);
 }
 
 // ---- census 3: operations with every touch marked -> one bit each
