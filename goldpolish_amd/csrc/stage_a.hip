@@ -683,32 +683,35 @@ __global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
 // k = 20 on 25 kbp contigs with 40x reads) -- sees only counters >= 1 and only moves them among
 // levels >= 1, so it is an ordinary conservative-update replay of the candidates alone with every
 // counter starting at level 1: thresholds one lower on a zero array.  The census finds the
-// candidates without random memory traffic: every counter touch goes as an 8-byte record into
-// the bucket of its counter range (1024 ranges per pair, coalesced runs), a workgroup per bucket
-// takes the earliest position per counter in LDS and marks the touches that are not it, and an
-// operation with all its touches marked is a candidate.  cbf_local then replays a fifth to a
-// third of the operations.  A bucket that overflows its room (a long run of one k-mer) sends its
-// pair back to the plain replay.
-constexpr int kCSuper = 8;                // tiles of kTile positions per census_scatter workgroup (one cursor atomic per bucket and workgroup)
+// candidates without random memory traffic: every counter touch goes as a 4-byte record into
+// the bucket of its counter range (1024 ranges per pair, a run of 64 slots per 6144-position
+// stretch and bucket), a workgroup per bucket takes the earliest position per counter in LDS and
+// marks the touches that are not it, and an operation with all its touches marked is a
+// candidate.  cbf_local then replays a fifth to a third of the operations.  A run that overflows
+// (many copies of one k-mer within a stretch) sends its pair back to the plain replay.
+constexpr int kCSuper = 6;                // tiles of kTile positions per census_scatter workgroup: a 6144-position stretch
+constexpr uint32_t kCStretch = kCSuper * kTile;
 constexpr uint32_t kCBuckets = 1024;      // counter ranges per pair
-constexpr uint32_t kCMaxBucketW = 16384;  // counters per range the LDS table of census_mark holds
+constexpr uint32_t kCRun = 64;            // records a stretch may leave in one bucket (24 expected at four hashes)
+constexpr uint32_t kCMaxBucketW = 16384;  // counters per range: 14 bits of a record, 64 KB of LDS in census_mark
 
 struct CensusArgs {
-    const uint32_t* wg_pair;       // [workgroups] pair (cohort-local) of a 4096-position stretch
+    const uint32_t* wg_pair;       // [workgroups] pair (cohort-local) of a stretch
     const uint64_t* wg_pos0;       // [workgroups] its first read position
     uint32_t n_wg;
     const uint32_t* pair_batch;    // [pairs]
     const uint32_t* pair_ki;       // [pairs]
-    const uint32_t* pair_cap;      // [pairs] records a bucket of the pair has room for
-    const uint64_t* pair_rec_off;  // [pairs] first record of the pair's buckets
+    const uint32_t* pair_nst;      // [pairs] stretches of the pair
+    const uint64_t* pair_rec_off;  // [pairs] first record of the pair: rec[bucket][stretch][kCRun]
+    const uint64_t* pair_cnt_off;  // [pairs] first count of the pair: cnt[bucket][stretch]
     const uint64_t* pair_flag_off; // [pairs] first position of the pair in `flags`
     const uint64_t* pair_bit_off;  // [pairs] first bit of the pair in `cand` (multiple of 64)
     const uint32_t* pair_queue;    // [pairs] index of the pair in cbf_local's queue (for pair_mode)
-    uint32_t* cursor;              // [pairs][kCBuckets] records written
-    unsigned long long* rec;       // (position in the batch << 32) | (counter in its range << 2) | hash number
+    uint32_t* rec;                 // (position in the stretch << 16) | (counter in its range << 2) | hash number
+    uint8_t* cnt;                  // records a stretch left in a bucket
     uint32_t* flags;               // one byte per (position, hash): 1 = that touch is not the counter's first
     uint32_t* overflow;            // [pairs]
-    uint32_t* pair_mode;           // [queue entries] cleared for pairs that overflowed
+    uint32_t* pair_mode;           // [queue entries] set to 2 for pairs that overflowed
     unsigned long long* cand;
     uint32_t bucket_w;
 };
@@ -760,74 +763,66 @@ __device__ inline LaneOps lane_hashes(const uint8_t* codes, int t0, const KConst
     return o;
 }
 
-// ---- census 1: every counter touch of a 4096-position stretch into the bucket of its counter range
+// ---- census 1: every counter touch of a 6144-position stretch into the bucket of its counter
+// range.  A stretch has a run of kCRun record slots of its own in every bucket, so nothing is
+// counted first and no cursor is shared: one hashing pass, 4-byte records (the stretch and the
+// bucket are in the address), a workgroup's stores to a run are contiguous and merge in L2.
 __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
 {
     __shared__ uint8_t codes[kTile + kHalo];
-    __shared__ uint32_t hist[kCBuckets], base[kCBuckets];
+    __shared__ uint32_t hist[kCBuckets];
     const uint32_t pair = c.wg_pair[blockIdx.x];
     const uint32_t b = c.pair_batch[pair], ki = c.pair_ki[pair];
     const KConsts& kc = a.kc[ki];
     const uint32_t k = kc.k;
     const uint64_t b_start = a.batch_pos[b], b_end = a.batch_pos[b + 1];
     const uint64_t pos0 = c.wg_pos0[blockIdx.x];
-    const uint64_t stretch_end = min(b_end, pos0 + (uint64_t)kCSuper * kTile);
-    const uint32_t cap = c.pair_cap[pair];
-    unsigned long long* const rec = c.rec + c.pair_rec_off[pair];
+    const uint64_t stretch_end = min(b_end, pos0 + (uint64_t)kCStretch);
+    const uint32_t nst = c.pair_nst[pair], stretch = (uint32_t)((pos0 - b_start) / kCStretch);
+    uint32_t* const rec = c.rec + c.pair_rec_off[pair];
     const int t0 = threadIdx.x * kPerThread;
     uint32_t n_positions = 0, n_ops = 0;
+    bool over = false;
     for (uint32_t i = threadIdx.x; i < kCBuckets; i += kBlock)
         hist[i] = 0;
-    // pass 0 counts the touches per bucket, pass 1 writes them behind the room taken with one
-    // atomic per bucket: the runs of a workgroup are contiguous, so L2 merges the 8-byte stores
-    for (int pass = 0; pass < 2; pass++) {
-        for (int st = 0; st < kCSuper; st++) {
-            const uint64_t tile0 = pos0 + (uint64_t)st * kTile;
-            if (tile0 >= stretch_end)
-                break; // uniform
-            const uint64_t tile_end = min(stretch_end, tile0 + (uint64_t)kTile);
-            __syncthreads(); // codes free (and hist cleared / base written before the first use)
-            for (int i = threadIdx.x; i < kTile + kHalo; i += kBlock) {
-                const uint64_t p = tile0 + i;
-                codes[i] = base_code(p < a.n_pos ? a.reads[p] : (uint8_t)'\n');
-            }
-            __syncthreads();
-            const LaneOps o = lane_hashes(codes, t0, kc, tile0 + t0, tile_end, a.n_pos);
-            if (pass == 0) {
-                // cbf_local only visits the candidates of a census pair: the counters of positions
-                // streamed and of operations (valid k-mers) are kept here
-                const uint64_t left = tile0 + t0 < tile_end ? min((uint64_t)kPerThread, tile_end - (tile0 + t0)) : 0;
-                n_positions += (uint32_t)left;
-                n_ops += (uint32_t)__popc(o.valid);
-            }
-#pragma unroll
-            for (int j = 0; j < kPerThread; j++) {
-                if (!((o.valid >> j) & 1u))
-                    continue;
-                const uint32_t t = (uint32_t)(tile0 + t0 + j - b_start);
-                for (uint32_t h = 0; h < a.hash_num; h++) {
-                    const uint32_t ix = (uint32_t)fastmod(h ? ext_hash(o.base[j], k, h) : o.base[j], a.cbf_mod);
-                    const uint32_t bucket = ix / c.bucket_w;
-                    const uint32_t rank = atomicAdd(&hist[bucket], 1u);
-                    if (pass == 1) {
-                        const uint32_t slot = base[bucket] + rank;
-                        if (slot < cap)
-                            rec[(uint64_t)bucket * cap + slot] =
-                                ((unsigned long long)t << 32) | ((ix - bucket * c.bucket_w) << 2) | h;
-                        else
-                            c.overflow[pair] = 1u;
-                    }
-                }
-            }
+    for (int st = 0; st < kCSuper; st++) {
+        const uint64_t tile0 = pos0 + (uint64_t)st * kTile;
+        if (tile0 >= stretch_end)
+            break; // uniform
+        const uint64_t tile_end = min(stretch_end, tile0 + (uint64_t)kTile);
+        __syncthreads(); // codes free (and hist cleared before the first use)
+        for (int i = threadIdx.x; i < kTile + kHalo; i += kBlock) {
+            const uint64_t p = tile0 + i;
+            codes[i] = base_code(p < a.n_pos ? a.reads[p] : (uint8_t)'\n');
         }
         __syncthreads();
-        if (pass == 0)
-            for (uint32_t i = threadIdx.x; i < kCBuckets; i += kBlock) {
-                const uint32_t n = hist[i];
-                base[i] = n ? atomicAdd(&c.cursor[(uint64_t)pair * kCBuckets + i], n) : 0u;
-                hist[i] = 0;
+        const LaneOps o = lane_hashes(codes, t0, kc, tile0 + t0, tile_end, a.n_pos);
+        // cbf_local only visits the candidates of a census pair: the counters of positions
+        // streamed and of operations (valid k-mers) are kept here
+        n_positions += tile0 + t0 < tile_end ? (uint32_t)min((uint64_t)kPerThread, tile_end - (tile0 + t0)) : 0u;
+        n_ops += (uint32_t)__popc(o.valid);
+#pragma unroll
+        for (int j = 0; j < kPerThread; j++) {
+            if (!((o.valid >> j) & 1u))
+                continue;
+            const uint32_t off = (uint32_t)(st * kTile + t0 + j); // position in the stretch, < 6144
+            for (uint32_t h = 0; h < a.hash_num; h++) {
+                const uint32_t ix = (uint32_t)fastmod(h ? ext_hash(o.base[j], k, h) : o.base[j], a.cbf_mod);
+                const uint32_t bucket = ix / c.bucket_w;
+                const uint32_t rank = atomicAdd(&hist[bucket], 1u);
+                if (rank < kCRun)
+                    rec[((uint64_t)bucket * nst + stretch) * kCRun + rank] = (off << 16) | ((ix - bucket * c.bucket_w) << 2) | h;
+                else
+                    over = true;
             }
+        }
     }
+    __syncthreads();
+    uint8_t* const cnt = c.cnt + c.pair_cnt_off[pair];
+    for (uint32_t i = threadIdx.x; i < kCBuckets; i += kBlock)
+        cnt[(uint64_t)i * nst + stretch] = (uint8_t)min(hist[i], kCRun);
+    if (over)
+        c.overflow[pair] = 1u; // a long run of one k-mer: this pair is replayed whole
     // per-wave sums, one atomic each
     for (int o = 32; o > 0; o >>= 1) {
         n_positions += (uint32_t)__shfl_down((int)n_positions, o);
@@ -839,51 +834,35 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
     }
 }
 
-// ---- census 2: per bucket, the earliest position per counter; every later touch is marked
+// ---- census 2: per bucket, the earliest position per counter; every later touch is marked.
+// A wave takes a stretch's run at a time (a 256-byte line of records, as many lanes as it holds).
 __global__ __launch_bounds__(256) void census_mark(CensusArgs c)
 {
     extern __shared__ uint32_t first_t[]; // bucket_w words (40 KB at GoldPolish's 10 MiB: four workgroups per CU)
     const uint32_t pair = blockIdx.x / kCBuckets, bucket = blockIdx.x % kCBuckets;
     if (c.overflow[pair])
         return;
-    const uint32_t cap = c.pair_cap[pair];
-    const uint32_t n = min(c.cursor[(uint64_t)pair * kCBuckets + bucket], cap);
-    if (n == 0)
-        return;
-    const unsigned long long* rec = c.rec + c.pair_rec_off[pair] + (uint64_t)bucket * cap;
+    const uint32_t nst = c.pair_nst[pair];
+    const uint32_t* rec = c.rec + c.pair_rec_off[pair] + (uint64_t)bucket * nst * kCRun;
+    const uint8_t* cnt = c.cnt + c.pair_cnt_off[pair] + (uint64_t)bucket * nst;
     for (uint32_t i = threadIdx.x; i < c.bucket_w; i += 256)
         first_t[i] = 0xFFFFFFFFu;
-    // a bucket's records are read once and kept in registers between the two passes (16 per
-    // lane: 4096, more than the room a bucket of a 2 M-position pair has; beyond that, read again)
-    constexpr int kKeep = 16;
-    unsigned long long keep[kKeep];
-#pragma unroll
-    for (int q = 0; q < kKeep; q++) {
-        const uint32_t i = threadIdx.x + (uint32_t)q * 256;
-        keep[q] = i < n ? rec[i] : ~0ULL;
-    }
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < kKeep; q++)
-        if (keep[q] != ~0ULL)
-            atomicMin(&first_t[((uint32_t)keep[q] >> 2) & 0xFFFFu], (uint32_t)(keep[q] >> 32));
-    for (uint32_t i = threadIdx.x + kKeep * 256; i < n; i += 256) {
-        const unsigned long long r = rec[i];
-        atomicMin(&first_t[((uint32_t)r >> 2) & 0xFFFFu], (uint32_t)(r >> 32));
-    }
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t st = wave; st < nst; st += 4)
+        if (lane < cnt[st]) {
+            const uint32_t r = rec[(uint64_t)st * kCRun + lane];
+            atomicMin(&first_t[(r >> 2) & 0x3FFFu], st * kCStretch + (r >> 16));
+        }
     __syncthreads();
     uint8_t* const fl = reinterpret_cast<uint8_t*>(c.flags + c.pair_flag_off[pair]);
-    auto mark = [&](unsigned long long r) {
-        const uint32_t t = (uint32_t)(r >> 32);
-        if (first_t[((uint32_t)r >> 2) & 0xFFFFu] != t)
-            fl[(uint64_t)t * 4 + ((uint32_t)r & 3u)] = 1; // (a counter hit twice by one operation: both touches are its first)
-    };
-#pragma unroll
-    for (int q = 0; q < kKeep; q++)
-        if (keep[q] != ~0ULL)
-            mark(keep[q]);
-    for (uint32_t i = threadIdx.x + kKeep * 256; i < n; i += 256)
-        mark(rec[i]);
+    for (uint32_t st = wave; st < nst; st += 4)
+        if (lane < cnt[st]) {
+            const uint32_t r = rec[(uint64_t)st * kCRun + lane];
+            const uint32_t t = st * kCStretch + (r >> 16);
+            if (first_t[(r >> 2) & 0x3FFFu] != t)
+                fl[(uint64_t)t * 4 + (r & 3u)] = 1; // (a counter hit twice by one operation: both touches are its first)
+        }
 }
 
 // ---- census 3: operations with every touch marked -> one bit each
@@ -898,7 +877,7 @@ __global__ __launch_bounds__(256) void census_pack(AArgs a, CensusArgs c)
     const uint32_t b = c.pair_batch[pair];
     const uint64_t b_start = a.batch_pos[b], b_end = a.batch_pos[b + 1];
     const uint64_t pos0 = c.wg_pos0[blockIdx.x];
-    const uint64_t stretch_end = min(b_end, pos0 + (uint64_t)kCSuper * kTile);
+    const uint64_t stretch_end = min(b_end, pos0 + (uint64_t)kCStretch);
     const uint32_t all = a.hash_num >= 4 ? 0x01010101u : ((1u << (8 * a.hash_num)) - 1u) & 0x01010101u;
     const uint32_t* fl = c.flags + c.pair_flag_off[pair];
     for (uint64_t p0 = pos0; p0 < stretch_end; p0 += 256) {
@@ -1621,8 +1600,8 @@ int stage_a_run(gp_job* job)
     const uint32_t n_local = job->n_batches - n_big;
     // census tables: host copies stay alive until the stream has been synchronised at the end
     struct Cohort {
-        std::vector<uint32_t> wg_pair, pair_batch, pair_ki, pair_cap, pair_queue, tab32;
-        std::vector<uint64_t> wg_pos0, pair_rec_off, pair_flag_off, pair_bit_off, tab64;
+        std::vector<uint32_t> wg_pair, pair_batch, pair_ki, pair_nst, pair_queue, tab32;
+        std::vector<uint64_t> wg_pos0, pair_rec_off, pair_cnt_off, pair_flag_off, pair_bit_off, tab64;
     };
     std::vector<Cohort> cohorts;
     std::vector<uint32_t> h_pair_mode;
@@ -1657,22 +1636,23 @@ int stage_a_run(gp_job* job)
         const uint32_t bucket_w = (uint32_t)((p.cbf_bytes + kCBuckets - 1) / kCBuckets);
         if (env_u64("GP_STAGE_A_CENSUS", 1) && p.hash_num <= 4 && bucket_w <= kCMaxBucketW) {
             const uint64_t min_pos = env_u64("GP_STAGE_A_CENSUS_MIN", 65536);           // below: too few touches per bucket
-            const uint64_t rec_budget = (env_u64("GP_STAGE_A_CENSUS_MB", 8192) << 20) / 8; // records of a cohort
+            const uint64_t rec_budget = (env_u64("GP_STAGE_A_CENSUS_MB", 8192) << 20) / 4; // (4-byte) record slots of a cohort
             h_pair_mode.assign(n_pairs, 0);
             h_pair_bit_off.assign(n_pairs, 0);
-            uint64_t bits = 0, max_rec = 0, max_flags = 0, max_pairs = 0, max_wg = 0;
+            uint64_t bits = 0, max_rec = 0, max_cnt = 0, max_flags = 0, max_pairs = 0, max_wg = 0;
             Cohort cur;
-            uint64_t cur_rec = 0, cur_flags = 0;
+            uint64_t cur_rec = 0, cur_cnt = 0, cur_flags = 0;
             auto close = [&]() {
                 if (cur.pair_batch.empty())
                     return;
                 max_rec = std::max(max_rec, cur_rec);
+                max_cnt = std::max(max_cnt, cur_cnt);
                 max_flags = std::max(max_flags, cur_flags);
                 max_pairs = std::max<uint64_t>(max_pairs, cur.pair_batch.size());
                 max_wg = std::max<uint64_t>(max_wg, cur.wg_pair.size());
                 cohorts.push_back(std::move(cur));
                 cur = Cohort();
-                cur_rec = cur_flags = 0;
+                cur_rec = cur_cnt = cur_flags = 0;
             };
             for (uint32_t i = 0; i < n_local; i++) {
                 const uint32_t b = order[n_big + i];
@@ -1681,9 +1661,8 @@ int stage_a_run(gp_job* job)
                 // it has seen a few times its size: the census pays up to about two touches per counter
                 if (pos < min_pos || pos >= (1ull << 32) || pos * p.hash_num > 2 * p.cbf_bytes)
                     continue;
-                const double mu = (double)pos * p.hash_num / kCBuckets;
-                const uint32_t cap = (uint32_t)(mu + 8.0 * std::sqrt(mu) + 32.0);
-                const uint64_t recs = (uint64_t)cap * kCBuckets;
+                const uint32_t nst = (uint32_t)((pos + kCStretch - 1) / kCStretch);
+                const uint64_t recs = (uint64_t)kCBuckets * nst * kCRun; // a run of slots per bucket and stretch
                 if (recs * p.n_k > rec_budget)
                     continue; // a batch that would not fit a cohort by itself
                 if (cur_rec + recs * p.n_k > rec_budget)
@@ -1692,17 +1671,19 @@ int stage_a_run(gp_job* job)
                     const uint32_t q = i * p.n_k + ki, lp = (uint32_t)cur.pair_batch.size();
                     cur.pair_batch.push_back(b);
                     cur.pair_ki.push_back(ki);
-                    cur.pair_cap.push_back(cap);
+                    cur.pair_nst.push_back(nst);
                     cur.pair_queue.push_back(q);
                     cur.pair_rec_off.push_back(cur_rec);
+                    cur.pair_cnt_off.push_back(cur_cnt);
                     cur.pair_flag_off.push_back(cur_flags);
                     cur.pair_bit_off.push_back(bits);
                     h_pair_mode[q] = 1;
                     h_pair_bit_off[q] = bits;
                     cur_rec += recs;
+                    cur_cnt += (uint64_t)kCBuckets * nst;
                     cur_flags += pos;
                     bits += (pos + kLWin - 1) / kLWin * kLWin; // whole windows of cbf_local
-                    for (uint64_t p0 = 0; p0 < pos; p0 += (uint64_t)kCSuper * kTile) {
+                    for (uint64_t p0 = 0; p0 < pos; p0 += kCStretch) {
                         cur.wg_pair.push_back(lp);
                         cur.wg_pos0.push_back(batch_pos[b] + p0);
                     }
@@ -1712,10 +1693,10 @@ int stage_a_run(gp_job* job)
             if (!cohorts.empty()) {
                 int rcc;
                 if ((rcc = job->d_census_rec.ensure(max_rec)) != GP_OK || (rcc = job->d_census_flags.ensure(max_flags)) != GP_OK ||
-                    (rcc = job->d_census_cursor.ensure(max_pairs * kCBuckets)) != GP_OK ||
+                    (rcc = job->d_census_cnt.ensure(max_cnt)) != GP_OK ||
                     (rcc = job->d_census_over.ensure(max_pairs)) != GP_OK ||
                     (rcc = job->d_census_tab32.ensure(max_wg + 4 * max_pairs)) != GP_OK ||
-                    (rcc = job->d_census_tab64.ensure(max_wg + 3 * max_pairs)) != GP_OK ||
+                    (rcc = job->d_census_tab64.ensure(max_wg + 4 * max_pairs)) != GP_OK ||
                     (rcc = job->d_cand.ensure(bits / 64)) != GP_OK || (rcc = job->d_pair_mode.ensure(n_pairs)) != GP_OK ||
                     (rcc = job->d_pair_bit_off.ensure(n_pairs)) != GP_OK)
                     return rcc;
@@ -1731,11 +1712,12 @@ int stage_a_run(gp_job* job)
                     co.tab32.insert(co.tab32.end(), co.wg_pair.begin(), co.wg_pair.end());
                     co.tab32.insert(co.tab32.end(), co.pair_batch.begin(), co.pair_batch.end());
                     co.tab32.insert(co.tab32.end(), co.pair_ki.begin(), co.pair_ki.end());
-                    co.tab32.insert(co.tab32.end(), co.pair_cap.begin(), co.pair_cap.end());
+                    co.tab32.insert(co.tab32.end(), co.pair_nst.begin(), co.pair_nst.end());
                     co.tab32.insert(co.tab32.end(), co.pair_queue.begin(), co.pair_queue.end());
-                    co.tab64.reserve(nw + 3 * np);
+                    co.tab64.reserve(nw + 4 * np);
                     co.tab64.insert(co.tab64.end(), co.wg_pos0.begin(), co.wg_pos0.end());
                     co.tab64.insert(co.tab64.end(), co.pair_rec_off.begin(), co.pair_rec_off.end());
+                    co.tab64.insert(co.tab64.end(), co.pair_cnt_off.begin(), co.pair_cnt_off.end());
                     co.tab64.insert(co.tab64.end(), co.pair_flag_off.begin(), co.pair_flag_off.end());
                     co.tab64.insert(co.tab64.end(), co.pair_bit_off.begin(), co.pair_bit_off.end());
                     GP_HIP(hipMemcpyAsync(job->d_census_tab32.p, co.tab32.data(), co.tab32.size() * sizeof(uint32_t),
@@ -1745,22 +1727,22 @@ int stage_a_run(gp_job* job)
                     uint64_t flags_n = 0;
                     for (size_t i = 0; i < np; i++)
                         flags_n = std::max<uint64_t>(flags_n, co.pair_flag_off[i] + (batch_pos[co.pair_batch[i] + 1] - batch_pos[co.pair_batch[i]]));
-                    GP_HIP(hipMemsetAsync(job->d_census_cursor.p, 0, np * kCBuckets * sizeof(uint32_t), s));
                     GP_HIP(hipMemsetAsync(job->d_census_over.p, 0, np * sizeof(uint32_t), s));
                     GP_HIP(hipMemsetAsync(job->d_census_flags.p, 0, flags_n * sizeof(uint32_t), s));
                     CensusArgs c{};
                     c.wg_pair = job->d_census_tab32.p;
                     c.pair_batch = c.wg_pair + nw;
                     c.pair_ki = c.pair_batch + np;
-                    c.pair_cap = c.pair_ki + np;
-                    c.pair_queue = c.pair_cap + np;
+                    c.pair_nst = c.pair_ki + np;
+                    c.pair_queue = c.pair_nst + np;
                     c.wg_pos0 = job->d_census_tab64.p;
                     c.pair_rec_off = c.wg_pos0 + nw;
-                    c.pair_flag_off = c.pair_rec_off + np;
+                    c.pair_cnt_off = c.pair_rec_off + np;
+                    c.pair_flag_off = c.pair_cnt_off + np;
                     c.pair_bit_off = c.pair_flag_off + np;
                     c.n_wg = (uint32_t)nw;
-                    c.cursor = job->d_census_cursor.p;
                     c.rec = job->d_census_rec.p;
+                    c.cnt = job->d_census_cnt.p;
                     c.flags = job->d_census_flags.p;
                     c.overflow = job->d_census_over.p;
                     c.pair_mode = job->d_pair_mode.p;
