@@ -689,10 +689,10 @@ __global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
 // marks the touches that are not it, and an operation with all its touches marked is a
 // candidate.  cbf_local then replays a fifth to a third of the operations.  A run that overflows
 // (many copies of one k-mer within a stretch) sends its pair back to the plain replay.
-constexpr int kCSuper = 6;                // tiles of kTile positions per census_scatter workgroup: a 6144-position stretch
+constexpr int kCSuper = 2;                // tiles of kTile positions per census_scatter workgroup: a 2048-position stretch
 constexpr uint32_t kCStretch = kCSuper * kTile;
 constexpr uint32_t kCBuckets = 1024;      // counter ranges per pair
-constexpr uint32_t kCRun = 64;            // records a stretch may leave in one bucket (24 expected at four hashes)
+constexpr uint32_t kCRun = 32;            // records a stretch may leave in one bucket (8 expected at four hashes)
 constexpr uint32_t kCMaxBucketW = 16384;  // counters per range: 14 bits of a record, 64 KB of LDS in census_mark
 
 struct CensusArgs {
@@ -763,14 +763,17 @@ __device__ inline LaneOps lane_hashes(const uint8_t* codes, int t0, const KConst
     return o;
 }
 
-// ---- census 1: every counter touch of a 6144-position stretch into the bucket of its counter
-// range.  A stretch has a run of kCRun record slots of its own in every bucket, so nothing is
-// counted first and no cursor is shared: one hashing pass, 4-byte records (the stretch and the
-// bucket are in the address), a workgroup's stores to a run are contiguous and merge in L2.
+// ---- census 1: every counter touch of a 2048-position stretch into the bucket of its counter
+// range.  A stretch has a run of kCRun record slots of its own in every bucket (the stretch and
+// the bucket are in the address: 4-byte records, no shared cursor).  The records are sorted by
+// bucket in LDS first (count, scan, place: two hashing passes) and every run is then written in
+// one go -- written as they are hashed, the 1024 open runs of each of the workgroups on an XCD
+// (256 KB each) were evicted from L2 half full over and over: 43 ms instead of SCATTER_MS for 1.2 G
+// positions.
 __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
 {
     __shared__ uint8_t codes[kTile + kHalo];
-    __shared__ uint32_t hist[kCBuckets];
+    __shared__ uint32_t hist[kCBuckets], base[kCBuckets], stage[kCStretch * 4], s_wsum[kBlock / 64];
     const uint32_t pair = c.wg_pair[blockIdx.x];
     const uint32_t b = c.pair_batch[pair], ki = c.pair_ki[pair];
     const KConsts& kc = a.kc[ki];
@@ -779,50 +782,87 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
     const uint64_t pos0 = c.wg_pos0[blockIdx.x];
     const uint64_t stretch_end = min(b_end, pos0 + (uint64_t)kCStretch);
     const uint32_t nst = c.pair_nst[pair], stretch = (uint32_t)((pos0 - b_start) / kCStretch);
-    uint32_t* const rec = c.rec + c.pair_rec_off[pair];
     const int t0 = threadIdx.x * kPerThread;
     uint32_t n_positions = 0, n_ops = 0;
-    bool over = false;
     for (uint32_t i = threadIdx.x; i < kCBuckets; i += kBlock)
         hist[i] = 0;
-    for (int st = 0; st < kCSuper; st++) {
-        const uint64_t tile0 = pos0 + (uint64_t)st * kTile;
-        if (tile0 >= stretch_end)
-            break; // uniform
-        const uint64_t tile_end = min(stretch_end, tile0 + (uint64_t)kTile);
-        __syncthreads(); // codes free (and hist cleared before the first use)
-        for (int i = threadIdx.x; i < kTile + kHalo; i += kBlock) {
-            const uint64_t p = tile0 + i;
-            codes[i] = base_code(p < a.n_pos ? a.reads[p] : (uint8_t)'\n');
+    for (int pass = 0; pass < 2; pass++) {
+        for (int st = 0; st < kCSuper; st++) {
+            const uint64_t tile0 = pos0 + (uint64_t)st * kTile;
+            if (tile0 >= stretch_end)
+                break; // uniform
+            const uint64_t tile_end = min(stretch_end, tile0 + (uint64_t)kTile);
+            __syncthreads(); // codes free (hist cleared / base written before their first use)
+            for (int i = threadIdx.x; i < kTile + kHalo; i += kBlock) {
+                const uint64_t p = tile0 + i;
+                codes[i] = base_code(p < a.n_pos ? a.reads[p] : (uint8_t)'\n');
+            }
+            __syncthreads();
+            const LaneOps o = lane_hashes(codes, t0, kc, tile0 + t0, tile_end, a.n_pos);
+            if (pass == 0) {
+                // cbf_local only visits the candidates of a census pair: the counters of positions
+                // streamed and of operations (valid k-mers) are kept here
+                n_positions += tile0 + t0 < tile_end ? (uint32_t)min((uint64_t)kPerThread, tile_end - (tile0 + t0)) : 0u;
+                n_ops += (uint32_t)__popc(o.valid);
+            }
+#pragma unroll
+            for (int j = 0; j < kPerThread; j++) {
+                if (!((o.valid >> j) & 1u))
+                    continue;
+                const uint32_t off = (uint32_t)(st * kTile + t0 + j); // position in the stretch
+                for (uint32_t h = 0; h < a.hash_num; h++) {
+                    const uint32_t ix = (uint32_t)fastmod(h ? ext_hash(o.base[j], k, h) : o.base[j], a.cbf_mod);
+                    const uint32_t bucket = ix / c.bucket_w;
+                    const uint32_t rank = atomicAdd(&hist[bucket], 1u);
+                    if (pass == 1)
+                        stage[base[bucket] + rank] = (off << 16) | ((ix - bucket * c.bucket_w) << 2) | h;
+                }
+            }
         }
         __syncthreads();
-        const LaneOps o = lane_hashes(codes, t0, kc, tile0 + t0, tile_end, a.n_pos);
-        // cbf_local only visits the candidates of a census pair: the counters of positions
-        // streamed and of operations (valid k-mers) are kept here
-        n_positions += tile0 + t0 < tile_end ? (uint32_t)min((uint64_t)kPerThread, tile_end - (tile0 + t0)) : 0u;
-        n_ops += (uint32_t)__popc(o.valid);
-#pragma unroll
-        for (int j = 0; j < kPerThread; j++) {
-            if (!((o.valid >> j) & 1u))
-                continue;
-            const uint32_t off = (uint32_t)(st * kTile + t0 + j); // position in the stretch, < 6144
-            for (uint32_t h = 0; h < a.hash_num; h++) {
-                const uint32_t ix = (uint32_t)fastmod(h ? ext_hash(o.base[j], k, h) : o.base[j], a.cbf_mod);
-                const uint32_t bucket = ix / c.bucket_w;
-                const uint32_t rank = atomicAdd(&hist[bucket], 1u);
-                if (rank < kCRun)
-                    rec[((uint64_t)bucket * nst + stretch) * kCRun + rank] = (off << 16) | ((ix - bucket * c.bucket_w) << 2) | h;
-                else
-                    over = true;
+        if (pass == 0) {
+            // exclusive scan of the 1024 counts (four per lane); the counts go back to zero to
+            // hand out the ranks again
+            uint32_t v[4], sum = 0;
+            for (int q = 0; q < 4; q++) {
+                v[q] = hist[threadIdx.x * 4 + q];
+                sum += v[q];
+            }
+            uint32_t inc = sum;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = (uint32_t)__shfl_up((int)inc, o);
+                if ((int)(threadIdx.x & 63) >= o)
+                    inc += u;
+            }
+            if ((threadIdx.x & 63) == 63)
+                s_wsum[threadIdx.x >> 6] = inc;
+            __syncthreads();
+            uint32_t before = inc - sum;
+            for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
+                before += s_wsum[w];
+            for (int q = 0; q < 4; q++) {
+                base[threadIdx.x * 4 + q] = before;
+                before += v[q];
+                hist[threadIdx.x * 4 + q] = 0;
             }
         }
     }
-    __syncthreads();
+    // every run in one go: a lane per bucket, its records back to back
+    uint32_t* const rec = c.rec + c.pair_rec_off[pair];
     uint8_t* const cnt = c.cnt + c.pair_cnt_off[pair];
-    for (uint32_t i = threadIdx.x; i < kCBuckets; i += kBlock)
-        cnt[(uint64_t)i * nst + stretch] = (uint8_t)min(hist[i], kCRun);
+    bool over = false;
+    for (uint32_t i = threadIdx.x; i < kCBuckets; i += kBlock) {
+        const uint32_t n = hist[i];
+        over |= n > kCRun;
+        const uint32_t m = min(n, kCRun);
+        cnt[(uint64_t)i * nst + stretch] = (uint8_t)m;
+        uint32_t* out = rec + ((uint64_t)i * nst + stretch) * kCRun;
+        const uint32_t from = base[i];
+        for (uint32_t q = 0; q < m; q++)
+            out[q] = stage[from + q];
+    }
     if (over)
-        c.overflow[pair] = 1u; // a long run of one k-mer: this pair is replayed whole
+        c.overflow[pair] = 1u; // many copies of one k-mer within the stretch: this pair is replayed whole
     // per-wave sums, one atomic each
     for (int o = 32; o > 0; o >>= 1) {
         n_positions += (uint32_t)__shfl_down((int)n_positions, o);
@@ -835,34 +875,56 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
 }
 
 // ---- census 2: per bucket, the earliest position per counter; every later touch is marked.
-// A wave takes a stretch's run at a time (a 256-byte line of records, as many lanes as it holds).
+// Half a wave takes a stretch's run at a time (128 bytes of record slots, as many lanes as it
+// holds); the runs' lengths are fetched once, the records once (kept in registers between the
+// two passes when the bucket has no more than kKeep runs per half-wave).
 __global__ __launch_bounds__(256) void census_mark(CensusArgs c)
 {
-    extern __shared__ uint32_t first_t[]; // bucket_w words (40 KB at GoldPolish's 10 MiB: four workgroups per CU)
+    extern __shared__ uint32_t first_t[]; // bucket_w words (40 KB at GoldPolish's 10 MiB), then the run lengths
     const uint32_t pair = blockIdx.x / kCBuckets, bucket = blockIdx.x % kCBuckets;
     if (c.overflow[pair])
         return;
     const uint32_t nst = c.pair_nst[pair];
     const uint32_t* rec = c.rec + c.pair_rec_off[pair] + (uint64_t)bucket * nst * kCRun;
     const uint8_t* cnt = c.cnt + c.pair_cnt_off[pair] + (uint64_t)bucket * nst;
+    uint8_t* const s_cnt = reinterpret_cast<uint8_t*>(first_t + c.bucket_w);
     for (uint32_t i = threadIdx.x; i < c.bucket_w; i += 256)
         first_t[i] = 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < nst; i += 256)
+        s_cnt[i] = cnt[i];
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t st = wave; st < nst; st += 4)
-        if (lane < cnt[st]) {
+    constexpr int kKeep = 64; // 512 runs: a pair of a million positions
+    const uint32_t half = threadIdx.x >> 5, lane = threadIdx.x & 31; // eight half-waves
+    uint32_t keep[kKeep];
+#pragma unroll
+    for (int q = 0; q < kKeep; q++) {
+        const uint32_t st = half + 8u * (uint32_t)q;
+        keep[q] = (st < nst && lane < s_cnt[st]) ? rec[(uint64_t)st * kCRun + lane] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int q = 0; q < kKeep; q++)
+        if (keep[q] != 0xFFFFFFFFu)
+            atomicMin(&first_t[(keep[q] >> 2) & 0x3FFFu], (half + 8u * (uint32_t)q) * kCStretch + (keep[q] >> 16));
+#pragma unroll 4
+    for (uint32_t st = half + 8u * kKeep; st < nst; st += 8)
+        if (lane < s_cnt[st]) {
             const uint32_t r = rec[(uint64_t)st * kCRun + lane];
             atomicMin(&first_t[(r >> 2) & 0x3FFFu], st * kCStretch + (r >> 16));
         }
     __syncthreads();
     uint8_t* const fl = reinterpret_cast<uint8_t*>(c.flags + c.pair_flag_off[pair]);
-    for (uint32_t st = wave; st < nst; st += 4)
-        if (lane < cnt[st]) {
-            const uint32_t r = rec[(uint64_t)st * kCRun + lane];
-            const uint32_t t = st * kCStretch + (r >> 16);
-            if (first_t[(r >> 2) & 0x3FFFu] != t)
-                fl[(uint64_t)t * 4 + (r & 3u)] = 1; // (a counter hit twice by one operation: both touches are its first)
-        }
+    auto mark = [&](uint32_t r, uint32_t st) {
+        const uint32_t t = st * kCStretch + (r >> 16);
+        if (first_t[(r >> 2) & 0x3FFFu] != t)
+            fl[(uint64_t)t * 4 + (r & 3u)] = 1; // (a counter hit twice by one operation: both touches are its first)
+    };
+#pragma unroll
+    for (int q = 0; q < kKeep; q++)
+        if (keep[q] != 0xFFFFFFFFu)
+            mark(keep[q], half + 8u * (uint32_t)q);
+    for (uint32_t st = half + 8u * kKeep; st < nst; st += 8)
+        if (lane < s_cnt[st])
+            mark(rec[(uint64_t)st * kCRun + lane], st);
 }
 
 // ---- census 3: operations with every touch marked -> one bit each
@@ -1749,7 +1811,13 @@ int stage_a_run(gp_job* job)
                     c.cand = job->d_cand.p;
                     c.bucket_w = bucket_w;
                     hipLaunchKernelGGL(census_scatter, dim3((unsigned)nw), dim3(kBlock), 0, s, a, c);
-                    hipLaunchKernelGGL(census_mark, dim3((unsigned)(np * kCBuckets)), dim3(256), bucket_w * sizeof(uint32_t), s, c);
+                    {
+                        uint32_t max_nst = 0;
+                        for (uint32_t x : co.pair_nst)
+                            max_nst = std::max(max_nst, x);
+                        const size_t lds = (size_t)bucket_w * sizeof(uint32_t) + (max_nst + 3) / 4 * 4;
+                        hipLaunchKernelGGL(census_mark, dim3((unsigned)(np * kCBuckets)), dim3(256), lds, s, c);
+                    }
                     hipLaunchKernelGGL(census_pack, dim3((unsigned)nw), dim3(256), 0, s, a, c);
                     GP_HIP(hipGetLastError());
                 }
