@@ -691,9 +691,9 @@ __global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
 // (many copies of one k-mer within a stretch) sends its pair back to the plain replay.
 constexpr int kCSuper = 2;                // tiles of kTile positions per census_scatter workgroup: a 2048-position stretch
 constexpr uint32_t kCStretch = kCSuper * kTile;
-constexpr uint32_t kCBuckets = 1024;      // counter ranges per pair
-constexpr uint32_t kCRun = 32;            // records a stretch may leave in one bucket (8 expected at four hashes)
-constexpr uint32_t kCMaxBucketW = 16384;  // counters per range: 14 bits of a record, 64 KB of LDS in census_mark
+constexpr uint32_t kCBuckets = 2048;      // most counter ranges per pair (a range is a power of two wide: 1280 of 8192 for 10 MiB)
+constexpr uint32_t kCRun = 32;            // records a stretch may leave in one bucket (6 expected at four hashes)
+constexpr uint32_t kCMaxShift = 14;       // counters per range: 14 bits of a record, 64 KB of LDS in census_mark
 
 struct CensusArgs {
     const uint32_t* wg_pair;       // [workgroups] pair (cohort-local) of a stretch
@@ -713,7 +713,8 @@ struct CensusArgs {
     uint32_t* overflow;            // [pairs]
     uint32_t* pair_mode;           // [queue entries] set to 2 for pairs that overflowed
     unsigned long long* cand;
-    uint32_t bucket_w;
+    uint32_t bucket_shift;         // a range holds 1 << bucket_shift counters
+    uint32_t n_buckets;            // ranges per pair
 };
 
 // hashes of the lane's kPerThread consecutive positions of a staged tile (as cbf_first_pass does it)
@@ -765,15 +766,12 @@ __device__ inline LaneOps lane_hashes(const uint8_t* codes, int t0, const KConst
 
 // ---- census 1: every counter touch of a 2048-position stretch into the bucket of its counter
 // range.  A stretch has a run of kCRun record slots of its own in every bucket (the stretch and
-// the bucket are in the address: 4-byte records, no shared cursor).  The records are sorted by
-// bucket in LDS first (count, scan, place: two hashing passes) and every run is then written in
-// one go -- written as they are hashed, the 1024 open runs of each of the workgroups on an XCD
-// (256 KB each) were evicted from L2 half full over and over: 43 ms instead of SCATTER_MS for 1.2 G
-// positions.
+// the bucket are in the address: 4-byte records, no shared cursor, one hashing pass).  Ranges are
+// a power of two wide, so a touch finds its bucket with a shift.
 __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
 {
     __shared__ uint8_t codes[kTile + kHalo];
-    __shared__ uint32_t hist[kCBuckets], base[kCBuckets], stage[kCStretch * 4], s_wsum[kBlock / 64];
+    __shared__ uint32_t hist[kCBuckets];
     const uint32_t pair = c.wg_pair[blockIdx.x];
     const uint32_t b = c.pair_batch[pair], ki = c.pair_ki[pair];
     const KConsts& kc = a.kc[ki];
@@ -782,85 +780,49 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
     const uint64_t pos0 = c.wg_pos0[blockIdx.x];
     const uint64_t stretch_end = min(b_end, pos0 + (uint64_t)kCStretch);
     const uint32_t nst = c.pair_nst[pair], stretch = (uint32_t)((pos0 - b_start) / kCStretch);
+    uint32_t* const rec = c.rec + c.pair_rec_off[pair];
     const int t0 = threadIdx.x * kPerThread;
+    const uint32_t shift = c.bucket_shift, lmask = (1u << shift) - 1u;
     uint32_t n_positions = 0, n_ops = 0;
-    for (uint32_t i = threadIdx.x; i < kCBuckets; i += kBlock)
+    bool over = false;
+    for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock)
         hist[i] = 0;
-    for (int pass = 0; pass < 2; pass++) {
-        for (int st = 0; st < kCSuper; st++) {
-            const uint64_t tile0 = pos0 + (uint64_t)st * kTile;
-            if (tile0 >= stretch_end)
-                break; // uniform
-            const uint64_t tile_end = min(stretch_end, tile0 + (uint64_t)kTile);
-            __syncthreads(); // codes free (hist cleared / base written before their first use)
-            for (int i = threadIdx.x; i < kTile + kHalo; i += kBlock) {
-                const uint64_t p = tile0 + i;
-                codes[i] = base_code(p < a.n_pos ? a.reads[p] : (uint8_t)'\n');
-            }
-            __syncthreads();
-            const LaneOps o = lane_hashes(codes, t0, kc, tile0 + t0, tile_end, a.n_pos);
-            if (pass == 0) {
-                // cbf_local only visits the candidates of a census pair: the counters of positions
-                // streamed and of operations (valid k-mers) are kept here
-                n_positions += tile0 + t0 < tile_end ? (uint32_t)min((uint64_t)kPerThread, tile_end - (tile0 + t0)) : 0u;
-                n_ops += (uint32_t)__popc(o.valid);
-            }
-#pragma unroll
-            for (int j = 0; j < kPerThread; j++) {
-                if (!((o.valid >> j) & 1u))
-                    continue;
-                const uint32_t off = (uint32_t)(st * kTile + t0 + j); // position in the stretch
-                for (uint32_t h = 0; h < a.hash_num; h++) {
-                    const uint32_t ix = (uint32_t)fastmod(h ? ext_hash(o.base[j], k, h) : o.base[j], a.cbf_mod);
-                    const uint32_t bucket = ix / c.bucket_w;
-                    const uint32_t rank = atomicAdd(&hist[bucket], 1u);
-                    if (pass == 1)
-                        stage[base[bucket] + rank] = (off << 16) | ((ix - bucket * c.bucket_w) << 2) | h;
-                }
-            }
+    for (int st = 0; st < kCSuper; st++) {
+        const uint64_t tile0 = pos0 + (uint64_t)st * kTile;
+        if (tile0 >= stretch_end)
+            break; // uniform
+        const uint64_t tile_end = min(stretch_end, tile0 + (uint64_t)kTile);
+        __syncthreads(); // codes free (and hist cleared before the first use)
+        for (int i = threadIdx.x; i < kTile + kHalo; i += kBlock) {
+            const uint64_t p = tile0 + i;
+            codes[i] = base_code(p < a.n_pos ? a.reads[p] : (uint8_t)'\n');
         }
         __syncthreads();
-        if (pass == 0) {
-            // exclusive scan of the 1024 counts (four per lane); the counts go back to zero to
-            // hand out the ranks again
-            uint32_t v[4], sum = 0;
-            for (int q = 0; q < 4; q++) {
-                v[q] = hist[threadIdx.x * 4 + q];
-                sum += v[q];
-            }
-            uint32_t inc = sum;
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t u = (uint32_t)__shfl_up((int)inc, o);
-                if ((int)(threadIdx.x & 63) >= o)
-                    inc += u;
-            }
-            if ((threadIdx.x & 63) == 63)
-                s_wsum[threadIdx.x >> 6] = inc;
-            __syncthreads();
-            uint32_t before = inc - sum;
-            for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
-                before += s_wsum[w];
-            for (int q = 0; q < 4; q++) {
-                base[threadIdx.x * 4 + q] = before;
-                before += v[q];
-                hist[threadIdx.x * 4 + q] = 0;
+        const LaneOps o = lane_hashes(codes, t0, kc, tile0 + t0, tile_end, a.n_pos);
+        // cbf_local only visits the candidates of a census pair: the counters of positions
+        // streamed and of operations (valid k-mers) are kept here
+        n_positions += tile0 + t0 < tile_end ? (uint32_t)min((uint64_t)kPerThread, tile_end - (tile0 + t0)) : 0u;
+        n_ops += (uint32_t)__popc(o.valid);
+#pragma unroll
+        for (int j = 0; j < kPerThread; j++) {
+            if (!((o.valid >> j) & 1u))
+                continue;
+            const uint32_t off = (uint32_t)(st * kTile + t0 + j); // position in the stretch
+            for (uint32_t h = 0; h < a.hash_num; h++) {
+                const uint32_t ix = (uint32_t)fastmod(h ? ext_hash(o.base[j], k, h) : o.base[j], a.cbf_mod);
+                const uint32_t bucket = ix >> shift;
+                const uint32_t rank = atomicAdd(&hist[bucket], 1u);
+                if (rank < kCRun)
+                    rec[((uint64_t)bucket * nst + stretch) * kCRun + rank] = (off << 16) | ((ix & lmask) << 2) | h;
+                else
+                    over = true;
             }
         }
     }
-    // every run in one go: a lane per bucket, its records back to back
-    uint32_t* const rec = c.rec + c.pair_rec_off[pair];
+    __syncthreads();
     uint8_t* const cnt = c.cnt + c.pair_cnt_off[pair];
-    bool over = false;
-    for (uint32_t i = threadIdx.x; i < kCBuckets; i += kBlock) {
-        const uint32_t n = hist[i];
-        over |= n > kCRun;
-        const uint32_t m = min(n, kCRun);
-        cnt[(uint64_t)i * nst + stretch] = (uint8_t)m;
-        uint32_t* out = rec + ((uint64_t)i * nst + stretch) * kCRun;
-        const uint32_t from = base[i];
-        for (uint32_t q = 0; q < m; q++)
-            out[q] = stage[from + q];
-    }
+    for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock)
+        cnt[(uint64_t)i * nst + stretch] = (uint8_t)min(hist[i], kCRun);
     if (over)
         c.overflow[pair] = 1u; // many copies of one k-mer within the stretch: this pair is replayed whole
     // per-wave sums, one atomic each
@@ -880,15 +842,16 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
 // two passes when the bucket has no more than kKeep runs per half-wave).
 __global__ __launch_bounds__(256) void census_mark(CensusArgs c)
 {
-    extern __shared__ uint32_t first_t[]; // bucket_w words (40 KB at GoldPolish's 10 MiB), then the run lengths
-    const uint32_t pair = blockIdx.x / kCBuckets, bucket = blockIdx.x % kCBuckets;
+    extern __shared__ uint32_t first_t[]; // a word per counter of the range (32 KB at GoldPolish's 10 MiB), then the run lengths
+    const uint32_t pair = blockIdx.x / c.n_buckets, bucket = blockIdx.x % c.n_buckets;
+    const uint32_t bucket_w = 1u << c.bucket_shift;
     if (c.overflow[pair])
         return;
     const uint32_t nst = c.pair_nst[pair];
     const uint32_t* rec = c.rec + c.pair_rec_off[pair] + (uint64_t)bucket * nst * kCRun;
     const uint8_t* cnt = c.cnt + c.pair_cnt_off[pair] + (uint64_t)bucket * nst;
-    uint8_t* const s_cnt = reinterpret_cast<uint8_t*>(first_t + c.bucket_w);
-    for (uint32_t i = threadIdx.x; i < c.bucket_w; i += 256)
+    uint8_t* const s_cnt = reinterpret_cast<uint8_t*>(first_t + bucket_w);
+    for (uint32_t i = threadIdx.x; i < bucket_w; i += 256)
         first_t[i] = 0xFFFFFFFFu;
     for (uint32_t i = threadIdx.x; i < nst; i += 256)
         s_cnt[i] = cnt[i];
@@ -1695,10 +1658,14 @@ int stage_a_run(gp_job* job)
         a.pair_mode = nullptr;
         a.pair_bit_off = nullptr;
         a.cand = nullptr;
-        const uint32_t bucket_w = (uint32_t)((p.cbf_bytes + kCBuckets - 1) / kCBuckets);
-        if (env_u64("GP_STAGE_A_CENSUS", 1) && p.hash_num <= 4 && bucket_w <= kCMaxBucketW) {
+        // counter ranges: a power of two wide, at most kCBuckets of them
+        uint32_t bucket_shift = 2;
+        while (((p.cbf_bytes + (1ull << bucket_shift) - 1) >> bucket_shift) > kCBuckets)
+            bucket_shift++;
+        const uint32_t n_buckets = (uint32_t)((p.cbf_bytes + (1ull << bucket_shift) - 1) >> bucket_shift);
+        if (env_u64("GP_STAGE_A_CENSUS", 1) && p.hash_num <= 4 && bucket_shift <= kCMaxShift) {
             const uint64_t min_pos = env_u64("GP_STAGE_A_CENSUS_MIN", 65536);           // below: too few touches per bucket
-            const uint64_t rec_budget = (env_u64("GP_STAGE_A_CENSUS_MB", 8192) << 20) / 4; // (4-byte) record slots of a cohort
+            const uint64_t rec_budget = (env_u64("GP_STAGE_A_CENSUS_MB", 16384) << 20) / 4; // (4-byte) record slots of a cohort
             h_pair_mode.assign(n_pairs, 0);
             h_pair_bit_off.assign(n_pairs, 0);
             uint64_t bits = 0, max_rec = 0, max_cnt = 0, max_flags = 0, max_pairs = 0, max_wg = 0;
@@ -1724,7 +1691,7 @@ int stage_a_run(gp_job* job)
                 if (pos < min_pos || pos >= (1ull << 32) || pos * p.hash_num > 2 * p.cbf_bytes)
                     continue;
                 const uint32_t nst = (uint32_t)((pos + kCStretch - 1) / kCStretch);
-                const uint64_t recs = (uint64_t)kCBuckets * nst * kCRun; // a run of slots per bucket and stretch
+                const uint64_t recs = (uint64_t)n_buckets * nst * kCRun; // a run of slots per bucket and stretch
                 if (recs * p.n_k > rec_budget)
                     continue; // a batch that would not fit a cohort by itself
                 if (cur_rec + recs * p.n_k > rec_budget)
@@ -1742,7 +1709,7 @@ int stage_a_run(gp_job* job)
                     h_pair_mode[q] = 1;
                     h_pair_bit_off[q] = bits;
                     cur_rec += recs;
-                    cur_cnt += (uint64_t)kCBuckets * nst;
+                    cur_cnt += (uint64_t)n_buckets * nst;
                     cur_flags += pos;
                     bits += (pos + kLWin - 1) / kLWin * kLWin; // whole windows of cbf_local
                     for (uint64_t p0 = 0; p0 < pos; p0 += kCStretch) {
@@ -1809,14 +1776,15 @@ int stage_a_run(gp_job* job)
                     c.overflow = job->d_census_over.p;
                     c.pair_mode = job->d_pair_mode.p;
                     c.cand = job->d_cand.p;
-                    c.bucket_w = bucket_w;
+                    c.bucket_shift = bucket_shift;
+                    c.n_buckets = n_buckets;
                     hipLaunchKernelGGL(census_scatter, dim3((unsigned)nw), dim3(kBlock), 0, s, a, c);
                     {
                         uint32_t max_nst = 0;
                         for (uint32_t x : co.pair_nst)
                             max_nst = std::max(max_nst, x);
-                        const size_t lds = (size_t)bucket_w * sizeof(uint32_t) + (max_nst + 3) / 4 * 4;
-                        hipLaunchKernelGGL(census_mark, dim3((unsigned)(np * kCBuckets)), dim3(256), lds, s, c);
+                        const size_t lds = ((size_t)sizeof(uint32_t) << bucket_shift) + (max_nst + 3) / 4 * 4;
+                        hipLaunchKernelGGL(census_mark, dim3((unsigned)(np * n_buckets)), dim3(256), lds, s, c);
                     }
                     hipLaunchKernelGGL(census_pack, dim3((unsigned)nw), dim3(256), 0, s, a, c);
                     GP_HIP(hipGetLastError());
