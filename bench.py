@@ -177,7 +177,7 @@ def main():
     ap.add_argument("--workload", default="config3")
     ap.add_argument("--jobs-per-gpu", type=int, default=-1,
                     help="jobs a rank cuts its batches into and keeps in flight (gp_jobs_polish pipelines the "
-                         "filter build of one behind the rest of another); default: by workload")
+                         "filter build of one behind the rest of another); default 1")
     ap.add_argument("--no-aux", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl",
@@ -370,8 +370,10 @@ def main():
                               "frac": round(rate / ATOMIC_CEILING_GPS, 3)}
         return out
 
-    # jobs in flight per GPU: one per ~1000 batches, at most 4 (a job holds 13 GiB of Sealer arenas)
-    n_jobs = args.jobs_per_gpu if args.jobs_per_gpu > 0 else max(1, min(4, w_main.n_contigs // 1000))
+    # One job per GPU.  (--jobs-per-gpu N cuts the batches into N jobs that gp_jobs_polish
+    # pipelines: +8 % while the filter build was one long latency-tolerant kernel, within noise
+    # since the census made stage A a chain of streaming kernels that compete with the other stages.)
+    n_jobs = args.jobs_per_gpu if args.jobs_per_gpu > 0 else 1
     main_res = run(w_main, ks_main, args.steps, args.warmup, rank == 0 and world == 1, n_jobs)
     total_bp = main_res["bp_per_rank"] * world
     value = total_bp * args.steps / main_res["dt"] / 1e6
