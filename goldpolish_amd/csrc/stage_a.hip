@@ -689,10 +689,8 @@ __global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
 // marks the touches that are not it, and an operation with all its touches marked is a
 // candidate.  cbf_local then replays a fifth to a third of the operations.  A run that overflows
 // (many copies of one k-mer within a stretch) sends its pair back to the plain replay.
-constexpr int kCBlock = 1024;             // census_scatter: one workgroup per CU (128 KB of LDS staging), four positions per lane
-constexpr int kCTile = kCBlock * kPerThread;
-constexpr int kCSuper = 2;                // tiles per workgroup: an 8192-position stretch
-constexpr uint32_t kCStretch = kCSuper * kCTile;
+constexpr int kCSuper = 8;                // tiles of kTile positions per census_scatter workgroup: an 8192-position stretch
+constexpr uint32_t kCStretch = kCSuper * kTile;
 constexpr uint32_t kCBuckets = 2048;      // most counter ranges per pair (a range is a power of two wide: 1280 of 8192 for 10 MiB)
 constexpr uint32_t kCRun = 64;            // records a stretch may leave in one bucket (26 expected at four hashes and 10 MiB)
 constexpr uint32_t kCMaxShift = 14;       // counters per range: 14 bits of a record, 64 KB of LDS in census_mark
@@ -768,15 +766,15 @@ __device__ inline LaneOps lane_hashes(const uint8_t* codes, int t0, const KConst
 
 // ---- census 1: every counter touch of an 8192-position stretch into the bucket of its counter
 // range.  A stretch has a run of kCRun record slots of its own in every bucket (the stretch and
-// the bucket are in the address: 4-byte records, no shared cursor).  The records are sorted by
-// bucket in LDS (count, scan, place: two hashing passes) and a lane writes a whole run, 16 bytes
-// at a time.  Written as they are hashed, 4 bytes here and 4 bytes there into a thousand open
-// runs per workgroup, the stores reached memory as partial sectors -- read-modify-writes, at the
-// rate of random ones (11 G lines/s) whatever the record size.  Ranges are a power of two wide.
-__global__ __launch_bounds__(kCBlock) void census_scatter(AArgs a, CensusArgs c)
+// the bucket are in the address: 4-byte records, no shared cursor, one hashing pass).  Ranges are
+// a power of two wide, so a touch finds its bucket with a shift.  (Measured on 1.2 G positions:
+// 43 ms like this; 63-68 ms with the records sorted by bucket in LDS first and every run written
+// in one go, which costs a second hashing pass and most of the occupancy; 67 ms with 2048-position
+// stretches, whose runs of six records reach memory as partial sectors.)
+__global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
 {
-    __shared__ uint8_t codes[kCTile + kHalo];
-    __shared__ uint32_t hist[kCBuckets], base[kCBuckets], stage[kCStretch * 4], s_wsum[kCBlock / 64];
+    __shared__ uint8_t codes[kTile + kHalo];
+    __shared__ uint32_t hist[kCBuckets];
     const uint32_t pair = c.wg_pair[blockIdx.x];
     const uint32_t b = c.pair_batch[pair], ki = c.pair_ki[pair];
     const KConsts& kc = a.kc[ki];
@@ -785,82 +783,49 @@ __global__ __launch_bounds__(kCBlock) void census_scatter(AArgs a, CensusArgs c)
     const uint64_t pos0 = c.wg_pos0[blockIdx.x];
     const uint64_t stretch_end = min(b_end, pos0 + (uint64_t)kCStretch);
     const uint32_t nst = c.pair_nst[pair], stretch = (uint32_t)((pos0 - b_start) / kCStretch);
+    uint32_t* const rec = c.rec + c.pair_rec_off[pair];
     const int t0 = threadIdx.x * kPerThread;
     const uint32_t shift = c.bucket_shift, lmask = (1u << shift) - 1u;
     uint32_t n_positions = 0, n_ops = 0;
-    for (uint32_t i = threadIdx.x; i < kCBuckets; i += kCBlock)
+    bool over = false;
+    for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock)
         hist[i] = 0;
-    for (int pass = 0; pass < 2; pass++) {
-        for (int st = 0; st < kCSuper; st++) {
-            const uint64_t tile0 = pos0 + (uint64_t)st * kCTile;
-            if (tile0 >= stretch_end)
-                break; // uniform
-            const uint64_t tile_end = min(stretch_end, tile0 + (uint64_t)kCTile);
-            __syncthreads(); // codes free (hist cleared / base written before their first use)
-            for (int i = threadIdx.x; i < kCTile + kHalo; i += kCBlock) {
-                const uint64_t p = tile0 + i;
-                codes[i] = base_code(p < a.n_pos ? a.reads[p] : (uint8_t)'\n');
-            }
-            __syncthreads();
-            const LaneOps o = lane_hashes(codes, t0, kc, tile0 + t0, tile_end, a.n_pos);
-            if (pass == 0) {
-                // cbf_local only visits the candidates of a census pair: the counters of positions
-                // streamed and of operations (valid k-mers) are kept here
-                n_positions += tile0 + t0 < tile_end ? (uint32_t)min((uint64_t)kPerThread, tile_end - (tile0 + t0)) : 0u;
-                n_ops += (uint32_t)__popc(o.valid);
-            }
-#pragma unroll
-            for (int j = 0; j < kPerThread; j++) {
-                if (!((o.valid >> j) & 1u))
-                    continue;
-                const uint32_t off = (uint32_t)(st * kCTile + t0 + j); // position in the stretch
-                for (uint32_t h = 0; h < a.hash_num; h++) {
-                    const uint32_t ix = (uint32_t)fastmod(h ? ext_hash(o.base[j], k, h) : o.base[j], a.cbf_mod);
-                    const uint32_t bucket = ix >> shift;
-                    const uint32_t rank = atomicAdd(&hist[bucket], 1u);
-                    if (pass == 1)
-                        stage[base[bucket] + rank] = (off << 16) | ((ix & lmask) << 2) | h;
-                }
-            }
+    for (int st = 0; st < kCSuper; st++) {
+        const uint64_t tile0 = pos0 + (uint64_t)st * kTile;
+        if (tile0 >= stretch_end)
+            break; // uniform
+        const uint64_t tile_end = min(stretch_end, tile0 + (uint64_t)kTile);
+        __syncthreads(); // codes free (and hist cleared before the first use)
+        for (int i = threadIdx.x; i < kTile + kHalo; i += kBlock) {
+            const uint64_t p = tile0 + i;
+            codes[i] = base_code(p < a.n_pos ? a.reads[p] : (uint8_t)'\n');
         }
         __syncthreads();
-        if (pass == 0) {
-            // exclusive scan of the bucket counts (two per lane); the counts go back to zero to
-            // hand out the ranks again
-            const uint32_t v0 = hist[threadIdx.x * 2], v1 = hist[threadIdx.x * 2 + 1];
-            uint32_t inc = v0 + v1;
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t u = (uint32_t)__shfl_up((int)inc, o);
-                if ((int)(threadIdx.x & 63) >= o)
-                    inc += u;
+        const LaneOps o = lane_hashes(codes, t0, kc, tile0 + t0, tile_end, a.n_pos);
+        // cbf_local only visits the candidates of a census pair: the counters of positions
+        // streamed and of operations (valid k-mers) are kept here
+        n_positions += tile0 + t0 < tile_end ? (uint32_t)min((uint64_t)kPerThread, tile_end - (tile0 + t0)) : 0u;
+        n_ops += (uint32_t)__popc(o.valid);
+#pragma unroll
+        for (int j = 0; j < kPerThread; j++) {
+            if (!((o.valid >> j) & 1u))
+                continue;
+            const uint32_t off = (uint32_t)(st * kTile + t0 + j); // position in the stretch
+            for (uint32_t h = 0; h < a.hash_num; h++) {
+                const uint32_t ix = (uint32_t)fastmod(h ? ext_hash(o.base[j], k, h) : o.base[j], a.cbf_mod);
+                const uint32_t bucket = ix >> shift;
+                const uint32_t rank = atomicAdd(&hist[bucket], 1u);
+                if (rank < kCRun)
+                    rec[((uint64_t)bucket * nst + stretch) * kCRun + rank] = (off << 16) | ((ix & lmask) << 2) | h;
+                else
+                    over = true;
             }
-            if ((threadIdx.x & 63) == 63)
-                s_wsum[threadIdx.x >> 6] = inc;
-            __syncthreads();
-            uint32_t before = inc - (v0 + v1);
-            for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
-                before += s_wsum[w];
-            base[threadIdx.x * 2] = before;
-            base[threadIdx.x * 2 + 1] = before + v0;
-            hist[threadIdx.x * 2] = 0;
-            hist[threadIdx.x * 2 + 1] = 0;
         }
     }
-    // a lane per bucket writes its run whole: 16 bytes at a time into 256-byte aligned slots
-    uint32_t* const rec = c.rec + c.pair_rec_off[pair];
+    __syncthreads();
     uint8_t* const cnt = c.cnt + c.pair_cnt_off[pair];
-    bool over = false;
-    for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kCBlock) {
-        const uint32_t n = hist[i];
-        over |= n > kCRun;
-        const uint32_t m = min(n, kCRun);
-        cnt[(uint64_t)i * nst + stretch] = (uint8_t)m;
-        uint4* out = reinterpret_cast<uint4*>(rec + ((uint64_t)i * nst + stretch) * kCRun);
-        const uint32_t* from = stage + base[i];
-        for (uint32_t q = 0; q < m; q += 4)
-            out[q >> 2] = make_uint4(from[q], q + 1 < m ? from[q + 1] : 0u, q + 2 < m ? from[q + 2] : 0u,
-                                     q + 3 < m ? from[q + 3] : 0u);
-    }
+    for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock)
+        cnt[(uint64_t)i * nst + stretch] = (uint8_t)min(hist[i], kCRun);
     if (over)
         c.overflow[pair] = 1u; // many copies of one k-mer within the stretch: this pair is replayed whole
     // per-wave sums, one atomic each
@@ -1816,7 +1781,7 @@ int stage_a_run(gp_job* job)
                     c.cand = job->d_cand.p;
                     c.bucket_shift = bucket_shift;
                     c.n_buckets = n_buckets;
-                    hipLaunchKernelGGL(census_scatter, dim3((unsigned)nw), dim3(kCBlock), 0, s, a, c);
+                    hipLaunchKernelGGL(census_scatter, dim3((unsigned)nw), dim3(kBlock), 0, s, a, c);
                     {
                         uint32_t max_nst = 0;
                         for (uint32_t x : co.pair_nst)
