@@ -322,19 +322,26 @@ def main():
         name = max(("cbf_local", "cbf_first_pass"), key=lambda n: k[n]["ms"])
         kk = k[name]
         out = {"bound": "hbm", "kernel": name, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        # With the census in front of it, cbf_local does its launch's units together with the three
+        # census kernels (one timer, "cbf_census"): the launch is priced over both, so that `frac`
+        # never credits cbf_local with work the census did.
+        census_ms = k.get("cbf_census", {}).get("ms", 0.0) if name == "cbf_local" else 0.0
         if kk["launches"]:
             bytes_per_launch = (1 + 2 * H) * kk["units"] / kk["launches"]
-            avg_s = kk["ms"] / kk["launches"] / 1e3
+            avg_s = (kk["ms"] + census_ms) / kk["launches"] / 1e3
             achieved = bytes_per_launch / avg_s / 1e9
         else:
             bytes_per_launch, avg_s, achieved = 0, 0.0, 0.0
+        if census_ms:
+            out["priced_over"] = ("cbf_local's launch plus the census kernels in front of it (census_scatter, census_mark, "
+                                  "census_pack: %.3f ms per cbf_local launch)" % (census_ms / max(kk["launches"], 1)))
         traffic, src = pmc_traffic(workload, name)
         out.update({
             "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic,
             "traffic_source": (src + " (committed rocprofv3 PMC passes of this workload; not collected by this run)"
                                if src else None),
-            "traffic_GBps": (round(traffic / avg_s / 1e9, 1) if traffic and avg_s else None),
+            "traffic_GBps": (round(traffic / (kk["ms"] / kk["launches"] / 1e3) / 1e9, 1) if traffic and kk["launches"] and kk["ms"] else None),
             "alg_bytes_per_launch": int(bytes_per_launch),
             "avg_launch_ms": round(kk["ms"] / max(kk["launches"], 1), 4),
             "largest_by_time": max(k, key=lambda n: k[n]["ms"]),
@@ -351,10 +358,16 @@ def main():
             out["avg_launch_ms_in_step"] = round(ks_["ms"] / max(ks_["launches"], 1), 4)
             out["kernel_ms_in_step"] = {n: round(v["ms"], 3) for n, v in res["kernels"].items()}
         c = res["counters"]
+        if k.get("cbf_census", {}).get("ms"):
+            # stage A for the short batches = census of first touches + replay of the candidates
+            sa_ms = k["cbf_census"]["ms"] + k["cbf_local"]["ms"]
+            out["stage_a"] = {"census_ms": round(k["cbf_census"]["ms"], 3), "replay_ms": round(k["cbf_local"]["ms"], 3),
+                              "operations": c["a_ops"], "replayed": c.get("a_replayed", 0),
+                              "alg_GBps": round((1 + 2 * H) * k["cbf_local"]["units"] / (sa_ms / 1e3) / 1e9, 2)}
         if name == "cbf_local" and kk["ms"]:
-            # what bounds this kernel: every counter touch is a random 1-byte read-modify-write
-            # in a 10 MiB array nobody else shares; the probe gives the chip's rate for that
-            touches = c["a_ops"] * H
+            # what bounds this kernel: every counter touch of a replayed operation is a random 1-byte
+            # read-modify-write in a 10 MiB array nobody else shares; the probe gives the chip's rate for that
+            touches = (c.get("a_replayed") or c["a_ops"]) * H
             rate = touches / (kk["ms"] / 1e3) / 1e9
             out["random_rmw"] = {"counter_touches_per_step": touches, "achieved_G_per_s": round(rate, 2),
                                  "measured_ceiling_G_per_s": RANDOM_RMW_CEILING_GPS,

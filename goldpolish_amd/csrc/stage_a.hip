@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     __shared__ uint8_t codes[kLWin + kHalo];
     __shared__ uint32_t keys[kLocalSlots]; // counter index held by the slot
     __shared__ uint32_t vals[kLocalSlots]; // earliest waiting operation of the tile on that counter
-    __shared__ unsigned long long s_stats[4];
+    __shared__ unsigned long long s_stats[6]; // [5]: operations replayed (all of a plain pair, the candidates of a census pair)
     __shared__ unsigned long long s_cw[kLWin / 64]; // census: candidate bits of the window ...
     __shared__ uint32_t s_cpre[kLWin / 64], s_ncand;   // ... candidates before each word, and in all
     // This workgroup's arena slot for the whole launch: the counting filter of whichever pair it
@@ -1038,13 +1038,13 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     // of leaving its CU idle.  Every workgroup reaches the end of the queue and exits.
     uint8_t* const cb = a.cbf + (uint64_t)blockIdx.x * a.cbf_stride;
     __shared__ uint32_t s_pair;
-    if (threadIdx.x < 4)
+    if (threadIdx.x < 6)
         s_stats[threadIdx.x] = 0;
     const int t0 = threadIdx.x * kLPer;
     bool slot_clean = false; // uniform: the previous pair was short and has been unwound
 
     for (;;) {
-    uint32_t n_ops = 0, n_ordered = 0, n_positions = 0, n_rounds = 0;
+    uint32_t n_ops = 0, n_ordered = 0, n_positions = 0, n_rounds = 0, n_replayed = 0;
     __syncthreads(); // the previous pair is finished by every wave
     if (threadIdx.x == 0)
         s_pair = atomicAdd(a.queue, 1u);
@@ -1139,6 +1139,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
                 op_base[j] = fh + rh;
                 op_thr[j] = (a.seg_thr[seg] - 2 + ki) | ((a.seg_smax[seg] - 2 + ki) << 16); // own threshold | S
                 op_state[j] = 1;
+                n_replayed++;
                 uint32_t pack = 0;
                 for (uint32_t h = 0; h < 4; h++) { // hash_num <= 4 on this path (stage_a_run)
                     if (h >= a.hash_num)
@@ -1220,6 +1221,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
             op_base[j] = fh + rh;
             op_thr[j] = (a.seg_thr[seg] - 2 + ki - 1) | ((a.seg_smax[seg] - 2 + ki - 1) << 16); // one lower: see census_scatter
             op_state[j] = 1;
+            n_replayed++;
             uint32_t pack = 0;
             for (uint32_t h = 0; h < 4; h++) {
                 if (h >= a.hash_num)
@@ -1335,6 +1337,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     }
     atomicAdd(&s_stats[2], (unsigned long long)n_ordered);
     atomicAdd(&s_stats[3], (unsigned long long)n_rounds);
+    atomicAdd(&s_stats[5], (unsigned long long)n_replayed);
     // fewer counter lines touched than a quarter of the slot holds: unwind instead of clearing
     slot_clean = (b_end - b_start) * a.hash_num * 64 * 4 < a.cbf_stride;
     if (slot_clean) {
@@ -1343,7 +1346,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     }
     } // next pair
     __syncthreads();
-    if (threadIdx.x < 4 && s_stats[threadIdx.x])
+    if (threadIdx.x < 6 && threadIdx.x != 4 && s_stats[threadIdx.x])
         atomicAdd(&a.stats[threadIdx.x], s_stats[threadIdx.x]);
 }
 
@@ -2112,7 +2115,7 @@ int stage_a_run(gp_job* job)
     }
     unsigned long long* const st = job->h_readback;   // pinned: [0..4] statistics, [8] the tail's error flag
     st[8] = 0;
-    GP_HIP(hipMemcpyAsync(st, job->d_stats.p, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    GP_HIP(hipMemcpyAsync(st, job->d_stats.p, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     GP_HIP(hipMemcpyAsync(st + 8, err_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     GP_HIP(hipStreamSynchronize(s));
     const uint32_t tail_err = (uint32_t)st[8];
@@ -2121,6 +2124,7 @@ int stage_a_run(gp_job* job)
     job->counters.a_ordered_ops = st[2];
     job->counters.a_rounds += st[3];
     job->counters.a_reservations = st[4];
+    job->counters.a_replayed = st[5];
     if (tail_err) {
         set_error("stage A: reservation rounds did not converge");
         return GP_ERR_STATE;

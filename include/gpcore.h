@@ -123,6 +123,7 @@ typedef struct gp_counters {
     uint64_t c_too_many_paths;    /* "Too many paths" */
     uint64_t c_too_many_branches; /* "Too many branches" */
     uint64_t c_max_cost;          /* "Max cost exceeded" */
+    uint64_t a_replayed;          /* operations cbf_local replayed: every one of a plain pair, the candidates of a census pair */
 } gp_counters;
 
 /* ---- library / context ------------------------------------------------- */
