@@ -135,9 +135,16 @@ __device__ inline uint64_t fastmod(uint64_t x, const FastMod& m)
     if (m.c == 1)
         return low;
     uint64_t q = x >> m.s;
-    uint32_t r = mod32((uint32_t)(q >> 32), m) * m.two32 + mod32((uint32_t)q, m);
-    r = mod32(r, m);
-    return ((uint64_t)r << m.s) | low;
+    if (m.s < 16) {
+        // q may have more than 48 bits: fold its top half first (an exact 32-bit reduction); what is
+        // left is below c * 2^32 < 2^48
+        const uint32_t r1 = mod32((uint32_t)(q >> 32), m);
+        q = ((uint64_t)r1 << 32) | (uint32_t)q;
+    }
+    // One step of Lemire's reduction with the 64-bit magic is exact for q < 2^48 and c < 2^16
+    // (precision needed: 48 + 16 bits).  GoldPolish's 10 MiB = 5 * 2^21 takes this path alone.
+    const uint64_t r = __umul64hi(m.magic * q, (uint64_t)m.c);
+    return (r << m.s) | low;
 }
 
 // first lane of the active set appends `n_active` items with one atomic

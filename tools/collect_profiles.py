@@ -13,13 +13,19 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 raw = pathlib.Path("gpurun_out/profiles_raw")
 out = pathlib.Path("profiles")
 out.mkdir(exist_ok=True)
+def newest(pattern):
+    """gpurun merges every call's files into the same directories: only the latest run counts"""
+    files = sorted(glob.glob(pattern), key=lambda f: pathlib.Path(f).stat().st_mtime)
+    return files[-1:]
+
+
 for name in ("config3", "config2", "goldenpath", "probe"):
-    for f in glob.glob(str(raw / f"{name}_trace" / "*" / "*kernel_stats.csv")):
+    for f in newest(str(raw / f"{name}_trace" / "*" / "*kernel_stats.csv")):
         shutil.copy(f, out / f"{rnd}_{name}_kernel_stats.csv")
 for name in ("config3", "config2", "goldenpath", "probe"):
     traffic = {}
     for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-        for f in glob.glob(str(raw / f"{name}_{kind}" / "*" / "*counter_collection.csv")):
+        for f in newest(str(raw / f"{name}_{kind}" / "*" / "*counter_collection.csv")):
             agg = collections.defaultdict(lambda: [0, 0.0])
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] != counter:
