@@ -704,12 +704,12 @@ struct CensusArgs {
     const uint32_t* pair_nst;      // [pairs] stretches of the pair
     const uint64_t* pair_rec_off;  // [pairs] first record of the pair: rec[bucket][stretch][kCRun]
     const uint64_t* pair_cnt_off;  // [pairs] first count of the pair: cnt[bucket][stretch]
+    const uint64_t* pair_flag_off; // [pairs] first position of the pair in `flags`
     const uint64_t* pair_bit_off;  // [pairs] first bit of the pair in `cand` (multiple of 64)
     const uint32_t* pair_queue;    // [pairs] index of the pair in cbf_local's queue (for pair_mode)
     uint32_t* rec;                 // (position in the stretch << 16) | (counter in its range << 2) | hash number
-    uint8_t* cnt;                  // records a stretch left in a bucket: cnt[bucket][stretch] ...
-    uint8_t* cnt2;                 // ... and the same as cnt2[stretch][bucket] (each reader gets a contiguous row)
-    unsigned long long* masks;     // masks[stretch][bucket]: bit i = record i of the run is not its counter's first touch
+    uint8_t* cnt;                  // records a stretch left in a bucket
+    uint32_t* flags;               // one byte per (position, hash): 1 = that touch is not the counter's first
     uint32_t* overflow;            // [pairs]
     uint32_t* pair_mode;           // [queue entries] set to 2 for pairs that overflowed
     unsigned long long* cand;
@@ -824,12 +824,8 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
     }
     __syncthreads();
     uint8_t* const cnt = c.cnt + c.pair_cnt_off[pair];
-    uint8_t* const cnt2 = c.cnt2 + c.pair_cnt_off[pair] + (uint64_t)stretch * c.n_buckets;
-    for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock) {
-        const uint8_t m = (uint8_t)min(hist[i], kCRun);
-        cnt[(uint64_t)i * nst + stretch] = m;
-        cnt2[i] = m;
-    }
+    for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock)
+        cnt[(uint64_t)i * nst + stretch] = (uint8_t)min(hist[i], kCRun);
     if (over)
         c.overflow[pair] = 1u; // many copies of one k-mer within the stretch: this pair is replayed whole
     // per-wave sums, one atomic each
@@ -882,38 +878,24 @@ __global__ __launch_bounds__(256) void census_mark(CensusArgs c)
             atomicMin(&first_t[(r >> 2) & 0x3FFFu], st * kCStretch + (r >> 16));
         }
     __syncthreads();
-    // one 64-bit mask per run: which of its records are not their counter's earliest touch (a
-    // counter hit twice by one operation: both touches are its first).  Written where the
-    // stretch's workgroup of census_pack reads a contiguous row; one 8-byte store per run instead
-    // of a byte scattered per touch (those reached memory as 32-byte read-modify-writes).
-    unsigned long long* const masks = c.masks + c.pair_cnt_off[pair];
-    auto later = [&](uint32_t r, uint32_t st) -> bool {
-        return r != 0xFFFFFFFFu && first_t[(r >> 2) & 0x3FFFu] != st * kCStretch + (r >> 16);
+    uint8_t* const fl = reinterpret_cast<uint8_t*>(c.flags + c.pair_flag_off[pair]);
+    auto mark = [&](uint32_t r, uint32_t st) {
+        const uint32_t t = st * kCStretch + (r >> 16);
+        if (first_t[(r >> 2) & 0x3FFFu] != t)
+            fl[(uint64_t)t * 4 + (r & 3u)] = 1; // (a counter hit twice by one operation: both touches are its first)
     };
 #pragma unroll
-    for (int q = 0; q < kKeep; q++) {
-        const uint32_t st = wave + 4u * (uint32_t)q;
-        if (st >= nst)
-            break; // uniform per wave
-        const unsigned long long mk = __ballot(later(keep[q], st));
-        if (lane == 0)
-            masks[(uint64_t)st * c.n_buckets + bucket] = mk;
-    }
-    for (uint32_t st = wave + 4u * kKeep; st < nst; st += 4) {
-        const uint32_t r = lane < s_cnt[st] ? rec[(uint64_t)st * kCRun + lane] : 0xFFFFFFFFu;
-        const unsigned long long mk = __ballot(later(r, st));
-        if (lane == 0)
-            masks[(uint64_t)st * c.n_buckets + bucket] = mk;
-    }
+    for (int q = 0; q < kKeep; q++)
+        if (keep[q] != 0xFFFFFFFFu)
+            mark(keep[q], wave + 4u * (uint32_t)q);
+    for (uint32_t st = wave + 4u * kKeep; st < nst; st += 4)
+        if (lane < s_cnt[st])
+            mark(rec[(uint64_t)st * kCRun + lane], st);
 }
 
-// ---- census 3: per stretch, gather the marked records of all its runs: a position with every
-// touch marked is a candidate -> one bit each
+// ---- census 3: operations with every touch marked -> one bit each
 __global__ __launch_bounds__(256) void census_pack(AArgs a, CensusArgs c)
 {
-    __shared__ uint32_t bits[kCStretch * 4 / 32];   // bit (position in the stretch * 4 + hash number)
-    __shared__ unsigned long long s_mask[kCBuckets];
-    __shared__ uint8_t s_n[kCBuckets];
     const uint32_t pair = c.wg_pair[blockIdx.x];
     if (c.overflow[pair]) {
         if (threadIdx.x == 0)
@@ -921,36 +903,18 @@ __global__ __launch_bounds__(256) void census_pack(AArgs a, CensusArgs c)
         return;
     }
     const uint32_t b = c.pair_batch[pair];
-    const uint64_t b_start = a.batch_pos[b];
+    const uint64_t b_start = a.batch_pos[b], b_end = a.batch_pos[b + 1];
     const uint64_t pos0 = c.wg_pos0[blockIdx.x];
-    const uint32_t nst = c.pair_nst[pair], stretch = (uint32_t)((pos0 - b_start) / kCStretch), nb = c.n_buckets;
-    const unsigned long long* masks = c.masks + c.pair_cnt_off[pair] + (uint64_t)stretch * nb;
-    const uint8_t* cnt2 = c.cnt2 + c.pair_cnt_off[pair] + (uint64_t)stretch * nb;
-    const uint32_t* rec = c.rec + c.pair_rec_off[pair];
-    for (uint32_t i = threadIdx.x; i < kCStretch * 4 / 32; i += 256)
-        bits[i] = 0;
-    for (uint32_t i = threadIdx.x; i < nb; i += 256) {
-        s_mask[i] = masks[i];
-        s_n[i] = cnt2[i];
+    const uint64_t stretch_end = min(b_end, pos0 + (uint64_t)kCStretch);
+    const uint32_t all = a.hash_num >= 4 ? 0x01010101u : ((1u << (8 * a.hash_num)) - 1u) & 0x01010101u;
+    const uint32_t* fl = c.flags + c.pair_flag_off[pair];
+    for (uint64_t p0 = pos0; p0 < stretch_end; p0 += 256) {
+        const uint64_t p = p0 + threadIdx.x;
+        const bool is_cand = p < stretch_end && fl[p - b_start] == all;
+        const unsigned long long m = __ballot(is_cand);
+        if ((threadIdx.x & 63) == 0 && p < stretch_end)
+            c.cand[(c.pair_bit_off[pair] + (p - b_start)) >> 6] = m; // stretches and batches start on multiples of 64 bits
     }
-    __syncthreads();
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (uint32_t bk = wave; bk < nb; bk += 4)
-        if (lane < s_n[bk] && ((s_mask[bk] >> lane) & 1ULL)) {
-            const uint32_t r = rec[((uint64_t)bk * nst + stretch) * kCRun + lane];
-            const uint32_t bit = (r >> 16) * 4 + (r & 3u);
-            atomicOr(&bits[bit >> 5], 1u << (bit & 31));
-        }
-    __syncthreads();
-    // 32 positions per lane: a nibble with all its hash bits set is a candidate
-    const uint32_t all = (1u << a.hash_num) - 1u;
-    uint32_t* const cand32 = reinterpret_cast<uint32_t*>(c.cand) + ((c.pair_bit_off[pair] + (pos0 - b_start)) >> 5);
-    uint32_t word = 0;
-    for (uint32_t i = 0; i < 32; i++) {
-        const uint32_t bit = (threadIdx.x * 32 + i) * 4;
-        word |= (((bits[bit >> 5] >> (bit & 31)) & all) == all ? 1u : 0u) << i;
-    }
-    cand32[threadIdx.x] = word; // positions past the end of the batch have no records: zero bits
 }
 
 // ---- many small filters: one workgroup per (batch, k) pair replays its operations alone.
@@ -1668,7 +1632,7 @@ int stage_a_run(gp_job* job)
     // census tables: host copies stay alive until the stream has been synchronised at the end
     struct Cohort {
         std::vector<uint32_t> wg_pair, pair_batch, pair_ki, pair_nst, pair_queue, tab32;
-        std::vector<uint64_t> wg_pos0, pair_rec_off, pair_cnt_off, pair_bit_off, tab64;
+        std::vector<uint64_t> wg_pos0, pair_rec_off, pair_cnt_off, pair_flag_off, pair_bit_off, tab64;
     };
     std::vector<Cohort> cohorts;
     std::vector<uint32_t> h_pair_mode;
@@ -1710,19 +1674,20 @@ int stage_a_run(gp_job* job)
             const uint64_t rec_budget = (env_u64("GP_STAGE_A_CENSUS_MB", 16384) << 20) / 4; // (4-byte) record slots of a cohort
             h_pair_mode.assign(n_pairs, 0);
             h_pair_bit_off.assign(n_pairs, 0);
-            uint64_t bits = 0, max_rec = 0, max_cnt = 0, max_pairs = 0, max_wg = 0;
+            uint64_t bits = 0, max_rec = 0, max_cnt = 0, max_flags = 0, max_pairs = 0, max_wg = 0;
             Cohort cur;
-            uint64_t cur_rec = 0, cur_cnt = 0;
+            uint64_t cur_rec = 0, cur_cnt = 0, cur_flags = 0;
             auto close = [&]() {
                 if (cur.pair_batch.empty())
                     return;
                 max_rec = std::max(max_rec, cur_rec);
                 max_cnt = std::max(max_cnt, cur_cnt);
+                max_flags = std::max(max_flags, cur_flags);
                 max_pairs = std::max<uint64_t>(max_pairs, cur.pair_batch.size());
                 max_wg = std::max<uint64_t>(max_wg, cur.wg_pair.size());
                 cohorts.push_back(std::move(cur));
                 cur = Cohort();
-                cur_rec = cur_cnt = 0;
+                cur_rec = cur_cnt = cur_flags = 0;
             };
             for (uint32_t i = 0; i < n_local; i++) {
                 const uint32_t b = order[n_big + i];
@@ -1745,12 +1710,14 @@ int stage_a_run(gp_job* job)
                     cur.pair_queue.push_back(q);
                     cur.pair_rec_off.push_back(cur_rec);
                     cur.pair_cnt_off.push_back(cur_cnt);
+                    cur.pair_flag_off.push_back(cur_flags);
                     cur.pair_bit_off.push_back(bits);
                     h_pair_mode[q] = 1;
                     h_pair_bit_off[q] = bits;
                     cur_rec += recs;
                     cur_cnt += (uint64_t)n_buckets * nst;
-                    bits += (pos + kCStretch - 1) / kCStretch * kCStretch; // whole stretches (census_pack writes them whole; a multiple of cbf_local's windows)
+                    cur_flags += pos;
+                    bits += (pos + kLWin - 1) / kLWin * kLWin; // whole windows of cbf_local
                     for (uint64_t p0 = 0; p0 < pos; p0 += kCStretch) {
                         cur.wg_pair.push_back(lp);
                         cur.wg_pos0.push_back(batch_pos[b] + p0);
@@ -1760,8 +1727,7 @@ int stage_a_run(gp_job* job)
             close();
             if (!cohorts.empty()) {
                 int rcc;
-                if ((rcc = job->d_census_rec.ensure(max_rec)) != GP_OK || (rcc = job->d_census_cnt2.ensure(max_cnt)) != GP_OK ||
-                    (rcc = job->d_census_masks.ensure(max_cnt)) != GP_OK ||
+                if ((rcc = job->d_census_rec.ensure(max_rec)) != GP_OK || (rcc = job->d_census_flags.ensure(max_flags)) != GP_OK ||
                     (rcc = job->d_census_cnt.ensure(max_cnt)) != GP_OK ||
                     (rcc = job->d_census_over.ensure(max_pairs)) != GP_OK ||
                     (rcc = job->d_census_tab32.ensure(max_wg + 4 * max_pairs)) != GP_OK ||
@@ -1783,16 +1749,21 @@ int stage_a_run(gp_job* job)
                     co.tab32.insert(co.tab32.end(), co.pair_ki.begin(), co.pair_ki.end());
                     co.tab32.insert(co.tab32.end(), co.pair_nst.begin(), co.pair_nst.end());
                     co.tab32.insert(co.tab32.end(), co.pair_queue.begin(), co.pair_queue.end());
-                    co.tab64.reserve(nw + 3 * np);
+                    co.tab64.reserve(nw + 4 * np);
                     co.tab64.insert(co.tab64.end(), co.wg_pos0.begin(), co.wg_pos0.end());
                     co.tab64.insert(co.tab64.end(), co.pair_rec_off.begin(), co.pair_rec_off.end());
                     co.tab64.insert(co.tab64.end(), co.pair_cnt_off.begin(), co.pair_cnt_off.end());
+                    co.tab64.insert(co.tab64.end(), co.pair_flag_off.begin(), co.pair_flag_off.end());
                     co.tab64.insert(co.tab64.end(), co.pair_bit_off.begin(), co.pair_bit_off.end());
                     GP_HIP(hipMemcpyAsync(job->d_census_tab32.p, co.tab32.data(), co.tab32.size() * sizeof(uint32_t),
                                           hipMemcpyHostToDevice, s));
                     GP_HIP(hipMemcpyAsync(job->d_census_tab64.p, co.tab64.data(), co.tab64.size() * sizeof(uint64_t),
                                           hipMemcpyHostToDevice, s));
+                    uint64_t flags_n = 0;
+                    for (size_t i = 0; i < np; i++)
+                        flags_n = std::max<uint64_t>(flags_n, co.pair_flag_off[i] + (batch_pos[co.pair_batch[i] + 1] - batch_pos[co.pair_batch[i]]));
                     GP_HIP(hipMemsetAsync(job->d_census_over.p, 0, np * sizeof(uint32_t), s));
+                    GP_HIP(hipMemsetAsync(job->d_census_flags.p, 0, flags_n * sizeof(uint32_t), s));
                     CensusArgs c{};
                     c.wg_pair = job->d_census_tab32.p;
                     c.pair_batch = c.wg_pair + nw;
@@ -1802,12 +1773,12 @@ int stage_a_run(gp_job* job)
                     c.wg_pos0 = job->d_census_tab64.p;
                     c.pair_rec_off = c.wg_pos0 + nw;
                     c.pair_cnt_off = c.pair_rec_off + np;
-                    c.pair_bit_off = c.pair_cnt_off + np;
+                    c.pair_flag_off = c.pair_cnt_off + np;
+                    c.pair_bit_off = c.pair_flag_off + np;
                     c.n_wg = (uint32_t)nw;
                     c.rec = job->d_census_rec.p;
                     c.cnt = job->d_census_cnt.p;
-                    c.cnt2 = job->d_census_cnt2.p;
-                    c.masks = job->d_census_masks.p;
+                    c.flags = job->d_census_flags.p;
                     c.overflow = job->d_census_over.p;
                     c.pair_mode = job->d_pair_mode.p;
                     c.cand = job->d_cand.p;
