@@ -131,7 +131,7 @@ def split_records(lens, payload):
     return out
 
 
-def cpu_baseline(w, ks, desc):
+def cpu_baseline(w, ks, desc, gpu_out=None):
     """The oracle (a C port of the reference path, oracle/) timed on this box's host cores on
     a bounded sample of the SAME workload: its first contigs, batches in parallel over every
     core the process may use -- one OpenMP task per batch, each batch serial, which is how the
@@ -158,10 +158,20 @@ def cpu_baseline(w, ks, desc):
     thr = [int(x) for x in w.kmer_threshold[:n]]
     params = O.batch_params(k_values=tuple(ks))
     t = time.perf_counter()
-    _, used = O.polish_batches(names, seqs, reads, thr, list(range(n + 1)), params, n_threads=cores)
+    outs, used = O.polish_batches(names, seqs, reads, thr, list(range(n + 1)), params, n_threads=cores)
     dt = time.perf_counter() - t
     bp = sum(len(s) for s in seqs)
+    parity = None
+    if gpu_out is not None:
+        # the oracle's output for the sample is there anyway: the device path's polished records
+        # for the same batches, from the timed job, must be the same bytes (parity at the bench's
+        # full size, not only in tests/)
+        bad = [i for i in range(n) if gpu_out[i] != outs[i]]
+        if bad:
+            raise SystemExit(f"bench.py: {len(bad)} of the {n} sampled batches differ from the oracle (first: {w.names[bad[0]]})")
+        parity = {"batches_compared_with_the_oracle": n, "identical": True}
     return {
+        **({"parity_sample": parity} if parity else {}),
         "value": round(bp / dt / 1e6, 4), "unit": "Mbp/s", "cores": int(min(used, n)), "kind": "port",
         "sample": f"the first {n} of {w.n_contigs} batches of this workload ({bp} bp + their reads), whole path, "
                   f"k={','.join(map(str, ks))}, {dt:.1f} s: the C oracle, one OpenMP task per batch on "
@@ -284,6 +294,7 @@ def main():
                     kt[name]["units"] += units
             return kt
         res["kernels"] = kernel_times()          # the last timed step, kernels of several jobs side by side
+        res["polished"] = [x for j in jobs for x in j.sequences()] if rank == 0 and world == 1 else None
         if n_jobs > 1:
             # every job once more, ONE AT A TIME: a launch's own duration with the chip to itself
             for j in jobs:
@@ -423,7 +434,7 @@ def main():
             "roofline": r, "counters": aux["counters"],
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(w_main, ks_main, desc_main)
+        line["cpu_baseline"] = cpu_baseline(w_main, ks_main, desc_main, main_res.get("polished"))
     if rank == 0:
         print(json.dumps(line))
     if dist:
