@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -28,6 +29,15 @@ int on_exception(const char* where) noexcept; // inside a catch: records the mes
         if (e__ != hipSuccess)                                          \
             return gp::hip_fail(e__, #call, __FILE__, __LINE__);        \
     } while (0)
+
+// tuning knobs read from the environment (INTEGRATION.md lists them)
+inline uint64_t env_u64(const char* name, uint64_t dflt)
+{
+    const char* v = getenv(name);
+    if (!v || !*v)
+        return dflt;
+    return strtoull(v, nullptr, 10);
+}
 
 template <typename T>
 struct DevBuf {

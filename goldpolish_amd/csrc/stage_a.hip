@@ -1398,14 +1398,6 @@ void KernelTimer::destroy()
     used = 0;
 }
 
-static uint64_t env_u64(const char* name, uint64_t dflt)
-{
-    const char* v = getenv(name);
-    if (!v || !*v)
-        return dflt;
-    return strtoull(v, nullptr, 10);
-}
-
 int stage_a_prepare(gp_job* job)
 {
     const gp_params& p = job->prm;
