@@ -83,6 +83,43 @@ __host__ __device__ inline uint64_t sroln(uint64_t x, uint32_t n)
 }
 
 // i-th extension hash of canonical value `base` for k-mer size k (i >= 1)
+// Seeds rotated in advance: T[j * 8 + code] = srol^j(seed[code]) for j < 64 (k <= 64), zero in the
+// columns of kBadCode and its "complement" kBadCode ^ 2.  srol is a permutation of bits, so the
+// hash of a k-mer from scratch -- k rotate-select-xor steps per strand, a few hundred
+// instructions of every stage-A kernel per operation -- is the XOR of k table entries per strand:
+//   forward = XOR_i srol^(k-1-i)(seed[c_i]),  reverse = XOR_i srol^i(seed[c_i ^ 2]).
+constexpr int kSeedTableWords = 64 * 8;
+
+#ifdef __HIPCC__
+// every lane of the workgroup calls it; a workgroup barrier must follow before the first use
+__device__ inline void fill_seed_table(uint64_t* T)
+{
+    for (int i = (int)threadIdx.x; i < kSeedTableWords; i += (int)blockDim.x) {
+        const uint32_t code = (uint32_t)i & 7u;
+        T[i] = code < 4 ? sroln(seed_of_code(code), (uint32_t)i >> 3) : 0ULL;
+    }
+}
+
+// both strands of the k-mer at codes[0..k), and the index of its last byte that is not ACGT (-1: none)
+__device__ inline void kmer_hash_from_table(const uint64_t* T, const uint8_t* codes, uint32_t k, uint64_t& fh,
+                                            uint64_t& rh, int& last_bad)
+{
+    uint64_t f = 0, r = 0;
+    int lb = -1;
+#pragma unroll 4
+    for (uint32_t i = 0; i < k; i++) {
+        const uint32_t c = codes[i];
+        f ^= T[(k - 1 - i) * 8 + c];
+        r ^= T[i * 8 + (c ^ 2u)];
+        if (c >= 4)
+            lb = (int)i;
+    }
+    fh = f;
+    rh = r;
+    last_bad = lb;
+}
+#endif
+
 __host__ __device__ inline uint64_t ext_hash(uint64_t base, uint32_t k, uint32_t i)
 {
     uint64_t t = base * ((uint64_t)i ^ ((uint64_t)k * kMultiSeed));

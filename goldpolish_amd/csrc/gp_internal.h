@@ -148,7 +148,7 @@ struct gp_job {
     gp::DevBuf<uint32_t> d_batch_slot;    // [n_batches] first arena slot of a batch of the grid-wide schedule
     gp::DevBuf<uint32_t> d_queue;         // cbf_local's pair counter
     // census of first touches (stage_a.hip): work buffers of a cohort, results for the whole job
-    gp::DevBuf<unsigned long long> d_cand;
+    gp::DevBuf<unsigned long long> d_cand, d_kset;
     gp::DevBuf<uint8_t> d_census_cnt;
     gp::DevBuf<uint32_t> d_census_rec, d_census_flags, d_census_over, d_census_tab32, d_pair_mode;
     gp::DevBuf<uint64_t> d_census_tab64, d_pair_bit_off;

@@ -91,6 +91,9 @@ struct AArgs {
     const uint32_t* pair_mode;              // 1: only the operations marked in `cand` are replayed, thresholds one lower (2: census overflowed)
     const uint64_t* pair_bit_off;           // first bit of the pair in `cand` (multiple of 64)
     const unsigned long long* cand;         // bit (pair_bit_off + position in the batch's reads)
+    // census pairs: the k-mers cbf_local has seen settled for good (see there), a table per workgroup
+    unsigned long long* kset;
+    uint32_t kset_mask;                     // entries per table - 1 (0: none)
     uint32_t nib;        // 1: two 4-bit counters per byte (every threshold <= 15)
     uint32_t bf_words;
     FastMod cbf_mod, bf_mod;
@@ -241,6 +244,7 @@ __device__ inline uint32_t block_append(uint32_t* counter, uint32_t n_mine, uint
 __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
 {
     __shared__ uint8_t codes[kTile + kHalo];
+    __shared__ uint64_t seed_t[kSeedTableWords];
     __shared__ unsigned long long s_stats[3];
     __shared__ uint32_t s_wave[kBlock / 64 + 1];
     const uint32_t ki = blockIdx.y;
@@ -255,6 +259,7 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
 
     if (threadIdx.x < 3)
         s_stats[threadIdx.x] = 0;
+    fill_seed_table(seed_t);
     for (int i = threadIdx.x; i < kTile + kHalo; i += kBlock) {
         uint64_t p = tile0 + i;
         uint8_t c = p < a.n_pos ? a.reads[p] : (uint8_t)'\n';
@@ -307,14 +312,8 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
         // hash of the first window; bad bytes contribute 0 so rolling stays exact
         uint64_t fh = 0, rh = 0;
         int last_bad = -1;
-        for (uint32_t i = 0; i < k && !saturated; i++) {
-            uint32_t cf = codes[t0 + i];
-            uint32_t cr = codes[t0 + k - 1 - i];
-            fh = srol1(fh) ^ (cf < 4 ? seed_of_code(cf) : 0ULL);
-            rh = srol1(rh) ^ (cr < 4 ? seed_of_code(cr ^ 2) : 0ULL);
-            if (cf >= 4)
-                last_bad = (int)i;
-        }
+        if (!saturated)
+            kmer_hash_from_table(seed_t, codes + t0, k, fh, rh, last_bad);
         // pass 1: hashes and counter loads of all of the lane's positions (the loads of the
         // four positions are independent, so they are in flight together)
 #pragma unroll
@@ -723,8 +722,8 @@ struct LaneOps {
     uint32_t valid; // bit j: position j of the lane holds a k-mer
 };
 
-__device__ inline LaneOps lane_hashes(const uint8_t* codes, int t0, const KConsts& kc, uint64_t pos0, uint64_t tile_end,
-                                      uint64_t n_pos)
+__device__ inline LaneOps lane_hashes(const uint64_t* seed_t, const uint8_t* codes, int t0, const KConsts& kc, uint64_t pos0,
+                                      uint64_t tile_end, uint64_t n_pos)
 {
     LaneOps o;
     o.valid = 0;
@@ -733,14 +732,7 @@ __device__ inline LaneOps lane_hashes(const uint8_t* codes, int t0, const KConst
         return o;
     uint64_t fh = 0, rh = 0;
     int last_bad = -1;
-    for (uint32_t i = 0; i < k; i++) {
-        uint32_t cf = codes[t0 + i];
-        uint32_t cr = codes[t0 + k - 1 - i];
-        fh = srol1(fh) ^ (cf < 4 ? seed_of_code(cf) : 0ULL);
-        rh = srol1(rh) ^ (cr < 4 ? seed_of_code(cr ^ 2) : 0ULL);
-        if (cf >= 4)
-            last_bad = (int)i;
-    }
+    kmer_hash_from_table(seed_t, codes + t0, k, fh, rh, last_bad);
 #pragma unroll
     for (int j = 0; j < kPerThread; j++) {
         const uint64_t pos = pos0 + j;
@@ -774,6 +766,7 @@ __device__ inline LaneOps lane_hashes(const uint8_t* codes, int t0, const KConst
 __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
 {
     __shared__ uint8_t codes[kTile + kHalo];
+    __shared__ uint64_t seed_t[kSeedTableWords];
     __shared__ uint32_t hist[kCBuckets];
     const uint32_t pair = c.wg_pair[blockIdx.x];
     const uint32_t b = c.pair_batch[pair], ki = c.pair_ki[pair];
@@ -790,6 +783,7 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
     bool over = false;
     for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock)
         hist[i] = 0;
+    fill_seed_table(seed_t);
     for (int st = 0; st < kCSuper; st++) {
         const uint64_t tile0 = pos0 + (uint64_t)st * kTile;
         if (tile0 >= stretch_end)
@@ -801,7 +795,7 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
             codes[i] = base_code(p < a.n_pos ? a.reads[p] : (uint8_t)'\n');
         }
         __syncthreads();
-        const LaneOps o = lane_hashes(codes, t0, kc, tile0 + t0, tile_end, a.n_pos);
+        const LaneOps o = lane_hashes(seed_t, codes, t0, kc, tile0 + t0, tile_end, a.n_pos);
         // cbf_local only visits the candidates of a census pair: the counters of positions
         // streamed and of operations (valid k-mers) are kept here
         n_positions += tile0 + t0 < tile_end ? (uint32_t)min((uint64_t)kPerThread, tile_end - (tile0 + t0)) : 0u;
@@ -1027,6 +1021,7 @@ constexpr uint32_t kLocalEmpty = 0xFFFFFFFFu;
 __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, uint32_t n_pairs) // 4 workgroups per CU: <= 128 VGPRs
 {
     __shared__ uint8_t codes[kLWin + kHalo];
+    __shared__ uint64_t seed_t[kSeedTableWords];
     __shared__ uint32_t keys[kLocalSlots]; // counter index held by the slot
     __shared__ uint32_t vals[kLocalSlots]; // earliest waiting operation of the tile on that counter
     __shared__ unsigned long long s_stats[6]; // [5]: operations replayed (all of a plain pair, the candidates of a census pair)
@@ -1040,6 +1035,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     __shared__ uint32_t s_pair;
     if (threadIdx.x < 6)
         s_stats[threadIdx.x] = 0;
+    fill_seed_table(seed_t); // (the barriers at the top of the pair loop come before its first use)
     const int t0 = threadIdx.x * kLPer;
     bool slot_clean = false; // uniform: the previous pair was short and has been unwound
 
@@ -1065,6 +1061,23 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     const unsigned long long* const cand_bits = census ? a.cand + (a.pair_bit_off[pair] >> 6) : nullptr;
     if (!slot_clean)
         zero_slot(cb, a.cbf_stride);
+    // Census pairs: the candidates are mostly later copies of k-mers that reached their threshold
+    // long ago -- four counter look-ups and four filter look-ups each to learn that nothing is
+    // left to do.  Once an operation finds ALL its counters >= S-1 (rule (b) at the top of the
+    // file: it and every later operation on these counters insert and write nothing) and has put
+    // its k-mer into the filter, every later copy of that k-mer is done before it starts; its
+    // 64-bit hash (which fixes the counters and the filter bits) goes into a direct-mapped table
+    // of the workgroup's own, and a candidate that finds its hash there costs that one look-up.
+    // A table entry lost to another k-mer only costs the full look-ups again.
+    // (thresholds of a census pair are kept one lower: see census_scatter; a batch of one contig
+    // has one pair of them, fetched here and not behind every candidate's hash)
+    const uint32_t seg_lo = a.batch_seg[b], seg_hi = a.batch_seg[b + 1];
+    const uint32_t thr_one =
+        seg_lo < seg_hi ? (a.seg_thr[seg_lo] - 2 + ki - 1) | ((a.seg_smax[seg_lo] - 2 + ki - 1) << 16) : 0u;
+    unsigned long long* const kset =
+        census && a.kset_mask ? a.kset + (uint64_t)blockIdx.x * ((uint64_t)a.kset_mask + 1) : nullptr;
+    if (kset)
+        zero_slot(reinterpret_cast<uint8_t*>(kset), ((uint64_t)a.kset_mask + 1) * 8);
 
     // A turn of this loop replays up to 512 operations, two per lane, in serial order.  Plain
     // pairs: the next 512 positions.  Census pairs: the next 512 CANDIDATES of a 2048-position
@@ -1076,6 +1089,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
         uint32_t op_state[kLPer] = {}, op_thr[kLPer] = {}, op_c[kLPer] = {};
         uint32_t op_idx[kLPer][4] = {};
         uint64_t op_base[kLPer] = {};
+        uint32_t op_set[kLPer] = {};
         __syncthreads(); // everyone is done with the previous turn (codes, table)
         if (!census) {
         if (next0 >= b_end)
@@ -1092,7 +1106,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
 
         const uint64_t pos0 = tile0 + t0;
         if (pos0 < tile_end) {
-            uint32_t lo = 0, hi = a.n_seg;
+            uint32_t lo = seg_lo, hi = seg_hi; // the batch's contigs
             while (hi - lo > 1) {
                 uint32_t mid = (lo + hi) >> 1;
                 if (a.seg_start[mid] <= pos0)
@@ -1104,14 +1118,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
             uint64_t seg_end = a.seg_start[seg + 1];
             uint64_t fh = 0, rh = 0;
             int last_bad = -1;
-            for (uint32_t i = 0; i < k; i++) {
-                uint32_t cf = codes[t0 + i];
-                uint32_t cr = codes[t0 + k - 1 - i];
-                fh = srol1(fh) ^ (cf < 4 ? seed_of_code(cf) : 0ULL);
-                rh = srol1(rh) ^ (cr < 4 ? seed_of_code(cr ^ 2) : 0ULL);
-                if (cf >= 4)
-                    last_bad = (int)i;
-            }
+            kmer_hash_from_table(seed_t, codes + t0, k, fh, rh, last_bad);
 #pragma unroll
             for (int j = 0; j < kLPer; j++) {
                 const uint64_t pos = pos0 + j;
@@ -1206,22 +1213,28 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
             const uint32_t prel = wlo * 64 + select64(s_cw[wlo], ci - s_cpre[wlo]);
             const uint64_t pos = win0 + prel;
             uint64_t fh = 0, rh = 0;
-            for (uint32_t i = 0; i < k; i++) { // a candidate is a k-mer: no byte of it is bad
-                fh = srol1(fh) ^ seed_of_code(codes[prel + i]);
-                rh = srol1(rh) ^ seed_of_code(codes[prel + k - 1 - i] ^ 2u);
-            }
-            uint32_t seg = a.batch_seg[b];
-            for (uint32_t hi = a.batch_seg[b + 1]; hi - seg > 1;) { // one contig per batch: no step
-                const uint32_t mid = (seg + hi) >> 1;
-                if (a.seg_start[mid] <= pos)
-                    seg = mid;
-                else
-                    hi = mid;
-            }
+            int no_bad = -1; // a candidate is a k-mer: no byte of it is bad
+            kmer_hash_from_table(seed_t, codes + prel, k, fh, rh, no_bad);
             op_base[j] = fh + rh;
-            op_thr[j] = (a.seg_thr[seg] - 2 + ki - 1) | ((a.seg_smax[seg] - 2 + ki - 1) << 16); // one lower: see census_scatter
-            op_state[j] = 1;
             n_replayed++;
+            if (kset) {
+                op_set[j] = (uint32_t)((op_base[j] * 0x9E3779B97F4A7C15ULL) >> 32) & a.kset_mask;
+                if (kset[op_set[j]] == op_base[j] && op_base[j] != 0)
+                    continue; // settled for good and in the filter
+            }
+            op_thr[j] = thr_one;
+            if (seg_hi - seg_lo > 1) { // several contigs in the batch: the one whose reads hold the position
+                uint32_t seg = seg_lo;
+                for (uint32_t hi = seg_hi; hi - seg > 1;) {
+                    const uint32_t mid = (seg + hi) >> 1;
+                    if (a.seg_start[mid] <= pos)
+                        seg = mid;
+                    else
+                        hi = mid;
+                }
+                op_thr[j] = (a.seg_thr[seg] - 2 + ki - 1) | ((a.seg_smax[seg] - 2 + ki - 1) << 16);
+            }
+            op_state[j] = 1;
             uint32_t pack = 0;
             for (uint32_t h = 0; h < 4; h++) {
                 if (h >= a.hash_num)
@@ -1260,6 +1273,8 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
                         for (uint32_t i = 1; i < a.hash_num; i++)
                             hv[i] = ext_hash(op_base[j], k, i);
                         bf_insert(a, stream, hv);
+                        if (kset && m + 1 >= (op_thr[j] >> 16))
+                            kset[op_set[j]] = op_base[j];
                         op_state[j] = 0;
                         continue;
                     }
@@ -1325,6 +1340,8 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
                     for (uint32_t h = 1; h < a.hash_num; h++)
                         hv[h] = ext_hash(op_base[j], k, h);
                     bf_insert(a, stream, hv);
+                    if (kset && m + 1 >= (op_thr[j] >> 16))
+                        kset[op_set[j]] = op_base[j]; // every counter is >= m now
                 }
                 op_state[j] = 0;
             }
@@ -1792,6 +1809,18 @@ int stage_a_run(gp_job* job)
                 a.pair_mode = job->d_pair_mode.p;
                 a.pair_bit_off = job->d_pair_bit_off.p;
                 a.cand = job->d_cand.p;
+            }
+        }
+        a.kset = nullptr;
+        a.kset_mask = 0;
+        if (a.pair_mode) {
+            // the table of settled k-mers of a census pair: 2^16 entries (512 KiB) per workgroup
+            const uint64_t lg = std::min<uint64_t>(24, env_u64("GP_STAGE_A_KSET_LOG2", 16));
+            if (lg >= 4) {
+                if ((rc0 = job->d_kset.ensure((uint64_t)grid << lg)) != GP_OK)
+                    return rc0;
+                a.kset = job->d_kset.p;
+                a.kset_mask = (uint32_t)((1ull << lg) - 1);
             }
         }
         if ((rc0 = job->t_local.begin(s, units)) != GP_OK)
