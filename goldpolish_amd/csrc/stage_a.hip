@@ -175,14 +175,21 @@ __device__ inline void ctr_increment(const AArgs& a, uint8_t* cb, uint32_t idx, 
 __device__ inline void bf_insert(const AArgs& a, uint32_t stream, const uint64_t* hv)
 {
     uint32_t* w = a.bf + (uint64_t)stream * a.bf_words;
-    for (uint32_t i = 0; i < a.hash_num; i++) {
-        uint64_t n = fastmod(hv[i], a.bf_mod);
-        uint32_t bit = 1u << (uint32_t)(n & 31);
-        uint32_t* p = w + (n >> 5);
-        // a stale read only costs a redundant atomic: bits are never cleared
-        if (!(*p & bit))
-            atomicOr(p, bit);
-    }
+    // the words first, all in flight together, then the bits that are missing
+    uint32_t* p[kMaxHash];
+    uint32_t bit[kMaxHash], have[kMaxHash];
+#pragma unroll
+    for (int i = 0; i < kMaxHash; i++)
+        if ((uint32_t)i < a.hash_num) {
+            const uint64_t n = fastmod(hv[i], a.bf_mod);
+            bit[i] = 1u << (uint32_t)(n & 31);
+            p[i] = w + (n >> 5);
+            have[i] = *p[i];
+        }
+#pragma unroll
+    for (int i = 0; i < kMaxHash; i++)
+        if ((uint32_t)i < a.hash_num && !(have[i] & bit[i]))
+            atomicOr(p[i], bit[i]); // a stale read only costs a redundant atomic: bits are never cleared
 }
 
 // A reservation is (tag, position) packed so that atomicMin prefers the newer round first
@@ -1166,6 +1173,21 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
                     break;
                 win0 = next0;
                 next0 += kLWin;
+                // the window's bases and its candidate bits in one round trip (the loads first, all
+                // in flight together, then the stores)
+                {
+                    constexpr int kPer = (kLWin + kHalo + kLBlock - 1) / kLBlock;
+                    uint8_t raw[kPer];
+#pragma unroll
+                    for (int q = 0; q < kPer; q++) {
+                        const uint64_t p = win0 + (uint64_t)(q * kLBlock) + threadIdx.x;
+                        raw[q] = p < a.n_pos ? a.reads[p] : (uint8_t)'\n';
+                    }
+#pragma unroll
+                    for (int q = 0; q < kPer; q++)
+                        if (q * kLBlock + (int)threadIdx.x < kLWin + kHalo)
+                            codes[q * kLBlock + threadIdx.x] = base_code(raw[q]);
+                }
                 if (threadIdx.x < kLWin / 64) { // lanes 0..31 of wave 0
                     unsigned long long w = cand_bits[((win0 - b_start) >> 6) + threadIdx.x];
                     const uint64_t first = win0 + (uint64_t)threadIdx.x * 64; // bits past the batch are not the census's
@@ -1194,12 +1216,10 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
             }
             if (c0 >= n_c)
                 break; // no candidate left in the batch (uniform)
-            for (int i = threadIdx.x; i < kLWin + kHalo; i += kLBlock) {
-                const uint64_t p = win0 + i;
-                codes[i] = base_code(p < a.n_pos ? a.reads[p] : (uint8_t)'\n');
-            }
-            __syncthreads();
         }
+        // the hashes first, and the look-ups in the table of settled k-mers in flight together
+        unsigned long long seen[kLPer] = {};
+        uint64_t op_pos[kLPer] = {};
 #pragma unroll
         for (int j = 0; j < kLPer; j++) {
             const uint32_t ci = c0 + (uint32_t)(t0 + j);
@@ -1216,12 +1236,23 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
             int no_bad = -1; // a candidate is a k-mer: no byte of it is bad
             kmer_hash_from_table(seed_t, codes + prel, k, fh, rh, no_bad);
             op_base[j] = fh + rh;
-            n_replayed++;
+            op_pos[j] = pos;
+            op_state[j] = 1;
             if (kset) {
                 op_set[j] = (uint32_t)((op_base[j] * 0x9E3779B97F4A7C15ULL) >> 32) & a.kset_mask;
-                if (kset[op_set[j]] == op_base[j] && op_base[j] != 0)
-                    continue; // settled for good and in the filter
+                seen[j] = kset[op_set[j]];
             }
+        }
+#pragma unroll
+        for (int j = 0; j < kLPer; j++) {
+            if (!op_state[j])
+                continue;
+            n_replayed++;
+            if (kset && seen[j] == op_base[j] && op_base[j] != 0) {
+                op_state[j] = 0; // settled for good and in the filter
+                continue;
+            }
+            const uint64_t pos = op_pos[j];
             op_thr[j] = thr_one;
             if (seg_hi - seg_lo > 1) { // several contigs in the batch: the one whose reads hold the position
                 uint32_t seg = seg_lo;
@@ -1234,7 +1265,6 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
                 }
                 op_thr[j] = (a.seg_thr[seg] - 2 + ki - 1) | ((a.seg_smax[seg] - 2 + ki - 1) << 16);
             }
-            op_state[j] = 1;
             uint32_t pack = 0;
             for (uint32_t h = 0; h < 4; h++) {
                 if (h >= a.hash_num)
