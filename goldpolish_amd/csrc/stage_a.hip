@@ -1779,6 +1779,20 @@ int stage_a_run(gp_job* job)
                                       hipMemcpyHostToDevice, s));
                 if ((rcc = job->t_census.begin(s, units)) != GP_OK)
                     return rcc;
+                // census_scatter is faster with FEWER workgroups on the chip: each has 1280 runs of
+                // record slots open (327 KB), eight per CU keep 670 MB of half-written lines in
+                // flight and every record leaves L2 as a sector of its own; two per CU (168 MB, inside
+                // the 256 MB of Infinity Cache) take 0.46 s instead of 0.59 s for configs[2], one or
+                // three the same.  Held down with unused dynamic LDS.  (census_mark is the other way
+                // round: 0.27 s at full occupancy, 0.38 s at three per CU.)
+                size_t scatter_pad = 0;
+                if (const uint64_t want = env_u64("GP_STAGE_A_SCATTER_PER_CU", 2)) {
+                    hipFuncAttributes fa{};
+                    GP_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(census_scatter)));
+                    const size_t lds_cu = 160 * 1024, share = lds_cu / want;
+                    if (share > fa.sharedSizeBytes + 256)
+                        scatter_pad = (share - fa.sharedSizeBytes) / 256 * 256;
+                }
                 for (Cohort& co : cohorts) {
                     const size_t np = co.pair_batch.size(), nw = co.wg_pair.size();
                     // one table of 32-bit and one of 64-bit columns per cohort
@@ -1823,7 +1837,7 @@ int stage_a_run(gp_job* job)
                     c.cand = job->d_cand.p;
                     c.bucket_shift = bucket_shift;
                     c.n_buckets = n_buckets;
-                    hipLaunchKernelGGL(census_scatter, dim3((unsigned)nw), dim3(kBlock), 0, s, a, c);
+                    hipLaunchKernelGGL(census_scatter, dim3((unsigned)nw), dim3(kBlock), scatter_pad, s, a, c);
                     {
                         uint32_t max_nst = 0;
                         for (uint32_t x : co.pair_nst)
