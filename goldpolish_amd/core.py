@@ -71,7 +71,7 @@ class Counters(C.Structure):
         "a_positions", "a_ops", "a_ordered_ops", "a_rounds", "b_scan_kmers", "b_sites",
         "b_probes", "b_edits", "c_gaps", "c_closed", "c_vertex_tests", "a_reservations",
         "c_no_start_goal", "c_no_path", "c_unique_path", "c_multiple_paths", "c_too_many_paths",
-        "c_too_many_branches", "c_max_cost", "a_replayed")]
+        "c_too_many_branches", "c_max_cost", "a_replayed", "a_settled_hits")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

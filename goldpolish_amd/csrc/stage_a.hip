@@ -127,7 +127,7 @@ struct AArgs {
     const uint32_t* batch_order; // batches in the order the groups take them (long ones first, then the cbf_local ones)
     uint32_t grp_first, grp_n, tiles_per_batch;
     uint64_t off, slice;
-    unsigned long long* stats; // [0] positions [1] ops [2] ordered ops [3] tail / local rounds [4] reservation atomics
+    unsigned long long* stats; // [0] positions [1] ops [2] ordered ops [3] tail / local rounds [4] reservation atomics [5] replayed [6] settled-table hits
 };
 
 __device__ inline uint32_t resv_slot(const AArgs& a, uint32_t bits, uint32_t stream, uint32_t idx)
@@ -772,9 +772,19 @@ __device__ inline LaneOps lane_hashes(const uint64_t* seed_t, const uint8_t* cod
 // stretches, whose runs of six records reach memory as partial sectors.)
 __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
 {
+    // Records do not go to memory one by one (a 4-byte store is an L2 request of its own and, with
+    // hundreds of MB of half-written runs in flight, leaves L2 as a 32-byte sector of its own: PMC
+    // showed 1.35 TB written per configs[2] step for 0.26 TB of records, and the kernel bound by
+    // that).  Every range has a ring of eight record slots in LDS; after each tile the complete
+    // groups of four records are written as 16 bytes.  The window of a range is [base, base + 8)
+    // record slots of its run, base a multiple of four: a record whose slot lies in it goes to the
+    // ring, any other (a tile that brings a range more than the ring holds) straight to memory, so
+    // a group of four is always written by one of the two ways only.
+    extern __shared__ uint32_t ring[]; // [ranges][8]
     __shared__ uint8_t codes[kTile + kHalo];
     __shared__ uint64_t seed_t[kSeedTableWords];
     __shared__ uint32_t hist[kCBuckets];
+    __shared__ uint8_t gbase[kCBuckets]; // groups of four of the run that are not the ring's any more (base / 4)
     const uint32_t pair = c.wg_pair[blockIdx.x];
     const uint32_t b = c.pair_batch[pair], ki = c.pair_ki[pair];
     const KConsts& kc = a.kc[ki];
@@ -788,15 +798,17 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
     const uint32_t shift = c.bucket_shift, lmask = (1u << shift) - 1u;
     uint32_t n_positions = 0, n_ops = 0;
     bool over = false;
-    for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock)
+    for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock) {
         hist[i] = 0;
+        gbase[i] = 0;
+    }
     fill_seed_table(seed_t);
     for (int st = 0; st < kCSuper; st++) {
         const uint64_t tile0 = pos0 + (uint64_t)st * kTile;
         if (tile0 >= stretch_end)
             break; // uniform
         const uint64_t tile_end = min(stretch_end, tile0 + (uint64_t)kTile);
-        __syncthreads(); // codes free (and hist cleared before the first use)
+        __syncthreads(); // codes and ring free (and the counters cleared before the first use)
         for (int i = threadIdx.x; i < kTile + kHalo; i += kBlock) {
             const uint64_t p = tile0 + i;
             codes[i] = base_code(p < a.n_pos ? a.reads[p] : (uint8_t)'\n');
@@ -816,17 +828,43 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
                 const uint32_t ix = (uint32_t)fastmod(h ? ext_hash(o.base[j], k, h) : o.base[j], a.cbf_mod);
                 const uint32_t bucket = ix >> shift;
                 const uint32_t rank = atomicAdd(&hist[bucket], 1u);
-                if (rank < kCRun)
-                    rec[((uint64_t)bucket * nst + stretch) * kCRun + rank] = (off << 16) | ((ix & lmask) << 2) | h;
-                else
+                const uint32_t r = (off << 16) | ((ix & lmask) << 2) | h;
+                if (rank >= kCRun)
                     over = true;
+                else if (rank - 4u * gbase[bucket] < 8u)
+                    ring[bucket * 8u + (rank & 7u)] = r;
+                else
+                    rec[((uint64_t)bucket * nst + stretch) * kCRun + rank] = r;
             }
+        }
+        __syncthreads();
+        // the groups of four this tile completed
+        for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock) {
+            const uint32_t cnt = min(hist[i], kCRun), g0 = gbase[i];
+            uint32_t ng, g_next;
+            if (cnt > 4u * g0 + 8u) { // more than the ring holds: its two groups are full, the rest is in memory
+                ng = 2;
+                g_next = (cnt + 3u) / 4u;
+            } else {
+                ng = cnt > 4u * g0 ? (cnt - 4u * g0) / 4u : 0u; // (after such a tile the window starts past the records)
+                g_next = g0 + ng;
+            }
+            uint4* const dst = reinterpret_cast<uint4*>(rec + ((uint64_t)i * nst + stretch) * kCRun);
+            const uint4* const src = reinterpret_cast<const uint4*>(ring + i * 8u);
+            for (uint32_t g = g0; g < g0 + ng; g++)
+                dst[g] = src[g & 1u];
+            gbase[i] = (uint8_t)g_next;
         }
     }
     __syncthreads();
     uint8_t* const cnt = c.cnt + c.pair_cnt_off[pair];
-    for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock)
-        cnt[(uint64_t)i * nst + stretch] = (uint8_t)min(hist[i], kCRun);
+    for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock) {
+        const uint32_t n = min(hist[i], kCRun);
+        cnt[(uint64_t)i * nst + stretch] = (uint8_t)n;
+        // what is left in the ring: fewer than four records
+        for (uint32_t r = 4u * gbase[i]; r < n; r++)
+            rec[((uint64_t)i * nst + stretch) * kCRun + r] = ring[i * 8u + (r & 7u)];
+    }
     if (over)
         c.overflow[pair] = 1u; // many copies of one k-mer within the stretch: this pair is replayed whole
     // per-wave sums, one atomic each
@@ -1031,7 +1069,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     __shared__ uint64_t seed_t[kSeedTableWords];
     __shared__ uint32_t keys[kLocalSlots]; // counter index held by the slot
     __shared__ uint32_t vals[kLocalSlots]; // earliest waiting operation of the tile on that counter
-    __shared__ unsigned long long s_stats[6]; // [5]: operations replayed (all of a plain pair, the candidates of a census pair)
+    __shared__ unsigned long long s_stats[7]; // [5]: operations replayed (all of a plain pair, the candidates of a census pair), [6]: settled-table hits
     __shared__ unsigned long long s_cw[kLWin / 64]; // census: candidate bits of the window ...
     __shared__ uint32_t s_cpre[kLWin / 64], s_ncand;   // ... candidates before each word, and in all
     // This workgroup's arena slot for the whole launch: the counting filter of whichever pair it
@@ -1040,14 +1078,14 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     // of leaving its CU idle.  Every workgroup reaches the end of the queue and exits.
     uint8_t* const cb = a.cbf + (uint64_t)blockIdx.x * a.cbf_stride;
     __shared__ uint32_t s_pair;
-    if (threadIdx.x < 6)
+    if (threadIdx.x < 7)
         s_stats[threadIdx.x] = 0;
     fill_seed_table(seed_t); // (the barriers at the top of the pair loop come before its first use)
     const int t0 = threadIdx.x * kLPer;
     bool slot_clean = false; // uniform: the previous pair was short and has been unwound
 
     for (;;) {
-    uint32_t n_ops = 0, n_ordered = 0, n_positions = 0, n_rounds = 0, n_replayed = 0;
+    uint32_t n_ops = 0, n_ordered = 0, n_positions = 0, n_rounds = 0, n_replayed = 0, n_hits = 0;
     __syncthreads(); // the previous pair is finished by every wave
     if (threadIdx.x == 0)
         s_pair = atomicAdd(a.queue, 1u);
@@ -1250,6 +1288,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
             n_replayed++;
             if (kset && seen[j] == op_base[j] && op_base[j] != 0) {
                 op_state[j] = 0; // settled for good and in the filter
+                n_hits++;
                 continue;
             }
             const uint64_t pos = op_pos[j];
@@ -1385,6 +1424,8 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     atomicAdd(&s_stats[2], (unsigned long long)n_ordered);
     atomicAdd(&s_stats[3], (unsigned long long)n_rounds);
     atomicAdd(&s_stats[5], (unsigned long long)n_replayed);
+    if (n_hits)
+        atomicAdd(&s_stats[6], (unsigned long long)n_hits);
     // fewer counter lines touched than a quarter of the slot holds: unwind instead of clearing
     slot_clean = (b_end - b_start) * a.hash_num * 64 * 4 < a.cbf_stride;
     if (slot_clean) {
@@ -1393,7 +1434,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     }
     } // next pair
     __syncthreads();
-    if (threadIdx.x < 6 && threadIdx.x != 4 && s_stats[threadIdx.x])
+    if (threadIdx.x < 7 && threadIdx.x != 4 && s_stats[threadIdx.x])
         atomicAdd(&a.stats[threadIdx.x], s_stats[threadIdx.x]);
 }
 
@@ -1779,20 +1820,10 @@ int stage_a_run(gp_job* job)
                                       hipMemcpyHostToDevice, s));
                 if ((rcc = job->t_census.begin(s, units)) != GP_OK)
                     return rcc;
-                // census_scatter is faster with FEWER workgroups on the chip: each has 1280 runs of
-                // record slots open (327 KB), eight per CU keep 670 MB of half-written lines in
-                // flight and every record leaves L2 as a sector of its own; two per CU (168 MB, inside
-                // the 256 MB of Infinity Cache) take 0.46 s instead of 0.59 s for configs[2], one or
-                // three the same.  Held down with unused dynamic LDS.  (census_mark is the other way
-                // round: 0.27 s at full occupancy, 0.38 s at three per CU.)
-                size_t scatter_pad = 0;
-                if (const uint64_t want = env_u64("GP_STAGE_A_SCATTER_PER_CU", 2)) {
-                    hipFuncAttributes fa{};
-                    GP_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(census_scatter)));
-                    const size_t lds_cu = 160 * 1024, share = lds_cu / want;
-                    if (share > fa.sharedSizeBytes + 256)
-                        scatter_pad = (share - fa.sharedSizeBytes) / 256 * 256;
-                }
+                // census_scatter: a ring of eight record slots per range in LDS (40 KB at 1280 ranges:
+                // two workgroups per CU, which is also what it likes best -- with eight per CU and
+                // records stored one by one it had 670 MB of half-written runs in flight)
+                const size_t scatter_lds = (size_t)n_buckets * 8 * sizeof(uint32_t);
                 for (Cohort& co : cohorts) {
                     const size_t np = co.pair_batch.size(), nw = co.wg_pair.size();
                     // one table of 32-bit and one of 64-bit columns per cohort
@@ -1837,7 +1868,7 @@ int stage_a_run(gp_job* job)
                     c.cand = job->d_cand.p;
                     c.bucket_shift = bucket_shift;
                     c.n_buckets = n_buckets;
-                    hipLaunchKernelGGL(census_scatter, dim3((unsigned)nw), dim3(kBlock), scatter_pad, s, a, c);
+                    hipLaunchKernelGGL(census_scatter, dim3((unsigned)nw), dim3(kBlock), scatter_lds, s, a, c);
                     {
                         uint32_t max_nst = 0;
                         for (uint32_t x : co.pair_nst)
@@ -2180,7 +2211,7 @@ int stage_a_run(gp_job* job)
     }
     unsigned long long* const st = job->h_readback;   // pinned: [0..4] statistics, [8] the tail's error flag
     st[8] = 0;
-    GP_HIP(hipMemcpyAsync(st, job->d_stats.p, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    GP_HIP(hipMemcpyAsync(st, job->d_stats.p, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     GP_HIP(hipMemcpyAsync(st + 8, err_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     GP_HIP(hipStreamSynchronize(s));
     const uint32_t tail_err = (uint32_t)st[8];
@@ -2190,6 +2221,7 @@ int stage_a_run(gp_job* job)
     job->counters.a_rounds += st[3];
     job->counters.a_reservations = st[4];
     job->counters.a_replayed = st[5];
+    job->counters.a_settled_hits = st[6];
     if (tail_err) {
         set_error("stage A: reservation rounds did not converge");
         return GP_ERR_STATE;

@@ -124,6 +124,7 @@ typedef struct gp_counters {
     uint64_t c_too_many_branches; /* "Too many branches" */
     uint64_t c_max_cost;          /* "Max cost exceeded" */
     uint64_t a_replayed;          /* operations cbf_local replayed: every one of a plain pair, the candidates of a census pair */
+    uint64_t a_settled_hits;      /* ... of which found in the table of k-mers settled for good: one look-up each, nothing else */
 } gp_counters;
 
 /* ---- library / context ------------------------------------------------- */
