@@ -83,6 +83,18 @@ __host__ __device__ inline uint64_t sroln(uint64_t x, uint32_t n)
 }
 
 // i-th extension hash of canonical value `base` for k-mer size k (i >= 1)
+#ifdef __HIPCC__
+// Workgroups go round the eight XCDs by blockIdx, each XCD with an L2 of its own.  For a grid whose
+// neighbouring units read the same data (tiles of one contig probing that contig's 512 KiB Bloom
+// filter), unit = xcd_contiguous(blockIdx.x, gridDim.x) gives every XCD one contiguous eighth of
+// the units, so that a filter is fetched into one L2, not into eight.
+__device__ inline uint32_t xcd_contiguous(uint32_t i, uint32_t n)
+{
+    const uint32_t per = n / 8u;
+    return i < per * 8u ? (i % 8u) * per + i / 8u : i;
+}
+#endif
+
 // Seeds rotated in advance: T[j * 8 + code] = srol^j(seed[code]) for j < 64 (k <= 64), zero in the
 // columns of kBadCode and its "complement" kBadCode ^ 2.  srol is a permutation of bits, so the
 // hash of a k-mer from scratch -- k rotate-select-xor steps per strand, a few hundred

@@ -805,7 +805,8 @@ __global__ __launch_bounds__(kWalkThreads, 6) void ntedit_site_eval(WalkArgs a, 
     __shared__ uint32_t s_cand[kEvalTile], s_n;
     const uint32_t tid = threadIdx.x;
     // the tile tables are per 4096-position tile (kMatTile); this kernel cuts them in 16
-    const uint32_t big = blockIdx.x / (kMatTile / kEvalTile), sub = blockIdx.x % (kMatTile / kEvalTile);
+    const uint32_t unit = xcd_contiguous(blockIdx.x, gridDim.x); // a contig's tiles probe one filter: one XCD, one L2
+    const uint32_t big = unit / (kMatTile / kEvalTile), sub = unit % (kMatTile / kEvalTile);
     const uint32_t cid = tile_contig[big];
     if (a.dropped[cid])
         return;
@@ -1935,7 +1936,7 @@ __global__ __launch_bounds__(256) void ntedit_scan(WalkArgs a, uint32_t n_contig
 {
     __shared__ uint8_t z[kScanTile + kMaxK];
     __shared__ HashTab ht;
-    const uint64_t tile0 = (uint64_t)blockIdx.x * kScanTile;
+    const uint64_t tile0 = (uint64_t)xcd_contiguous(blockIdx.x, gridDim.x) * kScanTile; // (as in ntedit_site_eval)
     // contig whose slot holds tile0
     uint32_t lo = 0, hi = n_contigs;
     while (hi - lo > 1) {
