@@ -1890,7 +1890,7 @@ int stage_a_run(gp_job* job)
         a.kset_mask = 0;
         if (a.pair_mode) {
             // the table of settled k-mers of a census pair: 2^18 entries (2 MiB) per workgroup (44 % of the
-            // candidates of configs[2] are found in 2^16 entries, 49 % in 2^18, 50 % in 2^20)
+            // candidates of configs[2] are found there with 2^16 entries, 50 % with 2^20)
             const uint64_t lg = std::min<uint64_t>(24, env_u64("GP_STAGE_A_KSET_LOG2", 18));
             if (lg >= 4) {
                 if ((rc0 = job->d_kset.ensure((uint64_t)grid << lg)) != GP_OK)

@@ -1111,90 +1111,128 @@ __device__ inline int nw_score(uint8_t x, uint8_t y, uint8_t& c)
     return (c == x || c == y) ? 5 : -4;
 }
 
+// LDS of one consensus worker (one wave): the two sequences and three anti-diagonals of the
+// three score matrices
+struct NwLds {
+    int32_t dg[3][3][kNwMax + 2]; // [diagonal % 3][F, G, H][row]
+    uint8_t A[kNwMax + 4], B[kNwMax + 4];
+    uint32_t n;
+};
+
 // Gotoh global alignment + consensus (Align/alignGlobal.cc:55-198); out gets the
-// consensus, returns its length
-__device__ uint32_t nw_consensus(const uint8_t* A, uint32_t la, const uint8_t* B, uint32_t lb,
+// consensus, returns its length.  Called by every lane of the worker's wave: the matrices are
+// filled anti-diagonal by anti-diagonal, a cell per lane, with the two previous diagonals in LDS
+// (a cell needs its upper and left neighbours of the diagonal before and the upper-left one of
+// the diagonal before that); every cell also goes to memory, where lane 0 then walks back
+// through them exactly as the serial code does.  (One lane filling 300 x 300 cells from memory
+// took tens of milliseconds: the multi-path gaps were a fifth of stage C's time.)
+__device__ uint32_t nw_consensus(NwLds& L, const uint8_t* A_in, uint32_t la, const uint8_t* B_in, uint32_t lb,
                                  int32_t* mat, uint8_t* out)
 {
     const int OPEN = -12, EXT = -4, NEG = -(1 << 29);
     const uint32_t W = lb + 1;
+    const uint32_t lane = threadIdx.x;
     int32_t* f = mat;
     int32_t* g = mat + (uint64_t)(kNwMax + 1) * (kNwMax + 1);
     int32_t* h = g + (uint64_t)(kNwMax + 1) * (kNwMax + 1);
 #define F(i, j) f[(uint64_t)(i) * W + (j)]
 #define G(i, j) g[(uint64_t)(i) * W + (j)]
 #define H(i, j) h[(uint64_t)(i) * W + (j)]
-    for (uint32_t i = 0; i <= la; i++) {
-        F(i, 0) = G(i, 0) = i == 0 ? 0 : OPEN + EXT * ((int)i - 1);
-        H(i, 0) = NEG;
-    }
-    for (uint32_t j = 0; j <= lb; j++) {
-        F(0, j) = H(0, j) = j == 0 ? 0 : OPEN + EXT * ((int)j - 1);
-        G(0, j) = NEG;
-    }
+    __syncthreads(); // the previous alignment's LDS is free
+    for (uint32_t i = lane; i < la; i += 64)
+        L.A[i] = A_in[i];
+    for (uint32_t j = lane; j < lb; j += 64)
+        L.B[j] = B_in[j];
+    __syncthreads();
     uint8_t c;
-    for (uint32_t i = 1; i <= la; i++)
-        for (uint32_t j = 1; j <= lb; j++) {
-            const int a1 = F(i - 1, j) + OPEN, a2 = G(i - 1, j) + EXT;
-            G(i, j) = max(a1, a2);
-            const int b1 = F(i, j - 1) + OPEN, b2 = H(i, j - 1) + EXT;
-            H(i, j) = max(b1, b2);
-            const int d = F(i - 1, j - 1) + nw_score(A[i - 1], B[j - 1], c);
-            F(i, j) = max(d, max(G(i, j), H(i, j)));
+    for (uint32_t d = 0; d <= la + lb; d++) {
+        const uint32_t cur = d % 3, p1 = (d + 2) % 3, p2 = (d + 1) % 3;
+        const uint32_t i_lo = d > lb ? d - lb : 0u, i_hi = min(d, la);
+        for (uint32_t i = i_lo + lane; i <= i_hi; i += 64) {
+            const uint32_t j = d - i;
+            int fv, gv, hv;
+            if (i == 0) {
+                fv = hv = j == 0 ? 0 : OPEN + EXT * ((int)j - 1);
+                gv = NEG;
+            } else if (j == 0) {
+                fv = gv = OPEN + EXT * ((int)i - 1);
+                hv = NEG;
+            } else {
+                gv = max(L.dg[p1][0][i - 1] + OPEN, L.dg[p1][1][i - 1] + EXT);
+                hv = max(L.dg[p1][0][i] + OPEN, L.dg[p1][2][i] + EXT);
+                const int dv = L.dg[p2][0][i - 1] + nw_score(L.A[i - 1], L.B[j - 1], c);
+                fv = max(dv, max(gv, hv));
+            }
+            L.dg[cur][0][i] = fv;
+            L.dg[cur][1][i] = gv;
+            L.dg[cur][2][i] = hv;
+            F(i, j) = fv;
+            G(i, j) = gv;
+            H(i, j) = hv;
         }
-    uint32_t n = 0, i = la, j = lb;
-    while (i > 0 && j > 0) {
-        const int fij = F(i, j);
-        const uint8_t x = A[i - 1], y = B[j - 1];
-        const int sc = nw_score(x, y, c);
-        if (fij == F(i - 1, j - 1) + sc) {
-            out[n++] = c;
-            i--;
-            j--;
-        } else if (fij == F(i - 1, j) + OPEN || fij == G(i - 1, j) + EXT) {
-            while (i > 1 && G(i, j) == G(i - 1, j) + EXT) {
+        __syncthreads();
+    }
+    if (lane == 0) {
+        const uint8_t* A = L.A;
+        const uint8_t* B = L.B;
+        uint32_t n = 0, i = la, j = lb;
+        while (i > 0 && j > 0) {
+            const int fij = F(i, j);
+            const uint8_t x = A[i - 1], y = B[j - 1];
+            const int sc = nw_score(x, y, c);
+            if (fij == F(i - 1, j - 1) + sc) {
+                out[n++] = c;
+                i--;
+                j--;
+            } else if (fij == F(i - 1, j) + OPEN || fij == G(i - 1, j) + EXT) {
+                while (i > 1 && G(i, j) == G(i - 1, j) + EXT) {
+                    out[n++] = (uint8_t)(A[i - 1] | 0x20);
+                    i--;
+                }
                 out[n++] = (uint8_t)(A[i - 1] | 0x20);
                 i--;
-            }
-            out[n++] = (uint8_t)(A[i - 1] | 0x20);
-            i--;
-        } else {
-            while (j > 1 && H(i, j) == H(i, j - 1) + EXT) {
+            } else {
+                while (j > 1 && H(i, j) == H(i, j - 1) + EXT) {
+                    out[n++] = (uint8_t)(B[j - 1] | 0x20);
+                    j--;
+                }
                 out[n++] = (uint8_t)(B[j - 1] | 0x20);
                 j--;
             }
-            out[n++] = (uint8_t)(B[j - 1] | 0x20);
-            j--;
         }
+        while (i > 0)
+            out[n++] = (uint8_t)(A[--i] | 0x20);
+        while (j > 0)
+            out[n++] = (uint8_t)(B[--j] | 0x20);
+        for (uint32_t x = 0, y = n; x + 1 < y; x++, y--) {
+            const uint8_t t = out[x];
+            out[x] = out[y - 1];
+            out[y - 1] = t;
+        }
+        L.n = n;
     }
-    while (i > 0)
-        out[n++] = (uint8_t)(A[--i] | 0x20);
-    while (j > 0)
-        out[n++] = (uint8_t)(B[--j] | 0x20);
-    for (uint32_t x = 0, y = n; x + 1 < y; x++, y--) {
-        const uint8_t t = out[x];
-        out[x] = out[y - 1];
-        out[y - 1] = t;
-    }
+    __syncthreads(); // `out` (memory, written by lane 0) and L.n are there for every lane
 #undef F
 #undef G
 #undef H
-    return n;
+    return L.n;
 }
 
-__device__ void consensus_one(const CArgs& a, uint32_t it, int32_t* mat, uint8_t* bufA,
+// every lane of the worker's wave (the alignments are filled by all of them)
+__device__ void consensus_one(const CArgs& a, NwLds& L, uint32_t it, int32_t* mat, uint8_t* bufA,
                               uint8_t* bufB, uint8_t* r1, uint8_t* r2)
 {
     const MultiHdr h = a.multi[it];
     bool ok = true;
     for (uint32_t p = 0; p < h.n_paths; p++)
         ok &= (h.off[p] != ~0ULL) && h.len[p] <= kNwMax;
-    if (!ok) {
-        atomicOr(a.err, 256u);
+    if (!ok) { // (uniform: every lane read the same header)
+        if (threadIdx.x == 0)
+            atomicOr(a.err, 256u);
         return;
     }
     // alignPair for two, alignMulti's left fold for more
-    uint32_t lc = nw_consensus(a.pool + h.off[0], h.len[0], a.pool + h.off[1], h.len[1], mat, bufA);
+    uint32_t lc = nw_consensus(L, a.pool + h.off[0], h.len[0], a.pool + h.off[1], h.len[1], mat, bufA);
     uint8_t* cur = bufA;
     uint8_t* nxt = bufB;
     for (uint32_t p = 2; p < h.n_paths && ok; p++) {
@@ -1202,11 +1240,13 @@ __device__ void consensus_one(const CArgs& a, uint32_t it, int32_t* mat, uint8_t
             ok = false;
             break;
         }
-        lc = nw_consensus(cur, lc, a.pool + h.off[p], h.len[p], mat, nxt);
+        lc = nw_consensus(L, cur, lc, a.pool + h.off[p], h.len[p], mat, nxt);
         uint8_t* t = cur;
         cur = nxt;
         nxt = t;
     }
+    if (threadIdx.x != 0)
+        return;
     if (!ok) {
         atomicOr(a.err, 256u);
         return;
@@ -1224,6 +1264,7 @@ __device__ void consensus_one(const CArgs& a, uint32_t it, int32_t* mat, uint8_t
 
 __global__ __launch_bounds__(64) void sealer_consensus(CArgs a)
 {
+    __shared__ NwLds L;
     __shared__ uint32_t item;
     __shared__ uint8_t r1[64], r2[64];
     const uint32_t wid = blockIdx.x, lane = threadIdx.x;
@@ -1242,8 +1283,7 @@ __global__ __launch_bounds__(64) void sealer_consensus(CArgs a)
         __syncthreads();
         if (it >= n_multi)
             break;
-        if (lane == 0)
-            consensus_one(a, it, mat, bufA, bufB, r1, r2);
+        consensus_one(a, L, it, mat, bufA, bufB, r1, r2);
     }
 }
 
