@@ -93,6 +93,21 @@ def pmc_traffic(workload, kernel):
     return None, None
 
 
+def pmc_traffic_census(workload):
+    """the same for the three census kernels in front of a cbf_local launch, summed per cbf_local launch"""
+    for f in sorted((ROOT / "profiles").glob(f"r*_{workload}_pmc_traffic.json"), reverse=True):
+        t = json.loads(f.read_text())
+        loc = t.get("gp::cbf_local")
+        if not loc or "FETCH_SIZE" not in loc:
+            continue
+        kb = 0.0
+        for name in ("gp::census_scatter", "gp::census_mark", "gp::census_pack"):
+            for c in ("FETCH_SIZE", "WRITE_SIZE"):
+                kb += t.get(name, {}).get(c, {}).get("sum_KB", 0.0)
+        return int(kb * 1024 / max(loc["FETCH_SIZE"]["launches"], 1))
+    return None
+
+
 def gather_to_rank0(lens, payload, rank, world):
     """Variable-length gather of the polished records on rank 0 (the path's only exchange).
     `lens` (int64) and `payload` (uint8) are tensors on the backend's device: HBM under
@@ -347,6 +362,8 @@ def main():
             out["priced_over"] = ("cbf_local's launch plus the census kernels in front of it (census_scatter, census_mark, "
                                   "census_pack: %.3f ms per cbf_local launch)" % (census_ms / max(kk["launches"], 1)))
         traffic, src = pmc_traffic(workload, name)
+        if census_ms and traffic:
+            out["traffic_census_kernels"] = pmc_traffic_census(workload)   # per cbf_local launch, same source
         out.update({
             "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic,
