@@ -150,7 +150,7 @@ struct gp_job {
     // census of first touches (stage_a.hip): work buffers of a cohort, results for the whole job
     gp::DevBuf<unsigned long long> d_cand, d_kset;
     gp::DevBuf<uint8_t> d_census_cnt;
-    gp::DevBuf<uint32_t> d_census_rec, d_census_flags, d_census_over, d_census_tab32, d_pair_mode;
+    gp::DevBuf<uint32_t> d_census_rec, d_census_over, d_census_tab32, d_pair_mode;
     gp::DevBuf<uint64_t> d_census_tab64, d_pair_bit_off;
     gp::DevBuf<uint32_t> d_counts;        // ring of per-step list lengths, one 128-B line each
     gp::DevBuf<unsigned long long> d_stats; // device-side gp_counters

@@ -710,12 +710,10 @@ struct CensusArgs {
     const uint32_t* pair_nst;      // [pairs] stretches of the pair
     const uint64_t* pair_rec_off;  // [pairs] first record of the pair: rec[bucket][stretch][kCRun]
     const uint64_t* pair_cnt_off;  // [pairs] first count of the pair: cnt[bucket][stretch]
-    const uint64_t* pair_flag_off; // [pairs] first position of the pair in `flags`
     const uint64_t* pair_bit_off;  // [pairs] first bit of the pair in `cand` (multiple of 64)
     const uint32_t* pair_queue;    // [pairs] index of the pair in cbf_local's queue (for pair_mode)
-    uint32_t* rec;                 // (position in the stretch << 16) | (counter in its range << 2) | hash number
+    uint32_t* rec;                 // (position in the stretch << 16) | (counter in its range << 2) | hash number; bit 31: marked (census_mark)
     uint8_t* cnt;                  // records a stretch left in a bucket
-    uint32_t* flags;               // one byte per (position, hash): 1 = that touch is not the counter's first
     uint32_t* overflow;            // [pairs]
     uint32_t* pair_mode;           // [queue entries] set to 2 for pairs that overflowed
     unsigned long long* cand;
@@ -890,7 +888,7 @@ __global__ __launch_bounds__(256) void census_mark(CensusArgs c)
     if (c.overflow[pair])
         return;
     const uint32_t nst = c.pair_nst[pair];
-    const uint32_t* rec = c.rec + c.pair_rec_off[pair] + (uint64_t)bucket * nst * kCRun;
+    uint32_t* const rec = c.rec + c.pair_rec_off[pair] + (uint64_t)bucket * nst * kCRun;
     const uint8_t* cnt = c.cnt + c.pair_cnt_off[pair] + (uint64_t)bucket * nst;
     uint8_t* const s_cnt = reinterpret_cast<uint8_t*>(first_t + bucket_w);
     for (uint32_t i = threadIdx.x; i < bucket_w; i += 256)
@@ -917,24 +915,41 @@ __global__ __launch_bounds__(256) void census_mark(CensusArgs c)
             atomicMin(&first_t[(r >> 2) & 0x3FFFu], st * kCStretch + (r >> 16));
         }
     __syncthreads();
-    uint8_t* const fl = reinterpret_cast<uint8_t*>(c.flags + c.pair_flag_off[pair]);
-    auto mark = [&](uint32_t r, uint32_t st) {
+    // The touches that are not their counter's first go back into the head of their own run, bit 31
+    // set, packed (the records are in registers, the run is this wave's alone): a sector or two per
+    // run, next to each other, instead of a flag byte per touch scattered over the pair's positions
+    // (19 G bytes per configs[2] step that left L2 as 0.64 TB of partial sectors).  census_pack reads
+    // a run up to the first record without the bit; a run whose touches are all marked gets a zero
+    // behind them (what lies past a run's records is left over from an earlier cohort).
+    auto mark = [&](uint32_t r, bool valid, uint32_t st) { // every lane of the wave
         const uint32_t t = st * kCStretch + (r >> 16);
-        if (first_t[(r >> 2) & 0x3FFFu] != t)
-            fl[(uint64_t)t * 4 + (r & 3u)] = 1; // (a counter hit twice by one operation: both touches are its first)
+        const bool later = valid && first_t[(r >> 2) & 0x3FFFu] != t; // (a counter hit twice by one operation: both touches are its first)
+        const unsigned long long m = __ballot(later);
+        uint32_t* const run = rec + (uint64_t)st * kCRun;
+        if (later)
+            run[__popcll(m & ((1ull << lane) - 1ull))] = r | 0x80000000u;
+        const uint32_t n = (uint32_t)__popcll(m);
+        if (lane == 0 && n == s_cnt[st] && n < kCRun)
+            run[n] = 0;
     };
 #pragma unroll
-    for (int q = 0; q < kKeep; q++)
-        if (keep[q] != 0xFFFFFFFFu)
-            mark(keep[q], wave + 4u * (uint32_t)q);
-    for (uint32_t st = wave + 4u * kKeep; st < nst; st += 4)
-        if (lane < s_cnt[st])
-            mark(rec[(uint64_t)st * kCRun + lane], st);
+    for (int q = 0; q < kKeep; q++) {
+        const uint32_t st = wave + 4u * (uint32_t)q;
+        if (st < nst)
+            mark(keep[q], keep[q] != 0xFFFFFFFFu, st);
+    }
+    for (uint32_t st = wave + 4u * kKeep; st < nst; st += 4) {
+        const bool valid = lane < s_cnt[st];
+        mark(valid ? rec[(uint64_t)st * kCRun + lane] : 0u, valid, st);
+    }
 }
 
-// ---- census 3: operations with every touch marked -> one bit each
+// ---- census 3: operations with every touch marked -> one bit each.  A workgroup per stretch: a lane
+// per range reads the marked records at the head of the stretch's run there and counts them per
+// position in LDS (a byte each).
 __global__ __launch_bounds__(256) void census_pack(AArgs a, CensusArgs c)
 {
+    __shared__ uint32_t s_touch[kCStretch / 4];
     const uint32_t pair = c.wg_pair[blockIdx.x];
     if (c.overflow[pair]) {
         if (threadIdx.x == 0)
@@ -945,11 +960,35 @@ __global__ __launch_bounds__(256) void census_pack(AArgs a, CensusArgs c)
     const uint64_t b_start = a.batch_pos[b], b_end = a.batch_pos[b + 1];
     const uint64_t pos0 = c.wg_pos0[blockIdx.x];
     const uint64_t stretch_end = min(b_end, pos0 + (uint64_t)kCStretch);
-    const uint32_t all = a.hash_num >= 4 ? 0x01010101u : ((1u << (8 * a.hash_num)) - 1u) & 0x01010101u;
-    const uint32_t* fl = c.flags + c.pair_flag_off[pair];
+    const uint32_t nst = c.pair_nst[pair], stretch = (uint32_t)((pos0 - b_start) / kCStretch);
+    for (uint32_t i = threadIdx.x; i < kCStretch / 4; i += 256)
+        s_touch[i] = 0;
+    __syncthreads();
+    const uint32_t* const rec = c.rec + c.pair_rec_off[pair];
+    for (uint32_t bu = threadIdx.x; bu < c.n_buckets; bu += 256) {
+        const uint4* run = reinterpret_cast<const uint4*>(rec + ((uint64_t)bu * nst + stretch) * kCRun);
+        for (uint32_t q = 0; q < kCRun / 4; q++) {
+            const uint4 v = run[q];
+            const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+            bool more = true;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (more && (w[i] >> 31)) {
+                    const uint32_t off = (w[i] >> 16) & (kCStretch - 1u);
+                    atomicAdd(&s_touch[off >> 2], 1u << (8u * (off & 3u)));
+                } else {
+                    more = false;
+                }
+            }
+            if (!more)
+                break;
+        }
+    }
+    __syncthreads();
     for (uint64_t p0 = pos0; p0 < stretch_end; p0 += 256) {
         const uint64_t p = p0 + threadIdx.x;
-        const bool is_cand = p < stretch_end && fl[p - b_start] == all;
+        const uint32_t rel = (uint32_t)(p - pos0);
+        const bool is_cand = p < stretch_end && ((s_touch[rel >> 2] >> (8u * (rel & 3u))) & 255u) == a.hash_num;
         const unsigned long long m = __ballot(is_cand);
         if ((threadIdx.x & 63) == 0 && p < stretch_end)
             c.cand[(c.pair_bit_off[pair] + (p - b_start)) >> 6] = m; // stretches and batches start on multiples of 64 bits
@@ -1712,7 +1751,7 @@ int stage_a_run(gp_job* job)
     // census tables: host copies stay alive until the stream has been synchronised at the end
     struct Cohort {
         std::vector<uint32_t> wg_pair, pair_batch, pair_ki, pair_nst, pair_queue, tab32;
-        std::vector<uint64_t> wg_pos0, pair_rec_off, pair_cnt_off, pair_flag_off, pair_bit_off, tab64;
+        std::vector<uint64_t> wg_pos0, pair_rec_off, pair_cnt_off, pair_bit_off, tab64;
     };
     std::vector<Cohort> cohorts;
     std::vector<uint32_t> h_pair_mode;
@@ -1754,20 +1793,19 @@ int stage_a_run(gp_job* job)
             const uint64_t rec_budget = (env_u64("GP_STAGE_A_CENSUS_MB", 16384) << 20) / 4; // (4-byte) record slots of a cohort
             h_pair_mode.assign(n_pairs, 0);
             h_pair_bit_off.assign(n_pairs, 0);
-            uint64_t bits = 0, max_rec = 0, max_cnt = 0, max_flags = 0, max_pairs = 0, max_wg = 0;
+            uint64_t bits = 0, max_rec = 0, max_cnt = 0, max_pairs = 0, max_wg = 0;
             Cohort cur;
-            uint64_t cur_rec = 0, cur_cnt = 0, cur_flags = 0;
+            uint64_t cur_rec = 0, cur_cnt = 0;
             auto close = [&]() {
                 if (cur.pair_batch.empty())
                     return;
                 max_rec = std::max(max_rec, cur_rec);
                 max_cnt = std::max(max_cnt, cur_cnt);
-                max_flags = std::max(max_flags, cur_flags);
                 max_pairs = std::max<uint64_t>(max_pairs, cur.pair_batch.size());
                 max_wg = std::max<uint64_t>(max_wg, cur.wg_pair.size());
                 cohorts.push_back(std::move(cur));
                 cur = Cohort();
-                cur_rec = cur_cnt = cur_flags = 0;
+                cur_rec = cur_cnt = 0;
             };
             for (uint32_t i = 0; i < n_local; i++) {
                 const uint32_t b = order[n_big + i];
@@ -1790,13 +1828,11 @@ int stage_a_run(gp_job* job)
                     cur.pair_queue.push_back(q);
                     cur.pair_rec_off.push_back(cur_rec);
                     cur.pair_cnt_off.push_back(cur_cnt);
-                    cur.pair_flag_off.push_back(cur_flags);
                     cur.pair_bit_off.push_back(bits);
                     h_pair_mode[q] = 1;
                     h_pair_bit_off[q] = bits;
                     cur_rec += recs;
                     cur_cnt += (uint64_t)n_buckets * nst;
-                    cur_flags += pos;
                     bits += (pos + kLWin - 1) / kLWin * kLWin; // whole windows of cbf_local
                     for (uint64_t p0 = 0; p0 < pos; p0 += kCStretch) {
                         cur.wg_pair.push_back(lp);
@@ -1807,11 +1843,11 @@ int stage_a_run(gp_job* job)
             close();
             if (!cohorts.empty()) {
                 int rcc;
-                if ((rcc = job->d_census_rec.ensure(max_rec)) != GP_OK || (rcc = job->d_census_flags.ensure(max_flags)) != GP_OK ||
+                if ((rcc = job->d_census_rec.ensure(max_rec)) != GP_OK ||
                     (rcc = job->d_census_cnt.ensure(max_cnt)) != GP_OK ||
                     (rcc = job->d_census_over.ensure(max_pairs)) != GP_OK ||
                     (rcc = job->d_census_tab32.ensure(max_wg + 4 * max_pairs)) != GP_OK ||
-                    (rcc = job->d_census_tab64.ensure(max_wg + 4 * max_pairs)) != GP_OK ||
+                    (rcc = job->d_census_tab64.ensure(max_wg + 3 * max_pairs)) != GP_OK ||
                     (rcc = job->d_cand.ensure(bits / 64)) != GP_OK || (rcc = job->d_pair_mode.ensure(n_pairs)) != GP_OK ||
                     (rcc = job->d_pair_bit_off.ensure(n_pairs)) != GP_OK)
                     return rcc;
@@ -1833,21 +1869,16 @@ int stage_a_run(gp_job* job)
                     co.tab32.insert(co.tab32.end(), co.pair_ki.begin(), co.pair_ki.end());
                     co.tab32.insert(co.tab32.end(), co.pair_nst.begin(), co.pair_nst.end());
                     co.tab32.insert(co.tab32.end(), co.pair_queue.begin(), co.pair_queue.end());
-                    co.tab64.reserve(nw + 4 * np);
+                    co.tab64.reserve(nw + 3 * np);
                     co.tab64.insert(co.tab64.end(), co.wg_pos0.begin(), co.wg_pos0.end());
                     co.tab64.insert(co.tab64.end(), co.pair_rec_off.begin(), co.pair_rec_off.end());
                     co.tab64.insert(co.tab64.end(), co.pair_cnt_off.begin(), co.pair_cnt_off.end());
-                    co.tab64.insert(co.tab64.end(), co.pair_flag_off.begin(), co.pair_flag_off.end());
                     co.tab64.insert(co.tab64.end(), co.pair_bit_off.begin(), co.pair_bit_off.end());
                     GP_HIP(hipMemcpyAsync(job->d_census_tab32.p, co.tab32.data(), co.tab32.size() * sizeof(uint32_t),
                                           hipMemcpyHostToDevice, s));
                     GP_HIP(hipMemcpyAsync(job->d_census_tab64.p, co.tab64.data(), co.tab64.size() * sizeof(uint64_t),
                                           hipMemcpyHostToDevice, s));
-                    uint64_t flags_n = 0;
-                    for (size_t i = 0; i < np; i++)
-                        flags_n = std::max<uint64_t>(flags_n, co.pair_flag_off[i] + (batch_pos[co.pair_batch[i] + 1] - batch_pos[co.pair_batch[i]]));
                     GP_HIP(hipMemsetAsync(job->d_census_over.p, 0, np * sizeof(uint32_t), s));
-                    GP_HIP(hipMemsetAsync(job->d_census_flags.p, 0, flags_n * sizeof(uint32_t), s));
                     CensusArgs c{};
                     c.wg_pair = job->d_census_tab32.p;
                     c.pair_batch = c.wg_pair + nw;
@@ -1857,12 +1888,10 @@ int stage_a_run(gp_job* job)
                     c.wg_pos0 = job->d_census_tab64.p;
                     c.pair_rec_off = c.wg_pos0 + nw;
                     c.pair_cnt_off = c.pair_rec_off + np;
-                    c.pair_flag_off = c.pair_cnt_off + np;
-                    c.pair_bit_off = c.pair_flag_off + np;
+                    c.pair_bit_off = c.pair_cnt_off + np;
                     c.n_wg = (uint32_t)nw;
                     c.rec = job->d_census_rec.p;
                     c.cnt = job->d_census_cnt.p;
-                    c.flags = job->d_census_flags.p;
                     c.overflow = job->d_census_over.p;
                     c.pair_mode = job->d_pair_mode.p;
                     c.cand = job->d_cand.p;

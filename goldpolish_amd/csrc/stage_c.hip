@@ -48,7 +48,7 @@ constexpr uint32_t kSmallSlotBits = 8, kSmallVerts = 96, kSmallEdges = 256;
 constexpr uint32_t kSimtWaves = 2048;   // waves of the lane-per-gap kernel ...
 constexpr uint32_t kSimtLanes = 32;     // ... and the lanes of each that take a gap (divergent walks serialise)
 constexpr uint32_t kNwMax = 1800;            // longest sequence the consensus aligner takes
-constexpr int kWorkers = 1024;
+constexpr uint32_t kMaxWorkers = 2048;  // one-wave workers of sealer_connect, 13 MB of arena each (CState::n_workers: by job size)
 constexpr int kNwWorkers = 16;
 
 enum { FWD = 0, REV = 1 };
@@ -107,6 +107,7 @@ struct CState {
     DevBuf<uint32_t> epoch;        // per worker
     std::vector<uint32_t> h_gap_off;
     uint32_t gap_cap = 0, table_bits = 0, multi_cap = 0;
+    uint32_t n_workers = 0;        // sealer_connect's grid: 1024 took 0.15 s per configs[2] step, 2048 take 0.10 s
     uint64_t pool_cap = 0;
 };
 
@@ -1420,6 +1421,10 @@ int stage_c_prepare(gp_job* job)
     c->table_bits = tb;
     c->multi_cap = (uint32_t)std::min<uint64_t>(g, 1u << 20);
     c->pool_cap = 2 * total_len + (16ull << 20);
+    // a worker per 4 kbp of contigs, 256 at least (3 GiB of arenas), kMaxWorkers (26 GiB) from 8 Mbp on
+    c->n_workers = (uint32_t)std::min<uint64_t>(
+        kMaxWorkers, std::max<uint64_t>(256, env_u64("GP_SEALER_WORKERS", total_len / 4096)));
+    const uint64_t n_workers = c->n_workers;
     int rc;
     if ((rc = c->gaps.alloc(g)) != GP_OK || (rc = c->gap_off.alloc((size_t)n + 1)) != GP_OK ||
         (rc = c->n_gaps.alloc(n)) != GP_OK || (rc = c->pair_last.alloc(g)) != GP_OK ||
@@ -1430,18 +1435,18 @@ int stage_c_prepare(gp_job* job)
         (rc = c->small.alloc((uint64_t)kSimtWaves * kSimtLanes * sizeof(SmallArena))) != GP_OK ||
         (rc = c->queue.alloc(8)) != GP_OK || (rc = c->pool.alloc(c->pool_cap)) != GP_OK ||
         (rc = c->pool_head.alloc(1)) != GP_OK || (rc = c->multi.alloc(c->multi_cap)) != GP_OK ||
-        (rc = c->slots.alloc((uint64_t)kWorkers * kSlots)) != GP_OK ||
-        (rc = c->verts.alloc((uint64_t)kWorkers * kVertCap)) != GP_OK ||
-        (rc = c->edges.alloc((uint64_t)kWorkers * kEdgeCap)) != GP_OK ||
-        (rc = c->scratch.alloc((uint64_t)kWorkers * kScratchWords)) != GP_OK ||
+        (rc = c->slots.alloc(n_workers * kSlots)) != GP_OK ||
+        (rc = c->verts.alloc(n_workers * kVertCap)) != GP_OK ||
+        (rc = c->edges.alloc(n_workers * kEdgeCap)) != GP_OK ||
+        (rc = c->scratch.alloc(n_workers * kScratchWords)) != GP_OK ||
         (rc = c->nw.alloc((uint64_t)kNwWorkers *
                           (3ull * (kNwMax + 1) * (kNwMax + 1) + 2 * (2 * kNwMax + 64) / 4 + 64))) != GP_OK ||
-        (rc = c->epoch.alloc(kWorkers)) != GP_OK)
+        (rc = c->epoch.alloc(n_workers)) != GP_OK)
         return rc;
     GP_HIP(hipMemcpy(c->gap_off.p, c->h_gap_off.data(), (n + 1) * sizeof(uint32_t),
                      hipMemcpyHostToDevice));
-    GP_HIP(hipMemset(c->slots.p, 0, (uint64_t)kWorkers * kSlots * sizeof(uint32_t)));
-    GP_HIP(hipMemset(c->epoch.p, 0, kWorkers * sizeof(uint32_t)));
+    GP_HIP(hipMemset(c->slots.p, 0, n_workers * kSlots * sizeof(uint32_t)));
+    GP_HIP(hipMemset(c->epoch.p, 0, n_workers * sizeof(uint32_t)));
     return GP_OK;
 }
 
@@ -1529,7 +1534,7 @@ int stage_c_run(gp_job* job)
         GP_HIP(hipMemsetAsync(c->queue.p + 4, 0, 2 * sizeof(uint32_t), s));
         hipLaunchKernelGGL(sealer_connect_lanes, dim3(kSimtWaves), dim3(64), 0, s, a,
                            reinterpret_cast<SmallArena*>(c->small.p));
-        hipLaunchKernelGGL(sealer_connect, dim3(kWorkers), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(sealer_connect, dim3(c->n_workers), dim3(64), 0, s, a);
         hipLaunchKernelGGL(sealer_consensus, dim3(kNwWorkers), dim3(64), 0, s, a);
     }
     hipLaunchKernelGGL(apply_fills, dim3(job->n_contigs), dim3(kApplyThreads), 0, s, a);
