@@ -1101,6 +1101,14 @@ constexpr int kLWin = 2048;            // census pairs: positions whose candidat
 constexpr int kLocalSlotBits = 12;
 constexpr int kLocalSlots = 1 << kLocalSlotBits; // >= 2 x the counter touches of a tile (hash_num <= 4)
 constexpr uint32_t kLocalEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kLSetBits = 1u << 17;   // LDS filter in front of the settled table: a candidate whose bit is clear is not in it
+
+__device__ inline void kset_put(unsigned long long* kset, uint32_t* s_kbits, uint32_t slot, uint64_t base)
+{
+    kset[slot] = base;
+    const uint32_t kb = (uint32_t)((base * 0x9E3779B97F4A7C15ULL) >> 10) & (kLSetBits - 1u);
+    atomicOr(&s_kbits[kb >> 5], 1u << (kb & 31u));
+}
 
 __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, uint32_t n_pairs) // 4 workgroups per CU: <= 128 VGPRs
 {
@@ -1109,6 +1117,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
     __shared__ uint32_t keys[kLocalSlots]; // counter index held by the slot
     __shared__ uint32_t vals[kLocalSlots]; // earliest waiting operation of the tile on that counter
     __shared__ unsigned long long s_stats[7]; // [5]: operations replayed (all of a plain pair, the candidates of a census pair), [6]: settled-table hits
+    __shared__ uint32_t s_kbits[kLSetBits / 32];    // census: a bit per k-mer hash that has gone into the settled table
     __shared__ unsigned long long s_cw[kLWin / 64]; // census: candidate bits of the window ...
     __shared__ uint32_t s_cpre[kLWin / 64], s_ncand;   // ... candidates before each word, and in all
     // This workgroup's arena slot for the whole launch: the counting filter of whichever pair it
@@ -1160,8 +1169,11 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
         seg_lo < seg_hi ? (a.seg_thr[seg_lo] - 2 + ki - 1) | ((a.seg_smax[seg_lo] - 2 + ki - 1) << 16) : 0u;
     unsigned long long* const kset =
         census && a.kset_mask ? a.kset + (uint64_t)blockIdx.x * ((uint64_t)a.kset_mask + 1) : nullptr;
-    if (kset)
+    if (kset) {
         zero_slot(reinterpret_cast<uint8_t*>(kset), ((uint64_t)a.kset_mask + 1) * 8);
+        for (uint32_t i = threadIdx.x; i < kLSetBits / 32; i += kLBlock)
+            s_kbits[i] = 0; // (the barrier at the top of the first turn comes before its first use)
+    }
 
     // A turn of this loop replays up to 512 operations, two per lane, in serial order.  Plain
     // pairs: the next 512 positions.  Census pairs: the next 512 CANDIDATES of a 2048-position
@@ -1316,8 +1328,11 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
             op_pos[j] = pos;
             op_state[j] = 1;
             if (kset) {
-                op_set[j] = (uint32_t)((op_base[j] * 0x9E3779B97F4A7C15ULL) >> 32) & a.kset_mask;
-                seen[j] = kset[op_set[j]];
+                const uint64_t mix = op_base[j] * 0x9E3779B97F4A7C15ULL;
+                op_set[j] = (uint32_t)(mix >> 32) & a.kset_mask;
+                const uint32_t kb = (uint32_t)(mix >> 10) & (kLSetBits - 1u);
+                // (more than half of the candidates are not in the table: most of them learn it here)
+                seen[j] = (s_kbits[kb >> 5] >> (kb & 31u)) & 1u ? kset[op_set[j]] : 0ull;
             }
         }
 #pragma unroll
@@ -1382,7 +1397,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
                             hv[i] = ext_hash(op_base[j], k, i);
                         bf_insert(a, stream, hv);
                         if (kset && m + 1 >= (op_thr[j] >> 16))
-                            kset[op_set[j]] = op_base[j];
+                            kset_put(kset, s_kbits, op_set[j], op_base[j]);
                         op_state[j] = 0;
                         continue;
                     }
@@ -1449,7 +1464,7 @@ __global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, ui
                         hv[h] = ext_hash(op_base[j], k, h);
                     bf_insert(a, stream, hv);
                     if (kset && m + 1 >= (op_thr[j] >> 16))
-                        kset[op_set[j]] = op_base[j]; // every counter is >= m now
+                        kset_put(kset, s_kbits, op_set[j], op_base[j]); // every counter is >= m now
                 }
                 op_state[j] = 0;
             }
