@@ -1606,6 +1606,8 @@ int stage_a_prepare(gp_job* job)
     }
     GP_HIP(hipEventCreateWithFlags(&job->a_ev_init, hipEventDisableTiming));
     GP_HIP(hipStreamCreateWithFlags(&job->a_stream2, hipStreamNonBlocking));
+    for (hipEvent_t& e : job->a_ev_census)
+        GP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return GP_OK;
 }
 
@@ -1624,6 +1626,11 @@ void stage_a_release(gp_job* job)
         (void)hipEventDestroy(job->a_ev_init);
     if (job->a_stream2)
         (void)hipStreamDestroy(job->a_stream2);
+    for (hipEvent_t& e : job->a_ev_census)
+        if (e) {
+            (void)hipEventDestroy(e);
+            e = nullptr;
+        }
 }
 
 int stage_a_run(gp_job* job)
@@ -1805,7 +1812,12 @@ int stage_a_run(gp_job* job)
         const uint32_t n_buckets = (uint32_t)((p.cbf_bytes + (1ull << bucket_shift) - 1) >> bucket_shift);
         if (env_u64("GP_STAGE_A_CENSUS", 1) && p.hash_num <= 4 && bucket_shift <= kCMaxShift) {
             const uint64_t min_pos = env_u64("GP_STAGE_A_CENSUS_MIN", 65536);           // below: too few touches per bucket
-            const uint64_t rec_budget = (env_u64("GP_STAGE_A_CENSUS_MB", 16384) << 20) / 4; // (4-byte) record slots of a cohort
+            // Two buffer sets: census_scatter of one cohort (VALU and write bandwidth) runs beside
+            // census_mark / census_pack of the one before it (latency), on two streams.  (Worth 4 % of
+            // the census: both kernels are held by LDS -- 2 x 56 KB and 4 x 33 KB per CU -- so beside a
+            // full scatter the mark gets one workgroup per CU.)
+            const uint32_t n_sets = env_u64("GP_STAGE_A_CENSUS_OVERLAP", 1) ? 2u : 1u;
+            const uint64_t rec_budget = (env_u64("GP_STAGE_A_CENSUS_MB", 16384) << 20) / 4 / n_sets; // (4-byte) record slots of a cohort
             h_pair_mode.assign(n_pairs, 0);
             h_pair_bit_off.assign(n_pairs, 0);
             uint64_t bits = 0, max_rec = 0, max_cnt = 0, max_pairs = 0, max_wg = 0;
@@ -1858,11 +1870,13 @@ int stage_a_run(gp_job* job)
             close();
             if (!cohorts.empty()) {
                 int rcc;
-                if ((rcc = job->d_census_rec.ensure(max_rec)) != GP_OK ||
-                    (rcc = job->d_census_cnt.ensure(max_cnt)) != GP_OK ||
-                    (rcc = job->d_census_over.ensure(max_pairs)) != GP_OK ||
-                    (rcc = job->d_census_tab32.ensure(max_wg + 4 * max_pairs)) != GP_OK ||
-                    (rcc = job->d_census_tab64.ensure(max_wg + 3 * max_pairs)) != GP_OK ||
+                max_rec = (max_rec + 63) / 64 * 64; // (a set's records start on a line)
+                const uint64_t tab32_n = (max_wg + 4 * max_pairs + 3) / 4 * 4, tab64_n = max_wg + 3 * max_pairs;
+                if ((rcc = job->d_census_rec.ensure(n_sets * max_rec)) != GP_OK ||
+                    (rcc = job->d_census_cnt.ensure(n_sets * max_cnt)) != GP_OK ||
+                    (rcc = job->d_census_over.ensure(n_sets * max_pairs)) != GP_OK ||
+                    (rcc = job->d_census_tab32.ensure(n_sets * tab32_n)) != GP_OK ||
+                    (rcc = job->d_census_tab64.ensure(n_sets * tab64_n)) != GP_OK ||
                     (rcc = job->d_cand.ensure(bits / 64)) != GP_OK || (rcc = job->d_pair_mode.ensure(n_pairs)) != GP_OK ||
                     (rcc = job->d_pair_bit_off.ensure(n_pairs)) != GP_OK)
                     return rcc;
@@ -1875,7 +1889,16 @@ int stage_a_run(gp_job* job)
                 // two workgroups per CU, which is also what it likes best -- with eight per CU and
                 // records stored one by one it had 670 MB of half-written runs in flight)
                 const size_t scatter_lds = (size_t)n_buckets * 8 * sizeof(uint32_t);
-                for (Cohort& co : cohorts) {
+                hipStream_t sm = n_sets > 1 ? job->a_stream2 : s; // mark and pack
+                for (size_t ci = 0; ci < cohorts.size(); ci++) {
+                    Cohort& co = cohorts[ci];
+                    const uint32_t set = (uint32_t)(ci % n_sets);
+                    hipEvent_t ev_scattered = job->a_ev_census[set], ev_marked = job->a_ev_census[2 + set];
+                    if (n_sets > 1 && ci >= n_sets)
+                        GP_HIP(hipStreamWaitEvent(s, ev_marked, 0)); // the set's previous cohort has been packed
+                    uint32_t* const d_tab32 = job->d_census_tab32.p + (uint64_t)set * tab32_n;
+                    uint64_t* const d_tab64 = job->d_census_tab64.p + (uint64_t)set * tab64_n;
+                    uint32_t* const d_over = job->d_census_over.p + (uint64_t)set * max_pairs;
                     const size_t np = co.pair_batch.size(), nw = co.wg_pair.size();
                     // one table of 32-bit and one of 64-bit columns per cohort
                     co.tab32.reserve(nw + 4 * np);
@@ -1889,40 +1912,49 @@ int stage_a_run(gp_job* job)
                     co.tab64.insert(co.tab64.end(), co.pair_rec_off.begin(), co.pair_rec_off.end());
                     co.tab64.insert(co.tab64.end(), co.pair_cnt_off.begin(), co.pair_cnt_off.end());
                     co.tab64.insert(co.tab64.end(), co.pair_bit_off.begin(), co.pair_bit_off.end());
-                    GP_HIP(hipMemcpyAsync(job->d_census_tab32.p, co.tab32.data(), co.tab32.size() * sizeof(uint32_t),
+                    GP_HIP(hipMemcpyAsync(d_tab32, co.tab32.data(), co.tab32.size() * sizeof(uint32_t),
                                           hipMemcpyHostToDevice, s));
-                    GP_HIP(hipMemcpyAsync(job->d_census_tab64.p, co.tab64.data(), co.tab64.size() * sizeof(uint64_t),
+                    GP_HIP(hipMemcpyAsync(d_tab64, co.tab64.data(), co.tab64.size() * sizeof(uint64_t),
                                           hipMemcpyHostToDevice, s));
-                    GP_HIP(hipMemsetAsync(job->d_census_over.p, 0, np * sizeof(uint32_t), s));
+                    GP_HIP(hipMemsetAsync(d_over, 0, np * sizeof(uint32_t), s));
                     CensusArgs c{};
-                    c.wg_pair = job->d_census_tab32.p;
+                    c.wg_pair = d_tab32;
                     c.pair_batch = c.wg_pair + nw;
                     c.pair_ki = c.pair_batch + np;
                     c.pair_nst = c.pair_ki + np;
                     c.pair_queue = c.pair_nst + np;
-                    c.wg_pos0 = job->d_census_tab64.p;
+                    c.wg_pos0 = d_tab64;
                     c.pair_rec_off = c.wg_pos0 + nw;
                     c.pair_cnt_off = c.pair_rec_off + np;
                     c.pair_bit_off = c.pair_cnt_off + np;
                     c.n_wg = (uint32_t)nw;
-                    c.rec = job->d_census_rec.p;
-                    c.cnt = job->d_census_cnt.p;
-                    c.overflow = job->d_census_over.p;
+                    c.rec = job->d_census_rec.p + (uint64_t)set * max_rec;
+                    c.cnt = job->d_census_cnt.p + (uint64_t)set * max_cnt;
+                    c.overflow = d_over;
                     c.pair_mode = job->d_pair_mode.p;
                     c.cand = job->d_cand.p;
                     c.bucket_shift = bucket_shift;
                     c.n_buckets = n_buckets;
                     hipLaunchKernelGGL(census_scatter, dim3((unsigned)nw), dim3(kBlock), scatter_lds, s, a, c);
+                    if (n_sets > 1) {
+                        GP_HIP(hipEventRecord(ev_scattered, s));
+                        GP_HIP(hipStreamWaitEvent(sm, ev_scattered, 0));
+                    }
                     {
                         uint32_t max_nst = 0;
                         for (uint32_t x : co.pair_nst)
                             max_nst = std::max(max_nst, x);
                         const size_t lds = ((size_t)sizeof(uint32_t) << bucket_shift) + (max_nst + 3) / 4 * 4;
-                        hipLaunchKernelGGL(census_mark, dim3((unsigned)(np * n_buckets)), dim3(256), lds, s, c);
+                        hipLaunchKernelGGL(census_mark, dim3((unsigned)(np * n_buckets)), dim3(256), lds, sm, c);
                     }
-                    hipLaunchKernelGGL(census_pack, dim3((unsigned)nw), dim3(256), 0, s, a, c);
+                    hipLaunchKernelGGL(census_pack, dim3((unsigned)nw), dim3(256), 0, sm, a, c);
                     GP_HIP(hipGetLastError());
+                    if (n_sets > 1)
+                        GP_HIP(hipEventRecord(ev_marked, sm));
                 }
+                if (n_sets > 1) // everything has been packed before the replay starts
+                    for (uint32_t set = 0; set < n_sets && set < cohorts.size(); set++)
+                        GP_HIP(hipStreamWaitEvent(s, job->a_ev_census[2 + set], 0));
                 if ((rcc = job->t_census.end(s)) != GP_OK)
                     return rcc;
                 a.pair_mode = job->d_pair_mode.p;
