@@ -42,6 +42,7 @@ constexpr int kCacheBases = kCacheWords * 64 + 256; // ... and their bases plus 
 constexpr int kMatTile = 4096; // bytes per workgroup in the tile-parallel copy kernels
 constexpr int kMaxK = 64;
 constexpr int kZMax = 2 * kMaxK + 16 + kWalkThreads; // window chars in LDS
+constexpr int kGSegMax = 40;                          // position runs of a gathered window copied by all lanes
 
 struct SiteRec;
 
@@ -142,6 +143,11 @@ struct Shared {
     uint32_t best_key;        // (support << 16) | order, reduced with atomicMax
     unsigned long long st_scan, st_sites, st_probes, st_edits;
     uint8_t Z[kZMax];
+    // what gather_plan leaves for every lane to copy: runs of untouched contig inside the window
+    struct GSeg {
+        uint32_t z0, pos, cnt;
+    } gseg[kGSegMax];
+    uint32_t n_gseg;
     // window of the contig the head is in, kept in LDS while everything right of the head is
     // untouched: the two bitmaps thread 0 scans and the bases a site's window is cut from
     unsigned long long c_site[kCacheWords], c_ok[kCacheWords];
@@ -652,24 +658,94 @@ __device__ void make_edit(const Ctx& c, Shared& S, uint8_t draft, Best& b)
     }
 }
 
-// gather up to `want` chars of the edited sequence starting at the head cursor
-__device__ uint32_t gather(const Ctx& c, const Shared& S, uint8_t* z, uint32_t want)
+// Up to `want` chars of the edited sequence starting at the head cursor, a NODE at a time
+// (thread 0): inserted bases go straight into z, runs of untouched contig are left as segments for
+// every lane to copy (gather_fill, after a barrier).  Char by char -- a node look-up and a
+// sequence byte from memory, one behind the other, for each of 2k + 12 chars -- this was most of
+// the 89 us of a site worked out on the spot (head among edited nodes) and of the walk.  Returns
+// the number of chars, exactly as the char-by-char loop of get_char / increment would.
+__device__ uint32_t gather_plan(const Ctx& c, Shared& S, uint8_t* z, uint32_t want)
 {
-    uint32_t pos = S.hi, ni = S.hn, n = 0;
+    uint32_t pos = S.hi, ni = S.hn, n = 0, ns = 0;
     while (n < want) {
         if (pos >= c.len || ni >= S.nn)
             break;
-        Node nd = c.nd[ni];
-        if (nd.type == -1) {
+        const Node nd = c.nd[ni];
+        if (nd.type == 0) {
+            // as many chars as the run still holds (one if the cursor stands past its end: the
+            // reference reads the base under the cursor before it looks at the run)
+            uint32_t take = pos <= nd.e ? nd.e - pos + 1 : 1u;
+            take = min(take, min(want - n, c.len - pos));
+            if (ns < (uint32_t)kGSegMax) {
+                S.gseg[ns].z0 = n;
+                S.gseg[ns].pos = pos;
+                S.gseg[ns].cnt = take;
+                ns++;
+            } else {
+                for (uint32_t i = 0; i < take; i++)
+                    z[n + i] = c.seq[pos + i];
+            }
+            n += take;
+            pos += take;
+            if (pos > nd.e) { // the cursor left the run: where increment() would have put it
+                ni++;
+                if (ni < S.nn && c.nd[ni].type == 0)
+                    pos = c.nd[ni].s;
+            }
+        } else if (nd.type == 1) {
+            z[n++] = (uint8_t)nd.c;
+            ni++;
+            if (ni < S.nn && c.nd[ni].type == 0)
+                pos = c.nd[ni].s;
+        } else {
             // the reference keeps reading a 0 byte from an unset node without advancing
             while (n < want)
                 z[n++] = 0;
             break;
         }
-        z[n++] = get_char(c, pos, nd);
-        increment(c, S, pos, ni);
     }
+    S.n_gseg = ns;
     return n;
+}
+
+// every lane, after the barrier behind gather_plan; a barrier must follow
+__device__ inline void gather_fill(const Ctx& c, Shared& S, uint8_t* z)
+{
+    const uint32_t ns = S.n_gseg;
+    for (uint32_t g = 0; g < ns; g++) {
+        const uint32_t z0 = S.gseg[g].z0, pos = S.gseg[g].pos, cnt = S.gseg[g].cnt;
+        for (uint32_t i = threadIdx.x; i < cnt; i += kWalkThreads)
+            z[z0 + i] = c.seq[pos + i];
+    }
+}
+
+// `steps` times increment(), a node at a time
+__device__ void advance(const Ctx& c, const Shared& S, uint32_t& pos, uint32_t& ni, uint32_t steps)
+{
+    while (steps) {
+        const Node n = nd_get(c, S, ni);
+        if (n.type == 0) {
+            if (pos < n.e) { // room inside the run
+                const uint32_t m = min(steps, n.e - pos);
+                pos += m;
+                steps -= m;
+                if (!steps)
+                    break;
+            }
+            pos++; // this step leaves the run
+            steps--;
+            ni++;
+            if (ni < S.nn && c.nd[ni].type == 0)
+                pos = c.nd[ni].s;
+        } else if (n.type == 1) {
+            ni++;
+            steps--;
+            if (ni < S.nn && c.nd[ni].type == 0)
+                pos = c.nd[ni].s;
+        } else {
+            break; // an unset node: increment() stands still however often it is called
+        }
+    }
 }
 
 // ------------------------------------------------------------- the kernel
@@ -1279,7 +1355,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                 // scan: current k-mer chars via the cursor, lookahead straight from the contig
                 Node hnode = nd_cached(c, S, S.hn);
                 S.fast_head = (hnode.type == 0 && S.hi + k - 1 <= hnode.e) ? 1u : 0u;
-                uint32_t got = S.fast_head ? k : gather(c, S, S.Z, k);
+                uint32_t got = S.fast_head ? k : gather_plan(c, S, S.Z, k);
                 if (got < k) {
                     S.request = REQ_DONE; // cannot happen while the tail is in range
                 } else {
@@ -1549,6 +1625,8 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             if (S.fast_head)
                 for (uint32_t i = tid; i < k; i += kWalkThreads)
                     S.Z[i] = c.seq[S.hi + i];
+            else
+                gather_fill(c, S, S.Z); // the runs gather_plan left
             for (uint32_t i = k + tid; i < S.nz; i += kWalkThreads)
                 S.Z[i] = c.seq[ti0 + 1 + (i - k)];
             __syncthreads();
@@ -1580,8 +1658,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                     if (hnode.type == 0 && S.hi + dest <= hnode.e) {
                         S.hi += dest;
                     } else {
-                        for (uint32_t s = 0; s < dest; s++)
-                            increment(c, S, S.hi, S.hn);
+                        advance(c, S, S.hi, S.hn, dest);
                     }
                 }
                 S.ti = ti0 + dest;
@@ -1617,7 +1694,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                 S.nz = min(want, hnode.e - S.hi + 1);
             } else {
                 S.fast_head = 0;
-                S.nz = gather(c, S, S.Z, want);
+                S.nz = gather_plan(c, S, S.Z, want);
             }
             S.draft = to_upper((uint8_t)S.char_in);
             S.best_key = 0;
@@ -1630,6 +1707,9 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                 const uint32_t pos = S.hi + i;
                 S.Z[i] = pos - S.cp0 < S.cpn ? S.c_seq[pos - S.cp0] : c.seq[pos];
             }
+            __syncthreads();
+        } else {
+            gather_fill(c, S, S.Z);
             __syncthreads();
         }
         {
