@@ -1,0 +1,260 @@
+"""CPU models of four device-side shortcuts (no GPU, no library): each restates, in a few lines of
+Python, the straightforward procedure and the shortcut a kernel takes instead, and checks that they
+agree on random inputs -- the argument the kernel's comment makes, executed.
+
+1. `kmer_hash_from_table` (goldpolish_amd/csrc/gp_device.h): the ntHash of a k-mer as the XOR of k
+   entries of a table of rotated seeds per strand, against the reference's own values
+   (tests/golden/nthash_kat.json, made with /root/reference's nthash.hpp).
+2. `gather_plan` / `advance` (stage_b.hip): the walker's window and head a node at a time, against
+   the char-by-char get_char / increment loop (ntedit.cpp's node list semantics).
+3. `census_scatter`'s ring (stage_a.hip): records staged in eight LDS slots per range and written in
+   groups of four, against storing every record at its slot.
+4. `census_mark` / `census_pack`: marked records packed into the head of their run and read back up
+   to the first record without the mark, against a flag per touch."""
+import json
+import pathlib
+
+import numpy as np
+
+M64 = (1 << 64) - 1
+SEED = {"A": 0x3c8bfbb395c60474, "C": 0x3193c18562a02b4c, "G": 0x20323ed082572324, "T": 0x295549f54be24456}
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+
+def sroln(x, n):
+    """split rotate: the high 31 and the low 33 bits each rotate left by n (gp_device.h)"""
+    hi, lo = x >> 33, x & 0x1FFFFFFFF
+    a, b = n % 31, n % 33
+    hi = ((hi << a) | (hi >> (31 - a))) & 0x7FFFFFFF
+    lo = ((lo << b) | (lo >> (33 - b))) & 0x1FFFFFFFF
+    return ((hi << 33) | lo) & M64
+
+
+def test_hash_from_rotated_seeds_equals_the_reference_nthash():
+    kat = json.loads((pathlib.Path(__file__).parent / "golden" / "nthash_kat.json").read_text())
+    checked = 0
+    for case in kat:
+        k, seq = case["k"], case["seq"].upper()
+        table = {c: [sroln(SEED[c], j) for j in range(k)] for c in "ACGT"}
+        for p, (fwd, rev) in enumerate(zip(case["fwd"], case["rev"])):
+            kmer = seq[p:p + k]
+            if len(kmer) < k or any(c not in "ACGT" for c in kmer):
+                continue
+            f = r = 0
+            for i, c in enumerate(kmer):
+                f ^= table[c][k - 1 - i]
+                r ^= table[COMP[c]][i]
+            assert f == fwd and r == rev, (k, p)
+            checked += 1
+    assert checked > 100
+
+
+# ---------------------------------------------------------------------------------- walker cursor
+def node_get(nodes, ni):
+    return nodes[ni] if ni < len(nodes) else (-1, 0, 0, 0)
+
+
+def increment(nodes, pos, ni):
+    t, s, e, c = node_get(nodes, ni)
+    if t == 0:
+        pos += 1
+        if pos > e:
+            ni += 1
+            if ni < len(nodes) and nodes[ni][0] == 0:
+                pos = nodes[ni][1]
+    elif t == 1:
+        ni += 1
+        if ni < len(nodes) and nodes[ni][0] == 0:
+            pos = nodes[ni][1]
+    return pos, ni
+
+
+def gather_chars(nodes, seq, pos, ni, want):
+    """stage_b.hip's gather before round 2: one char, one increment at a time"""
+    z = []
+    while len(z) < want:
+        if pos >= len(seq) or ni >= len(nodes):
+            break
+        t, s, e, c = nodes[ni]
+        if t == -1:
+            z += [0] * (want - len(z))
+            break
+        z.append(seq[pos] if t == 0 else c)
+        pos, ni = increment(nodes, pos, ni)
+    return z
+
+
+def gather_nodes(nodes, seq, pos, ni, want):
+    """gather_plan + gather_fill"""
+    z = [None] * want
+    n, segs = 0, []
+    while n < want:
+        if pos >= len(seq) or ni >= len(nodes):
+            break
+        t, s, e, c = nodes[ni]
+        if t == 0:
+            take = e - pos + 1 if pos <= e else 1
+            take = min(take, want - n, len(seq) - pos)
+            segs.append((n, pos, take))
+            n += take
+            pos += take
+            if pos > e:
+                ni += 1
+                if ni < len(nodes) and nodes[ni][0] == 0:
+                    pos = nodes[ni][1]
+        elif t == 1:
+            z[n] = c
+            n += 1
+            ni += 1
+            if ni < len(nodes) and nodes[ni][0] == 0:
+                pos = nodes[ni][1]
+        else:
+            while n < want:
+                z[n] = 0
+                n += 1
+            break
+    for z0, p, cnt in segs:
+        for i in range(cnt):
+            z[z0 + i] = seq[p + i]
+    return z[:n]
+
+
+def advance(nodes, pos, ni, steps):
+    while steps:
+        t, s, e, c = node_get(nodes, ni)
+        if t == 0:
+            if pos < e:
+                m = min(steps, e - pos)
+                pos += m
+                steps -= m
+                if not steps:
+                    break
+            pos += 1
+            steps -= 1
+            ni += 1
+            if ni < len(nodes) and nodes[ni][0] == 0:
+                pos = nodes[ni][1]
+        elif t == 1:
+            ni += 1
+            steps -= 1
+            if ni < len(nodes) and nodes[ni][0] == 0:
+                pos = nodes[ni][1]
+        else:
+            break
+    return pos, ni
+
+
+def random_nodes(rng, n_seq):
+    """a node list as edits leave it: position runs (type 0) with inserted bases (type 1) between
+    them, runs that skip deleted stretches, now and then an unset node (-1) or a run that ends past
+    the sequence"""
+    nodes, pos = [], 0
+    while pos < n_seq and len(nodes) < 30:
+        r = rng.random()
+        if r < 0.55:
+            e = min(n_seq + int(rng.integers(-2, 3)), pos + int(rng.integers(0, 25)))
+            e = max(e, pos)
+            nodes.append((0, pos, e, 0))
+            pos = e + 1 + int(rng.integers(0, 4))        # a deletion now and then
+        elif r < 0.95:
+            nodes.append((1, 0, 0, int(rng.integers(65, 90))))
+        else:
+            nodes.append((-1, 0, 0, 0))
+    return nodes
+
+
+def test_walker_window_and_head_a_node_at_a_time():
+    rng = np.random.default_rng(7)
+    for _ in range(3000):
+        n_seq = int(rng.integers(5, 120))
+        seq = [int(x) for x in rng.integers(97, 123, size=n_seq)]
+        nodes = random_nodes(rng, n_seq)
+        if not nodes:
+            continue
+        ni = int(rng.integers(0, len(nodes)))
+        t, s, e, c = nodes[ni]
+        # a cursor as the walker holds it: inside the run, at times just past its end; for an
+        # inserted base the position is whatever the last run left
+        pos = int(rng.integers(s, e + 2)) if t == 0 else int(rng.integers(0, n_seq + 2))
+        want = int(rng.integers(1, 90))
+        assert gather_nodes(nodes, seq, pos, ni, want) == gather_chars(nodes, seq, pos, ni, want)
+        steps = int(rng.integers(0, 60))
+        p1, n1 = pos, ni
+        for _s in range(steps):
+            p1, n1 = increment(nodes, p1, n1)
+        assert advance(nodes, pos, ni, steps) == (p1, n1)
+
+
+# ---------------------------------------------------------------------------------- scatter ring
+K_RUN = 64
+
+
+def scatter_with_ring(tiles):
+    """tiles: records a range gets in each tile of a stretch.  Returns the run as memory holds it."""
+    mem = [None] * K_RUN
+    ring = [None] * 8
+    hist, gbase = 0, 0
+    for recs in tiles:
+        for r in recs:
+            rank = hist
+            hist += 1
+            if rank >= K_RUN:
+                continue                                 # the pair falls back (overflow)
+            if 0 <= rank - 4 * gbase < 8:
+                ring[rank & 7] = r
+            else:
+                assert mem[rank] is None
+                mem[rank] = r
+        cnt = min(hist, K_RUN)
+        if cnt > 4 * gbase + 8:
+            ng, g_next = 2, (cnt + 3) // 4
+        else:
+            ng = (cnt - 4 * gbase) // 4 if cnt > 4 * gbase else 0
+            g_next = gbase + ng
+        for g in range(gbase, gbase + ng):
+            for i in range(4):
+                assert mem[4 * g + i] is None            # a group is written one way only
+                mem[4 * g + i] = ring[4 * (g & 1) + i]
+        gbase = g_next
+    n = min(hist, K_RUN)
+    for r in range(4 * gbase, n):
+        assert mem[r] is None
+        mem[r] = ring[r & 7]
+    return mem[:n]
+
+
+def test_scatter_ring_leaves_every_record_at_its_slot():
+    rng = np.random.default_rng(11)
+    for _ in range(4000):
+        lam = float(rng.choice([0.5, 3.2, 6.0, 12.0]))
+        tiles, nxt = [], 0
+        for _t in range(8):
+            n = int(rng.poisson(lam))
+            tiles.append(list(range(nxt, nxt + n)))
+            nxt += n
+        want = list(range(min(nxt, K_RUN)))
+        assert scatter_with_ring(tiles) == want
+
+
+# ---------------------------------------------------------------------------------- mark and pack
+def test_marked_records_packed_into_the_run_head():
+    rng = np.random.default_rng(13)
+    for _ in range(3000):
+        cnt = int(rng.integers(0, K_RUN + 1))
+        stale = [int(x) for x in rng.integers(0, 1 << 32, size=K_RUN)]   # an earlier cohort's leftovers
+        recs = [int(x) for x in rng.integers(0, 1 << 29, size=cnt)]      # bit 31 clear: this cohort's records
+        later = [bool(x) for x in rng.integers(0, 2, size=cnt)]
+        run = recs + stale[cnt:]
+        # census_mark: the marked ones to the front, bit 31 set; a zero behind them when all are marked
+        packed = [r | (1 << 31) for r, m in zip(recs, later) if m]
+        for i, r in enumerate(packed):
+            run[i] = r
+        if len(packed) == cnt and cnt < K_RUN:
+            run[cnt] = 0
+        # census_pack: read up to the first record without the bit
+        got = []
+        for r in run:
+            if not r >> 31:
+                break
+            got.append(r & ~(1 << 31))
+        assert got == [r for r, m in zip(recs, later) if m]
