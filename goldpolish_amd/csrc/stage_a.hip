@@ -690,11 +690,12 @@ __global__ __launch_bounds__(kTailThreads) void cbf_tail(AArgs a, TailArgs t)
 // levels >= 1, so it is an ordinary conservative-update replay of the candidates alone with every
 // counter starting at level 1: thresholds one lower on a zero array.  The census finds the
 // candidates without random memory traffic: every counter touch goes as a 4-byte record into
-// the bucket of its counter range (1024 ranges per pair, a run of 64 slots per 6144-position
-// stretch and bucket), a workgroup per bucket takes the earliest position per counter in LDS and
-// marks the touches that are not it, and an operation with all its touches marked is a
-// candidate.  cbf_local then replays a fifth to a third of the operations.  A run that overflows
-// (many copies of one k-mer within a stretch) sends its pair back to the plain replay.
+// the bucket of its counter range (1280 ranges of 8192 counters at 10 MiB, a run of 64 slots per
+// 8192-position stretch and range: census_scatter), a workgroup per range takes the earliest
+// position per counter in LDS and packs the touches that are not it into the head of their run
+// (census_mark), and an operation with all its touches marked is a candidate (census_pack).
+// cbf_local then replays a fifth to a third of the operations.  A run that overflows (many
+// copies of one k-mer within a stretch) sends its pair back to the plain replay.
 constexpr int kCSuper = 8;                // tiles of kTile positions per census_scatter workgroup: an 8192-position stretch
 constexpr uint32_t kCStretch = kCSuper * kTile;
 constexpr uint32_t kCBuckets = 2048;      // most counter ranges per pair (a range is a power of two wide: 1280 of 8192 for 10 MiB)
@@ -1008,7 +1009,10 @@ __global__ __launch_bounds__(256) void census_pack(AArgs a, CensusArgs c)
 // agent-scope release writes the XCD's L2 back.  A round-0 winner has no earlier waiting
 // operation of its tile on any of its counters, so the values loaded for the settle test
 // are still the current ones: in a sparse filter an operation costs its four counter
-// loads and the stores, nothing else.  The kernel is bound by those random line fetches.
+// loads and the stores, nothing else.  (Replaying EVERY operation the kernel is bound by those
+// random line fetches; replaying the census's candidates it was bound by hashing them from
+// scratch and by one memory round trip behind the other, until the seed table, the settled
+// table and the merged loads below: DESIGN.md section 4.)
 // A fresh counting filter for the pair a cbf_local workgroup takes next.  The slot is that
 // workgroup's alone; its stores are visible to its own waves after the next workgroup barrier
 // (one CU, one L1).  Kept out of line, and the statistics flushed per pair: inlined, or with
