@@ -45,6 +45,11 @@ WORKLOADS = {
     "goldenpath": ([25_000] * 400, 30, [32, 28, 24, 20],
                    "10 Mbp as 400 x 25 kbp contigs + 30x reads, k=32,28,24,20"),
     "tiny": ([200_000], 30, [32], "one 200 kbp contig + 30x reads, k=32"),
+    # one rank's share of BASELINE.json configs[3] (3 Gbp over 8 GPUs) in GoldPolish's normal
+    # batch regime: more than 2^32 read positions and 60 000 (batch, k) pairs in one job
+    "config4share": ([25_000] * 15000, 30, [32, 28, 24, 20],
+                     "a rank's share of BASELINE.json configs[3]: 375 Mbp (15000 x 25 kbp contigs, one per "
+                     "batch) + 30x ONT-error reads, k=32,28,24,20, bsize=1"),
 }
 
 
