@@ -881,7 +881,8 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
 // A wave takes a stretch's run at a time (256 bytes of record slots, as many lanes as it
 // holds); the runs' lengths are fetched once, the records once (kept in registers between the
 // two passes when the bucket has no more than kKeep runs per wave).
-__global__ __launch_bounds__(256) void census_mark(CensusArgs c)
+constexpr int kMarkBlock = 512, kMarkWaves = kMarkBlock / 64; // eight waves share a range's table: 32 waves per CU at 10 MiB
+__global__ __launch_bounds__(kMarkBlock, 8) void census_mark(CensusArgs c)
 {
     extern __shared__ uint32_t first_t[]; // a word per counter of the range (32 KB at GoldPolish's 10 MiB), then the run lengths
     const uint32_t pair = blockIdx.x / c.n_buckets, bucket = blockIdx.x % c.n_buckets;
@@ -892,25 +893,25 @@ __global__ __launch_bounds__(256) void census_mark(CensusArgs c)
     uint32_t* const rec = c.rec + c.pair_rec_off[pair] + (uint64_t)bucket * nst * kCRun;
     const uint8_t* cnt = c.cnt + c.pair_cnt_off[pair] + (uint64_t)bucket * nst;
     uint8_t* const s_cnt = reinterpret_cast<uint8_t*>(first_t + bucket_w);
-    for (uint32_t i = threadIdx.x; i < bucket_w; i += 256)
+    for (uint32_t i = threadIdx.x; i < bucket_w; i += kMarkBlock)
         first_t[i] = 0xFFFFFFFFu;
-    for (uint32_t i = threadIdx.x; i < nst; i += 256)
+    for (uint32_t i = threadIdx.x; i < nst; i += kMarkBlock)
         s_cnt[i] = cnt[i];
     __syncthreads();
-    constexpr int kKeep = 32; // 128 runs: a pair of a million positions
+    constexpr int kKeep = 128 / kMarkWaves; // 128 runs: a pair of a million positions
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t keep[kKeep];
 #pragma unroll
     for (int q = 0; q < kKeep; q++) {
-        const uint32_t st = wave + 4u * (uint32_t)q;
+        const uint32_t st = wave + (uint32_t)kMarkWaves * (uint32_t)q;
         keep[q] = (st < nst && lane < s_cnt[st]) ? rec[(uint64_t)st * kCRun + lane] : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int q = 0; q < kKeep; q++)
         if (keep[q] != 0xFFFFFFFFu)
-            atomicMin(&first_t[(keep[q] >> 2) & 0x3FFFu], (wave + 4u * (uint32_t)q) * kCStretch + (keep[q] >> 16));
+            atomicMin(&first_t[(keep[q] >> 2) & 0x3FFFu], (wave + (uint32_t)kMarkWaves * (uint32_t)q) * kCStretch + (keep[q] >> 16));
 #pragma unroll 4
-    for (uint32_t st = wave + 4u * kKeep; st < nst; st += 4)
+    for (uint32_t st = wave + (uint32_t)kMarkWaves * kKeep; st < nst; st += kMarkWaves)
         if (lane < s_cnt[st]) {
             const uint32_t r = rec[(uint64_t)st * kCRun + lane];
             atomicMin(&first_t[(r >> 2) & 0x3FFFu], st * kCStretch + (r >> 16));
@@ -935,11 +936,11 @@ __global__ __launch_bounds__(256) void census_mark(CensusArgs c)
     };
 #pragma unroll
     for (int q = 0; q < kKeep; q++) {
-        const uint32_t st = wave + 4u * (uint32_t)q;
+        const uint32_t st = wave + (uint32_t)kMarkWaves * (uint32_t)q;
         if (st < nst)
             mark(keep[q], keep[q] != 0xFFFFFFFFu, st);
     }
-    for (uint32_t st = wave + 4u * kKeep; st < nst; st += 4) {
+    for (uint32_t st = wave + (uint32_t)kMarkWaves * kKeep; st < nst; st += kMarkWaves) {
         const bool valid = lane < s_cnt[st];
         mark(valid ? rec[(uint64_t)st * kCRun + lane] : 0u, valid, st);
     }
@@ -1949,7 +1950,7 @@ int stage_a_run(gp_job* job)
                         for (uint32_t x : co.pair_nst)
                             max_nst = std::max(max_nst, x);
                         const size_t lds = ((size_t)sizeof(uint32_t) << bucket_shift) + (max_nst + 3) / 4 * 4;
-                        hipLaunchKernelGGL(census_mark, dim3((unsigned)(np * n_buckets)), dim3(256), lds, sm, c);
+                        hipLaunchKernelGGL(census_mark, dim3((unsigned)(np * n_buckets)), dim3(kMarkBlock), lds, sm, c);
                     }
                     hipLaunchKernelGGL(census_pack, dim3((unsigned)nw), dim3(256), 0, sm, a, c);
                     GP_HIP(hipGetLastError());
