@@ -45,10 +45,10 @@ constexpr uint32_t kPathCap = 1024;          // vertices per stored path
 // lane-per-gap first attempt: a small private arena per lane; what outgrows it, or finds paths
 // to enumerate, is done again by the one-gap-per-wave workers with their big arenas
 constexpr uint32_t kSmallSlotBits = 8, kSmallVerts = 96, kSmallEdges = 256;
-constexpr uint32_t kSimtWaves = 2048;   // waves of the lane-per-gap kernel ...
+constexpr uint32_t kSimtWaves = 3072;   // waves of the lane-per-gap kernel (three per SIMD is what its registers allow) ...
 constexpr uint32_t kSimtLanes = 32;     // ... and the lanes of each that take a gap (divergent walks serialise)
 constexpr uint32_t kNwMax = 1800;            // longest sequence the consensus aligner takes
-constexpr uint32_t kMaxWorkers = 2048;  // one-wave workers of sealer_connect, 13 MB of arena each (CState::n_workers: by job size)
+constexpr uint32_t kMaxWorkers = 3072;  // one-wave workers of sealer_connect, 13 MB of arena each (CState::n_workers: by job size)
 constexpr int kNwWorkers = 16;
 
 enum { FWD = 0, REV = 1 };
@@ -107,7 +107,7 @@ struct CState {
     DevBuf<uint32_t> epoch;        // per worker
     std::vector<uint32_t> h_gap_off;
     uint32_t gap_cap = 0, table_bits = 0, multi_cap = 0;
-    uint32_t n_workers = 0;        // sealer_connect's grid: 1024 took 0.15 s per configs[2] step, 2048 take 0.10 s
+    uint32_t n_workers = 0;        // sealer_connect's grid: 1024 took 0.15 s per configs[2] step, 2048 0.10 s, 3072 (three waves per SIMD: what its registers allow) 0.08 s
     uint64_t pool_cap = 0;
 };
 
@@ -1421,7 +1421,7 @@ int stage_c_prepare(gp_job* job)
     c->table_bits = tb;
     c->multi_cap = (uint32_t)std::min<uint64_t>(g, 1u << 20);
     c->pool_cap = 2 * total_len + (16ull << 20);
-    // a worker per 4 kbp of contigs, 256 at least (3 GiB of arenas), kMaxWorkers (26 GiB) from 8 Mbp on
+    // a worker per 4 kbp of contigs, 256 at least (3 GiB of arenas), kMaxWorkers (39 GiB) from 12 Mbp on
     c->n_workers = (uint32_t)std::min<uint64_t>(
         kMaxWorkers, std::max<uint64_t>(256, env_u64("GP_SEALER_WORKERS", total_len / 4096)));
     const uint64_t n_workers = c->n_workers;
