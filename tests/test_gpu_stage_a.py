@@ -216,6 +216,17 @@ def test_census_cohorts_and_bucket_overflow(gp, oracle, monkeypatch):
     run_and_compare(core, ctx, oracle, w2, core.default_params(k_values=[32, 20]), batch_contig_begin=[0, 2, 3])
 
 
+def test_census_pair_with_more_runs_than_a_wave_keeps(gp, oracle, stage_a_path):
+    """a pair of more than 128 stretches (1 Mi read positions): census_mark keeps the records of
+    128 runs per range in registers and fetches the rest again in both its passes"""
+    if stage_a_path != "census":
+        pytest.skip("the census schedule only")
+    core, ctx = gp
+    w = synth.make_workload([32000, 9000], 45, seed=31, s_per_10kbp=60.0)
+    assert int(w.read_off[int(w.contig_read_begin[1])]) > 129 * 8192
+    run_and_compare(core, ctx, oracle, w, core.default_params(k_values=[32, 20]))
+
+
 def test_threshold_below_4_is_refused(gp):
     core, ctx = gp
     w = _custom_workload([b"ACGT" * 100], [[b"ACGT" * 100]], [3])
