@@ -1099,9 +1099,10 @@ __device__ inline uint32_t select64(unsigned long long w, uint32_t r)
     return pos + (r >= (lo & 1u) ? 1u : 0u);
 }
 
-constexpr int kLTile = 512;            // positions per tile: with the 32 KB table four workgroups share a CU,
-constexpr int kLPer = 2;               // each in another phase (hash / load / order / store); 1024-position
-constexpr int kLBlock = kLTile / kLPer; // tiles with a 64 KB table (two workgroups per CU) ran 5 % slower
+constexpr int kLTile = 512;            // operations per turn (positions of a tile, or candidates of a window)
+constexpr int kLPer = 1;               // ... one per lane: 512-thread workgroups, two per CU (32 KB table + 16 KB filter each),
+constexpr int kLBlock = kLTile / kLPer; // at 128 registers 16 waves per CU.  (Two operations per lane in 256-thread
+                                        // workgroups -- 8 waves per CU -- took 0.54 s for configs[2]'s replay, this 0.48 s.)
 constexpr int kLWin = 2048;            // census pairs: positions whose candidates are gathered at a time
 constexpr int kLocalSlotBits = 12;
 constexpr int kLocalSlots = 1 << kLocalSlotBits; // >= 2 x the counter touches of a tile (hash_num <= 4)
@@ -1115,7 +1116,7 @@ __device__ inline void kset_put(unsigned long long* kset, uint32_t* s_kbits, uin
     atomicOr(&s_kbits[kb >> 5], 1u << (kb & 31u));
 }
 
-__global__ __launch_bounds__(kLBlock) void cbf_local(AArgs a, uint32_t first, uint32_t n_pairs) // 4 workgroups per CU: <= 128 VGPRs
+__global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first, uint32_t n_pairs) // two 8-wave workgroups per CU: <= 128 VGPRs
 {
     __shared__ uint8_t codes[kLWin + kHalo];
     __shared__ uint64_t seed_t[kSeedTableWords];
