@@ -19,10 +19,10 @@ def newest(pattern):
     return files[-1:]
 
 
-for name in ("config3", "config2", "goldenpath", "probe"):
+for name in ("config3", "config2", "probe"):
     for f in newest(str(raw / f"{name}_trace" / "*" / "*kernel_stats.csv")):
         shutil.copy(f, out / f"{rnd}_{name}_kernel_stats.csv")
-for name in ("config3", "config2", "goldenpath", "probe"):
+for name in ("config3", "config2", "probe"):
     traffic = {}
     for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         for f in newest(str(raw / f"{name}_{kind}" / "*" / "*counter_collection.csv")):
