@@ -34,6 +34,7 @@ SYMBOLS = [
     "gp_mappings_load", "gp_mappings_get", "gp_mappings_destroy", "gp_job_create_from_files",
     "gp_target_extract", "gp_target_update_paf", "gp_target_reinsert",
     "gp_jobs_polish", "gp_filter_save", "gp_filter_save_btllib", "gp_filter_load", "gp_job_write_fasta",
+    "gp_sealer_consensus",
 ]
 
 
@@ -162,6 +163,7 @@ def load_library(path=None):
     L.gp_filter_save.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64, u8p]
     L.gp_filter_save_btllib.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64, u8p]
     L.gp_filter_load.argtypes = [C.c_char_p, u32p, u32p, u64p, u8p, C.c_uint64]
+    L.gp_sealer_consensus.argtypes = [C.c_void_p, C.c_uint32, u32p, u8p, u64p, u8p, C.c_uint64, u32p]
     return L
 
 
@@ -241,6 +243,23 @@ class Context:
 
     def __exit__(self, *a):
         self.close()
+
+
+def sealer_consensus(ctx, sets):
+    """align() of Sealer (alignGlobal.h:73-83) for every set of connecting sequences, on the device."""
+    flat = [_bytes(q) for st in sets for q in st]
+    begin = np.zeros(len(sets) + 1, dtype=np.uint32)
+    begin[1:] = np.cumsum([len(st) for st in sets])
+    off = np.zeros(len(flat) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(q) for q in flat])
+    buf = np.frombuffer(b"".join(flat) or b"\0", dtype=np.uint8).copy()
+    stride = max([sum(len(_bytes(q)) for q in st) for st in sets] + [1])
+    out = np.zeros(len(sets) * stride, dtype=np.uint8)
+    out_len = np.zeros(len(sets), dtype=np.uint32)
+    _check(lib().gp_sealer_consensus(ctx._h, len(sets), begin.ctypes.data_as(u32p), buf.ctypes.data_as(u8p),
+                                     off.ctypes.data_as(u64p), out.ctypes.data_as(u8p), stride,
+                                     out_len.ctypes.data_as(u32p)))
+    return [out[i * stride:i * stride + int(out_len[i])].tobytes() for i in range(len(sets))]
 
 
 def _arr(a, dtype):

@@ -558,6 +558,33 @@ try {
     return finish(job, stage_upper(job), sync);
 } GP_CATCH("gp_job_upper")
 
+int gp_sealer_consensus(gp_ctx* ctx, uint32_t n_sets, const uint32_t* set_seq_begin, const uint8_t* seq_buf,
+                        const uint64_t* seq_off, uint8_t* out_buf, uint64_t out_stride, uint32_t* out_len)
+try {
+    if (!ctx || !set_seq_begin || !seq_buf || !seq_off || !out_buf || !out_len) {
+        set_error("gp_sealer_consensus: NULL argument");
+        return GP_ERR_INVALID_ARG;
+    }
+    if (n_sets == 0)
+        return GP_OK;
+    for (uint32_t i = 0; i < n_sets; i++)
+        if (set_seq_begin[i + 1] < set_seq_begin[i]) {
+            set_error("gp_sealer_consensus: set_seq_begin must not decrease");
+            return GP_ERR_INVALID_ARG;
+        }
+    for (uint32_t q = set_seq_begin[0]; q < set_seq_begin[n_sets]; q++)
+        if (seq_off[q + 1] < seq_off[q]) {
+            set_error("gp_sealer_consensus: seq_off must not decrease");
+            return GP_ERR_INVALID_ARG;
+        }
+    if (set_seq_begin[0] != 0) {
+        set_error("gp_sealer_consensus: set_seq_begin[0] must be 0");
+        return GP_ERR_INVALID_ARG;
+    }
+    GP_HIP(hipSetDevice(ctx->device));
+    return sealer_consensus_sets(ctx, n_sets, set_seq_begin, seq_buf, seq_off, out_buf, out_stride, out_len);
+} GP_CATCH("gp_sealer_consensus")
+
 // everything behind the filter build: ntEdit cascade + guard, mask, Sealer, upper
 static int polish_back(gp_job* job)
 {

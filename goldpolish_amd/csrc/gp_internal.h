@@ -187,6 +187,8 @@ int stage_b_guard(gp_job* job);
 int stage_mask(gp_job* job);
 int stage_c_run(gp_job* job);
 int stage_upper(gp_job* job);
+int sealer_consensus_sets(gp_ctx* ctx, uint32_t n_sets, const uint32_t* set_seq_begin, const uint8_t* seq_buf,
+                          const uint64_t* seq_off, uint8_t* out_buf, uint64_t out_stride, uint32_t* out_len);
 int stage_lengths(gp_job* job, uint64_t* lengths, uint8_t* dropped, uint64_t* total);
 int stage_sequences(gp_job* job, uint8_t* buf, uint64_t buf_bytes);
 int stage_sequences_device(gp_job* job, void* d_buf, uint64_t buf_bytes);

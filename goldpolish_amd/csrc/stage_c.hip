@@ -1288,6 +1288,118 @@ __global__ __launch_bounds__(64) void sealer_consensus(CArgs a)
     }
 }
 
+// align() alone, over caller-supplied sets of connecting sequences (gp_sealer_consensus): the
+// same worker layout and the same nw_consensus as sealer_consensus above
+__global__ __launch_bounds__(64) void consensus_sets(const uint8_t* seq, const uint64_t* seq_off,
+                                                     const uint32_t* set_begin, uint32_t n_sets, int32_t* nw,
+                                                     uint32_t* head, uint8_t* out, uint32_t* out_len,
+                                                     uint32_t* err)
+{
+    __shared__ NwLds L;
+    __shared__ uint32_t item;
+    const uint32_t wid = blockIdx.x, lane = threadIdx.x;
+    const uint64_t mat_words = 3ull * (kNwMax + 1) * (kNwMax + 1);
+    const uint64_t stride = mat_words + 2 * (2 * kNwMax + 64) / 4 + 64;
+    const uint32_t out_stride = 2 * kNwMax + 64;
+    int32_t* mat = nw + (uint64_t)wid * stride;
+    uint8_t* bufA = (uint8_t*)(mat + mat_words);
+    uint8_t* bufB = bufA + 2 * kNwMax + 64;
+    for (;;) {
+        if (lane == 0)
+            item = atomicAdd(head, 1u);
+        __syncthreads();
+        const uint32_t it = item;
+        __syncthreads();
+        if (it >= n_sets)
+            break;
+        const uint32_t s0 = set_begin[it], s1 = set_begin[it + 1];
+        bool ok = s1 - s0 >= 2;
+        for (uint32_t p = s0; p < s1; p++)
+            ok &= seq_off[p + 1] - seq_off[p] <= kNwMax && seq_off[p + 1] > seq_off[p];
+        if (!ok) { // (uniform)
+            if (lane == 0) {
+                atomicOr(err, 256u);
+                out_len[it] = 0;
+            }
+            continue;
+        }
+        uint32_t lc = nw_consensus(L, seq + seq_off[s0], (uint32_t)(seq_off[s0 + 1] - seq_off[s0]),
+                                   seq + seq_off[s0 + 1], (uint32_t)(seq_off[s0 + 2] - seq_off[s0 + 1]), mat, bufA);
+        uint8_t* cur = bufA;
+        uint8_t* nxt = bufB;
+        for (uint32_t p = s0 + 2; p < s1 && ok; p++) {
+            if (lc > kNwMax) {
+                ok = false;
+                break;
+            }
+            lc = nw_consensus(L, cur, lc, seq + seq_off[p], (uint32_t)(seq_off[p + 1] - seq_off[p]), mat, nxt);
+            uint8_t* t = cur;
+            cur = nxt;
+            nxt = t;
+        }
+        if (!ok) {
+            if (lane == 0) {
+                atomicOr(err, 256u);
+                out_len[it] = 0;
+            }
+            continue;
+        }
+        for (uint32_t i = lane; i < lc; i += 64)
+            out[(uint64_t)it * out_stride + i] = cur[i];
+        if (lane == 0)
+            out_len[it] = lc;
+    }
+}
+
+int sealer_consensus_sets(gp_ctx* ctx, uint32_t n_sets, const uint32_t* set_seq_begin, const uint8_t* seq_buf,
+                          const uint64_t* seq_off, uint8_t* out_buf, uint64_t out_stride, uint32_t* out_len)
+{
+    const uint32_t n_seqs = set_seq_begin[n_sets];
+    const uint64_t bytes = seq_off[n_seqs];
+    const uint32_t dev_stride = 2 * kNwMax + 64;
+    const uint32_t workers = std::min<uint32_t>(kNwWorkers, std::max<uint32_t>(1u, n_sets));
+    DevBuf<uint8_t> d_seq, d_out;
+    DevBuf<uint64_t> d_off;
+    DevBuf<uint32_t> d_begin, d_len, d_misc;
+    DevBuf<int32_t> d_nw;
+    int rc;
+    if ((rc = d_seq.alloc(bytes)) != GP_OK || (rc = d_off.alloc((size_t)n_seqs + 1)) != GP_OK ||
+        (rc = d_begin.alloc((size_t)n_sets + 1)) != GP_OK || (rc = d_len.alloc(n_sets)) != GP_OK ||
+        (rc = d_out.alloc((uint64_t)n_sets * dev_stride)) != GP_OK || (rc = d_misc.alloc(2)) != GP_OK ||
+        (rc = d_nw.alloc((uint64_t)workers *
+                         (3ull * (kNwMax + 1) * (kNwMax + 1) + 2 * (2 * kNwMax + 64) / 4 + 64))) != GP_OK)
+        return rc;
+    hipStream_t s = ctx->stream;
+    GP_HIP(hipMemcpyAsync(d_seq.p, seq_buf, bytes, hipMemcpyHostToDevice, s));
+    GP_HIP(hipMemcpyAsync(d_off.p, seq_off, ((size_t)n_seqs + 1) * 8, hipMemcpyHostToDevice, s));
+    GP_HIP(hipMemcpyAsync(d_begin.p, set_seq_begin, ((size_t)n_sets + 1) * 4, hipMemcpyHostToDevice, s));
+    GP_HIP(hipMemsetAsync(d_misc.p, 0, 8, s));
+    hipLaunchKernelGGL(consensus_sets, dim3(workers), dim3(64), 0, s, d_seq.p, d_off.p, d_begin.p, n_sets, d_nw.p,
+                       d_misc.p, d_out.p, d_len.p, d_misc.p + 1);
+    GP_HIP(hipGetLastError());
+    std::vector<uint32_t> h_len(n_sets);
+    std::vector<uint8_t> h_out((size_t)n_sets * dev_stride);
+    uint32_t h_misc[2] = { 0, 0 };
+    GP_HIP(hipMemcpyAsync(h_len.data(), d_len.p, (size_t)n_sets * 4, hipMemcpyDeviceToHost, s));
+    GP_HIP(hipMemcpyAsync(h_out.data(), d_out.p, h_out.size(), hipMemcpyDeviceToHost, s));
+    GP_HIP(hipMemcpyAsync(h_misc, d_misc.p, 8, hipMemcpyDeviceToHost, s));
+    GP_HIP(hipStreamSynchronize(s));
+    if (h_misc[1]) {
+        set_error("gp_sealer_consensus: a set with fewer than two sequences, an empty sequence, or a sequence / "
+                  "running consensus longer than " + std::to_string(kNwMax) + " bases");
+        return GP_ERR_UNSUPPORTED;
+    }
+    for (uint32_t i = 0; i < n_sets; i++) {
+        if (h_len[i] > out_stride) {
+            set_error("gp_sealer_consensus: out_stride is smaller than a consensus");
+            return GP_ERR_INVALID_ARG;
+        }
+        std::memcpy(out_buf + (uint64_t)i * out_stride, h_out.data() + (size_t)i * dev_stride, h_len[i]);
+        out_len[i] = h_len[i];
+    }
+    return GP_OK;
+}
+
 // --------------------------------------------------------------- splicing
 constexpr int kApplyThreads = 256;
 

@@ -186,6 +186,20 @@ int gp_job_sealer(gp_job* job, int sync);                 /* stage C */
 int gp_job_upper(gp_job* job, int sync);
 int gp_job_sync(gp_job* job);
 
+/* Sealer's consensus step alone: align() of subprojects/sealer/Align/alignGlobal.h:73-83 (alignPair
+ * for two connecting sequences, alignMulti's left fold for more; the Gotoh aligner and its
+ * ambiguity-code consensus of Align/alignGlobal.cc:28-198, Common/Sequence.h:97-106) as
+ * Konnector/konnector.h:393 calls it for a gap with several paths -- run by the same device code
+ * stage C uses (sealer_consensus), so that it can be checked against vectors made from the
+ * reference's own aligner (tests/golden/nw_kat.json).  Set s holds sequences
+ * [set_seq_begin[s], set_seq_begin[s+1]) (two at least), sequence q the bytes
+ * seq_buf[seq_off[q] .. seq_off[q+1]); its consensus goes to out_buf + s * out_stride,
+ * out_len[s] bytes.  Sequences and running consensus are limited to 1800 bases (a connecting
+ * sequence is at most -G + 2 * -L = 864): longer ones give GP_ERR_UNSUPPORTED. */
+int gp_sealer_consensus(gp_ctx* ctx, uint32_t n_sets, const uint32_t* set_seq_begin,
+                        const uint8_t* seq_buf, const uint64_t* seq_off, uint8_t* out_buf,
+                        uint64_t out_stride, uint32_t* out_len);
+
 /* ---- results (device -> host copies) ------------------------------------ */
 /* Bloom filter of batch b for k[k_index]: bf_bytes bytes into out. */
 int gp_job_get_filter(gp_job* job, uint32_t batch, uint32_t k_index, uint8_t* out);

@@ -131,6 +131,14 @@ size_t gpo_sealer_record(const char* seq, size_t len, unsigned nk, const unsigne
                          const uint8_t* const* bfs, size_t bf_bytes, unsigned hash_num,
                          const gpo_sealer_params* p, char* out, gpo_sealer_stats* st);
 
+/* Sealer's consensus step alone (Align/alignGlobal.cc:55-198, alignGlobal.h:44-83,
+ * Common/Sequence.cpp:21-57,141-204): pinned by tests/golden/nw_kat.json.  out of
+ * gpo_nw_consensus needs la + lb + 1 bytes, of gpo_align_multi sum(lens) + 1. */
+size_t gpo_nw_consensus(const char* a, size_t la, const char* b, size_t lb, char* out, unsigned* matches);
+size_t gpo_align_multi(unsigned n, const char* const* seqs, const size_t* lens, char* out, unsigned* matches);
+void gpo_revcomp(const char* s, size_t n, char* out);
+char gpo_amb_or(char a, char b);
+
 /* ------------------------------------------------------ whole batch (A->C) */
 typedef struct {
     unsigned nk;

@@ -649,6 +649,41 @@ static char* nw_consensus(const char* A, size_t la, const char* B, size_t lb, un
     return cons;
 }
 
+/* exported for the known-answer tests (tests/golden/nw_kat.json, made from the reference's own
+ * alignGlobal.cc + Sequence.cpp by oracle/_ref/align_ref) */
+size_t gpo_nw_consensus(const char* a, size_t la, const char* b, size_t lb, char* out, unsigned* matches)
+{
+    char* c = nw_consensus(a, la, b, lb, matches);
+    size_t n = strlen(c);
+    memcpy(out, c, n + 1);
+    free(c);
+    return n;
+}
+
+/* align() of Align/alignGlobal.h:73-83: alignPair for two sequences, alignMulti's left fold for
+ * more (whose `matches = min(0, ...)` is always 0, :64-67) -- what connect_pairs() below does with
+ * the connecting sequences.  out needs sum(lens) + 1 bytes. */
+size_t gpo_align_multi(unsigned n, const char* const* seqs, const size_t* lens, char* out, unsigned* matches)
+{
+    unsigned m = 0;
+    char* cons = nw_consensus(seqs[0], lens[0], seqs[1], lens[1], &m);
+    for (unsigned i = 2; i < n; i++) {
+        char* nx = nw_consensus(cons, strlen(cons), seqs[i], lens[i], &m);
+        free(cons);
+        cons = nx;
+    }
+    if (n > 2)
+        m = 0;
+    size_t l = strlen(cons);
+    memcpy(out, cons, l + 1);
+    free(cons);
+    *matches = m;
+    return l;
+}
+
+void gpo_revcomp(const char* s, size_t n, char* out) { revcomp(s, n, out); }
+char gpo_amb_or(char a, char b) { return amb_or(a, b); }
+
 /* ----------------------------------------------------------- connectPairs */
 /* read1 = upper(left flank), read2 = revcomp(upper(right flank)).  On success
  * returns the merged sequence (malloc'd), else NULL; *why = PathSearchResult or

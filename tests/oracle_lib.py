@@ -104,6 +104,15 @@ class Oracle:
             u32p, C.POINTER(C.c_char_p), u64p, u32p, C.POINTER(C.c_void_p), u64p,
             C.POINTER(u8p), C.POINTER(BatchStats)]
         L.gpo_free.argtypes = [C.c_void_p]
+        L.gpo_nw_consensus.restype = C.c_size_t
+        L.gpo_nw_consensus.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p,
+                                       C.POINTER(C.c_uint)]
+        L.gpo_align_multi.restype = C.c_size_t
+        L.gpo_align_multi.argtypes = [C.c_uint, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t),
+                                      C.c_char_p, C.POINTER(C.c_uint)]
+        L.gpo_revcomp.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+        L.gpo_amb_or.restype = C.c_char
+        L.gpo_amb_or.argtypes = [C.c_char, C.c_char]
         L.gpo_polish_batches.restype = C.c_int
         L.gpo_polish_batches.argtypes = [
             C.POINTER(BatchParams), C.c_uint, u32p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
@@ -197,6 +206,33 @@ class Oracle:
         n = self.L.gpo_sealer_record(seq, len(seq), nk, ks, pb, bfs[0].size, hash_num,
                                      C.byref(p), out, C.byref(st))
         return out.raw[:n], st
+
+    # ---- Sealer's consensus step alone
+    def nw_consensus(self, a, b):
+        a, b = _b(a), _b(b)
+        out = C.create_string_buffer(len(a) + len(b) + 2)
+        m = C.c_uint(0)
+        n = self.L.gpo_nw_consensus(a, len(a), b, len(b), out, C.byref(m))
+        return out.raw[:n], m.value
+
+    def align_multi(self, seqs):
+        seqs = [_b(s) for s in seqs]
+        n = len(seqs)
+        cs = (C.c_char_p * n)(*seqs)
+        ln = (C.c_size_t * n)(*[len(s) for s in seqs])
+        out = C.create_string_buffer(sum(len(s) for s in seqs) + 2)
+        m = C.c_uint(0)
+        k = self.L.gpo_align_multi(n, cs, ln, out, C.byref(m))
+        return out.raw[:k], m.value
+
+    def revcomp(self, s):
+        s = _b(s)
+        out = C.create_string_buffer(len(s) + 1)
+        self.L.gpo_revcomp(s, len(s), out)
+        return out.raw[:len(s)]
+
+    def amb_or(self, a, b):
+        return self.L.gpo_amb_or(_b(a), _b(b))
 
     # ---- whole batch
     def batch_params(self, k_values=(32, 28, 24, 20), **kw):
