@@ -677,18 +677,29 @@ try {
         uint32_t built = 0;
         std::thread front([&] {
             for (uint32_t i = 0; i < n_jobs; i++) {
-                int r = need_bc(jobs[i], "gp_jobs_polish");
-                if (r == GP_OK && hipSetDevice(jobs[i]->ctx->device) != hipSuccess) {
-                    set_error("gp_jobs_polish: hipSetDevice failed");
-                    r = GP_ERR_HIP;
-                }
-                if (r == GP_OK) {
-                    jobs[i]->ctx->stream = front_stream;
-                    r = stage_a_run(jobs[i]); // returns with the filters complete
+                // nothing may leave this thread function (std::terminate would take the host
+                // process down) and `built` must be published whatever happens, or the other
+                // thread waits for ever
+                int r;
+                try {
+                    r = need_bc(jobs[i], "gp_jobs_polish");
+                    if (r == GP_OK && hipSetDevice(jobs[i]->ctx->device) != hipSuccess) {
+                        set_error("gp_jobs_polish: hipSetDevice failed");
+                        r = GP_ERR_HIP;
+                    }
+                    if (r == GP_OK) {
+                        jobs[i]->ctx->stream = front_stream;
+                        r = stage_a_run(jobs[i]); // returns with the filters complete (both its streams drained)
+                    }
+                } catch (...) {
+                    r = on_exception("gp_jobs_polish (filter build)");
                 }
                 if (r != GP_OK) {
                     rc[i] = r;
-                    msg[i] = gp_last_error();
+                    try {
+                        msg[i] = gp_last_error();
+                    } catch (...) {
+                    }
                 }
                 {
                     std::lock_guard<std::mutex> g(mu);
@@ -697,6 +708,16 @@ try {
                 cv.notify_all();
             }
         });
+        // joined on every way out of this scope, a throw from the loop below included (a joinable
+        // std::thread's destructor terminates the process)
+        struct Joiner {
+            std::thread& t;
+            ~Joiner()
+            {
+                if (t.joinable())
+                    t.join();
+            }
+        } joiner{ front };
         for (uint32_t i = 0; i < n_jobs; i++) {
             {
                 std::unique_lock<std::mutex> g(mu);
@@ -714,7 +735,6 @@ try {
             }
             jobs[i]->ctx->stream = own[i];
         }
-        front.join();
     }
     for (uint32_t i = 0; i < n_jobs; i++)
         if (rc[i] != GP_OK) {

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 struct gp_seqindex {
@@ -729,7 +730,14 @@ try {
     // GoldPolish polishes in /dev/shm, where "no space left" is the usual failure: every write is
     // checked, and a file that could not be written whole is put back to what it was before
     // (a new file is removed, an appended one cut back), so that no truncated batch is collected
-    const long before = append ? std::ftell(f) : 0;
+    // (the size of the file, not ftell(): the position of a freshly opened append stream is
+    // implementation-defined -- glibc reports the size, musl 0, and cutting back to 0 would
+    // destroy the batches already collected)
+    long long before = 0;
+    if (append) {
+        struct stat sb;
+        before = fstat(fileno(f), &sb) == 0 ? (long long)sb.st_size : -1;
+    }
     bool ok = true;
     uint64_t at = 0;
     for (uint32_t c = 0; ok && c < job->n_contigs; c++) {
@@ -742,11 +750,9 @@ try {
     }
     ok = ok && std::fflush(f) == 0;
     const int write_errno = errno;
-    if (!ok && append && before >= 0) {
-        if (ftruncate(fileno(f), (off_t)before) != 0) {
-            // nothing more can be done for the file; the status below still reports the failure
-        }
-    }
+    bool cut_back = true;
+    if (!ok && append)
+        cut_back = before >= 0 && ftruncate(fileno(f), (off_t)before) == 0;
     if (std::fclose(f) != 0 && ok) {
         set_error(std::string("closing ") + path + " failed: " + std::strerror(errno));
         if (!append)
@@ -756,7 +762,8 @@ try {
     if (!ok) {
         if (!append)
             (void)std::remove(path);
-        set_error(std::string("writing ") + path + " failed: " + std::strerror(write_errno));
+        set_error(std::string("writing ") + path + " failed: " + std::strerror(write_errno) +
+                  (cut_back ? "" : "; the file could NOT be cut back to its previous size and holds a partial batch"));
         return GP_ERR_IO;
     }
     return GP_OK;

@@ -1643,6 +1643,19 @@ int stage_a_run(gp_job* job)
 {
     const gp_params& p = job->prm;
     hipStream_t s = job->ctx->stream;
+    // Whichever way this function is left -- the early return of a job without reads, an error
+    // half way, the end -- both of its streams are drained first: the caller (gp_jobs_polish runs
+    // the back half on another stream) may take "returned" as "the filters are there", and the
+    // copies enqueued below read from tables that live on this stack frame.
+    struct Drain {
+        hipStream_t a, b;
+        ~Drain()
+        {
+            (void)hipStreamSynchronize(a);
+            if (b)
+                (void)hipStreamSynchronize(b);
+        }
+    } drain{ s, job->a_stream2 };
     AArgs a{};
     a.reads = job->d_reads.p;
     a.n_pos = job->read_positions;

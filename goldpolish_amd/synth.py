@@ -96,19 +96,24 @@ def kmer_threshold(bases: int) -> int:
 def make_workload(contig_lens, coverage: float, seed: int, draft_err: float = 0.01,
                   read_err: float = 0.06, read_mean: float = 15000.0, read_sigma: float = 0.5,
                   read_min: int = 1000, read_max: int = 100000, s_per_10kbp: float = 40.0,
-                  keep_truth: bool = False) -> Workload:
+                  keep_truth: bool = False, truths=None, names_in=None) -> Workload:
     """One batch per contig.  Reads are sampled from the truth of their contig, so the
     mapping is exact; ranking follows the reference's rule (integer phred desc, id asc)
-    and the per-contig cap size_t(len*s/10000)."""
+    and the per-contig cap size_t(len*s/10000).  `truths` (uint8 arrays, upper-case ACGT...)
+    replaces the random genomes -- e.g. the contigs of a FASTA fixture (contig_lens is then
+    ignored); `names_in` their names."""
     rng = np.random.default_rng(seed)
-    names, contigs, truths = [], [], []
+    names, contigs = [], []
+    if truths is not None:
+        contig_lens = [len(t) for t in truths]
+    given, truths = truths, []
     reads, read_begin, thresholds = [], [0], []
     rid = 0
     mu = np.log(read_mean) - read_sigma ** 2 / 2
     for ci, n in enumerate(contig_lens):
-        truth = random_genome(int(n), rng)
+        truth = random_genome(int(n), rng) if given is None else np.asarray(given[ci], dtype=np.uint8)
         draft = mutate(truth, draft_err, rng)
-        names.append(f"contig{ci:06d}")
+        names.append(names_in[ci] if names_in is not None else f"contig{ci:06d}")
         contigs.append(draft)
         if keep_truth:
             truths.append(truth)
@@ -148,6 +153,24 @@ def make_workload(contig_lens, coverage: float, seed: int, draft_err: float = 0.
         kmer_threshold=np.asarray(thresholds, dtype=np.uint32),
         truth=truths if keep_truth else None,
     )
+
+
+def read_fasta(path):
+    """(names, sequences as uint8 arrays) of a FASTA file; names are whole header lines without '>'."""
+    names, seqs, cur = [], [], []
+    with open(path, "rb") as f:
+        for line in f:
+            line = line.rstrip(b"\r\n")
+            if line.startswith(b">"):
+                if names:
+                    seqs.append(np.frombuffer(b"".join(cur), dtype=np.uint8))
+                names.append(line[1:].decode())
+                cur = []
+            elif line:
+                cur.append(line)
+    if names:
+        seqs.append(np.frombuffer(b"".join(cur), dtype=np.uint8))
+    return names, seqs
 
 
 def _chunk_job(args):

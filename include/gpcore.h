@@ -169,13 +169,16 @@ void gp_job_destroy(gp_job* job);
  * May be called again: it restarts from the uploaded inputs. */
 int gp_job_polish(gp_job* job, int sync);
 /* gp_job_polish(job, 1) for several jobs, pipelined: the filter build of job i + 1 runs beside
- * the ntEdit cascade, mask, Sealer and upper of job i (two host threads, every job on its own
- * stream), so the memory-bound stage hides the latency-bound ones -- what the reference gets
- * from running polishing batches beside its filter server (scripts/goldpolish:496-514).  Every
- * job must have been created on a gp_ctx of its own, all on one device (for the duration of the
- * call the filter builds share the first job's stream and everything else the second job's: two
- * queues whatever the number of jobs).  Returns the first failing job's status, its message
- * prefixed with the job's index. */
+ * the ntEdit cascade, mask, Sealer and upper of job i (two host threads), so the memory-bound
+ * stage hides the latency-bound ones -- what the reference gets from running polishing batches
+ * beside its filter server (scripts/goldpolish:496-514).  Every job must have been created on a
+ * gp_ctx of its own, all on one device.  The contexts are BORROWED for the duration of the call:
+ * each job's ctx->stream is re-pointed -- to the first job's stream while its filters are built,
+ * to the second job's for everything behind them -- and put back before the call returns; the
+ * filter build also uses a private second stream per job (census mark / pack, reservation
+ * rounds).  So no other thread may touch any of these contexts or jobs (gp_job_sync included)
+ * while the call runs.  Returns the first failing job's status, its message prefixed with the
+ * job's index. */
 int gp_jobs_polish(gp_job* const* jobs, uint32_t n_jobs);
 /* Individual stages, in order, for tests and profiling. */
 int gp_job_build_filters(gp_job* job, int sync);          /* stage A */
