@@ -4,18 +4,27 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched
 under torch.distributed.run with one rank per GPU.  A step = one pass of the whole hot path
 (filter build -> ntEdit cascade + guard -> mask -> Sealer -> upper) over the rank's batches,
-with reads + contigs already resident in HBM; at N > 1 the step ends with the gather of the
-polished sequences on rank 0 (RCCL).  W untimed warm-up steps, then exactly K timed steps
-between barrier + synchronize; max over ranks; rank 0 prints ONE JSON line.
+measured as SURVEY.md 8d defines the metric: from reads + contigs resident in HOST memory to the
+polished bytes in HOST memory at rank 0.  The steps stream through gp_pipeline_*: while step i is
+polished, the inputs of step i + 1 are uploaded (pinned staging, DMA on a second stream), so every
+timed step contains one full upload (H2D over PCIe), the path, and the download (D2H) of the
+polished bytes; at N > 1 it ends with the gather of the polished sequences on rank 0 (RCCL, from
+HBM) and their copy to host memory there.  W untimed warm-up steps, then exactly K timed steps
+between barrier + synchronize; max over ranks; rank 0 prints ONE JSON line.  `hbm_resident`
+reports, beside it, the same path with the inputs already in HBM and the output left there
+(rounds 1-2's headline).
 
-Workload = the configuration BASELINE.json's metric is quoted on (full k cascade
+Workload at N = 1 = the configuration BASELINE.json's metric is quoted on (full k cascade
 {32,28,24,20}) that fits one GPU: configs[2], a synthetic 100 Mbp assembly + 40x ONT-like reads
-(6 % error) per GPU, bsize = 1 (weak scaling: every rank polishes its own 100 Mbp).  The
-assembly is 4000 contigs of 25 kbp: the regime GoldPolish's fixed 10 MiB / 512 KiB filters are
-sized for (the reference's own fixture, tests/goldrush_test_golden_path.fa, holds contigs of
-2-43 kbp); substitutions, indels and gap fills really happen there.  `aux` reports
-configs[1] beside it (one 10 Mbp contig, k = 32 only: its filters saturate, so it measures the
-filter build alone).  --workload picks another one (see WORKLOADS).
+(6 % error), bsize = 1.  The assembly is 4000 contigs of 25 kbp: the regime GoldPolish's fixed
+10 MiB / 512 KiB filters are sized for (the reference's own fixture,
+tests/goldrush_test_golden_path.fa, holds contigs of 2-43 kbp); substitutions, indels and gap
+fills really happen there.  At N > 1 the workload is BASELINE.json configs[3] scaled to the node:
+ONE assembly of N x 375 Mbp (3 Gbp at N = 8) in contigs of 5-100 kbp + 30x reads, its batches
+dealt to the ranks by gp_partition_batches, every rank generating and polishing
+its share (weak scaling: 375 Mbp per GPU).  `aux` reports configs[1] beside the N = 1 line (one
+10 Mbp contig, k = 32 only: its filters saturate, so it measures the filter build alone).
+--workload picks another one (see WORKLOADS).
 """
 import argparse
 import json
@@ -63,6 +72,29 @@ def fixture_like_lengths(total_bp, seed):
         out.append(n)
         got += n
     return out
+
+
+def node_share(world, rank, seed=4):
+    """BASELINE.json configs[3] scaled to the node: ONE assembly of world x 15000 contigs (log-normal
+    around 25 kbp, 5-100 kbp: 375 Mbp per GPU, 3 Gbp at 8) + 30x reads, its batches (bsize = 1) dealt
+    to the ranks by gp_partition_batches with cost = contig bases + mapped read bases.
+    A contig's bases and reads depend on its index in the assembly only, so every rank generates
+    exactly its own share of the same assembly, whatever the number of ranks."""
+    from goldpolish_amd import core, synth
+    rng = np.random.default_rng(seed)
+    lens = np.clip(rng.lognormal(np.log(22_000.0), 0.5, size=15000 * world), 5_000, 100_000).astype(np.int64)
+    cov = 30
+    cost = (lens * (1 + cov)).astype(np.uint64)
+    rank_of, load = core.partition_batches(cost, world)
+    mine = np.nonzero(np.asarray(rank_of) == rank)[0]
+    w = synth.make_workload_chunked([int(lens[i]) for i in mine], cov, seed=seed, chunk=1,
+                                    seeds=[seed * 1000003 + int(i) for i in mine])
+    desc = (f"BASELINE.json configs[3] scaled to the node: one synthetic assembly of {int(lens.sum())} bp "
+            f"({len(lens)} contigs of 5-100 kbp, one per batch) + 30x ONT-error reads, k=32,28,24,20, batches "
+            f"dealt to {world} ranks by gp_partition_batches (cost = contig + read bases; loads "
+            f"{int(min(load))}..{int(max(load))})")
+    return w, [32, 28, 24, 20], desc, {"assembly_bp": int(lens.sum()), "assembly_contigs": int(len(lens)),
+                                       "rank_contigs": int(len(mine))}
 
 
 def make_workload(kind, seed):
@@ -199,17 +231,30 @@ def cpu_baseline(w, ks, desc, gpu_out=None):
     }
 
 
+class _DevView:
+    """a device pointer as an object torch.as_tensor can wrap without copying"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="config3")
-    ap.add_argument("--jobs-per-gpu", type=int, default=-1,
-                    help="jobs a rank cuts its batches into and keeps in flight (gp_jobs_polish pipelines the "
-                         "filter build of one behind the rest of another); default 1")
+    ap.add_argument("--workload", default="auto",
+                    help="auto: config3 (BASELINE configs[2]) at N = 1, the node's share of configs[3] at N > 1")
+    ap.add_argument("--resident-steps", type=int, default=3,
+                    help="steps of the HBM-resident extra at N = 1 (0: skip it)")
+    ap.add_argument("--jobs-per-gpu", type=int, default=1,
+                    help="HBM-resident extra only: jobs the batches are cut into and kept in flight (gp_jobs_polish)")
     ap.add_argument("--no-aux", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cache", default=os.environ.get("GP_BENCH_CACHE", ""),
+                    help="directory of generated workloads (.npz): loaded when there, written when not -- a run "
+                         "under rocprofv3 must not fork its generator's workers")
+    ap.add_argument("--prepare-only", action="store_true", help="generate (and cache) the workloads, then exit")
     ap.add_argument("--backend", default="nccl",
                     help="gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -217,12 +262,33 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    kind = args.workload if args.workload != "auto" else ("config3" if world == 1 else "node")
 
     # Synthetic inputs first: the generator forks worker processes, which must happen before
     # anything in this process touches the GPU.
-    w_main, ks_main, desc_main = make_workload(args.workload, seed=2 + rank)
-    want_aux = world == 1 and rank == 0 and not args.no_aux and args.workload == "config3"
-    aux_in = make_workload("config2", seed=2) if want_aux else None
+    from goldpolish_amd import synth
+
+    def cached(name, make):
+        f = pathlib.Path(args.cache) / f"{name}.npz" if args.cache else None
+        if f and f.exists():
+            w = synth.load_workload(f)
+            return (w,) + tuple(json.loads((f.with_suffix(".json")).read_text()))
+        out = make()
+        if f:
+            f.parent.mkdir(parents=True, exist_ok=True)
+            synth.save_workload(out[0], f)
+            f.with_suffix(".json").write_text(json.dumps(list(out[1:])))
+        return out
+
+    extra_cfg = {}
+    if kind == "node":
+        w_main, ks_main, desc_main, extra_cfg = cached(f"node_{world}_{rank}", lambda: node_share(world, rank))
+    else:
+        w_main, ks_main, desc_main = cached(f"{kind}_{2 + rank}", lambda: make_workload(kind, seed=2 + rank))
+    want_aux = world == 1 and rank == 0 and not args.no_aux and kind == "config3"
+    aux_in = cached("config2_2", lambda: make_workload("config2", seed=2)) if want_aux else None
+    if args.prepare_only:
+        return
 
     import torch
     if not torch.cuda.is_available():
@@ -237,8 +303,94 @@ def main():
     on_gpu = args.backend == "nccl"
     from goldpolish_amd import core
 
-    def run(w, ks, steps, warmup, want_cold, n_jobs):
-        """the timed loop over one rank's batches, cut into n_jobs jobs of consecutive contigs"""
+    KERNELS = ("cbf_first_pass", "cbf_round", "cbf_census", "cbf_local", "ntedit_scan", "ntedit_walk", "mask",
+               "sealer_bfs", "upper")
+
+    def word_sum(a):
+        """a cheap checksum of host bytes: the sum of its 64-bit words (and of the odd tail)"""
+        n8 = a.size // 8 * 8
+        return (int(a[:n8].view(np.uint64).sum(dtype=np.uint64)) + int(a[n8:].sum(dtype=np.uint64))) & (2**64 - 1)
+
+    def run_stream(w, ks, steps, warmup):
+        """SURVEY 8d's timed region: host memory to host memory, the steps streamed through
+        gp_pipeline_* (upload of step i + 1 beside the polishing of step i).  Every step is the
+        whole workload: one upload, the path, one download (and at N > 1 the gather)."""
+        params = core.default_params(k_values=ks)
+        bs, keep = core.batch_set_of_workload(w)
+        pipe = core.Pipeline(device_index, params, depth=2)
+        sums, times = [], {"upload_ms": [], "polish_ms": [], "download_ms": []}
+        last = {}
+
+        def step(tag, timed):
+            r = pipe.collect(copy=False)
+            # keep the stream full: the set after next is handed over before anything else, so that
+            # its upload runs beside the polishing of the next one
+            pipe.submit(bs, keep, tag + 2)
+            data = r["bytes"]
+            if world > 1:
+                # polished records leave from HBM (the pipeline's packed copy), over xGMI; rank 0
+                # ends the step with every rank's bytes in host memory
+                n = r["total_bytes"]
+                lens_t = torch.from_numpy(r["lengths"].astype(np.int64))
+                if on_gpu:
+                    payload = torch.as_tensor(_DevView(r["device_ptr"], max(n, 1)), device="cuda")[:n]
+                    lens_t = lens_t.cuda()
+                else:   # rehearsal: the same exchange over host memory
+                    payload = torch.from_numpy(data)
+                got = gather_to_rank0(lens_t, payload, rank, world)
+                if rank == 0:
+                    host = [(l.cpu(), b.cpu()) for l, b in got[1:]]
+                    last["gathered"] = (sum(int(l.numel()) for l, _ in host) + r["lengths"].size,
+                                        sum(int(b.numel()) for _, b in host) + n)
+            sums.append((r["total_bytes"], word_sum(data)))
+            if timed:
+                for k in times:
+                    times[k].append(r[k])
+            last["r"] = r
+
+        pipe.submit(bs, keep, 0)
+        pipe.submit(bs, keep, 1)
+        for i in range(warmup):
+            step(i, False)
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i, True)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if len(set(sums)) != 1:
+            raise SystemExit(f"bench.py: the polished output changed between steps: {sorted(set(sums))}")
+        r = last["r"]
+        kt = {}
+        for name in KERNELS:
+            ms, n, units = pipe.kernel_time(name)
+            kt[name] = {"ms": ms, "launches": n, "units": units}
+        res = {"bp_per_rank": w.total_bp, "dt": dt, "steps": steps, "counters": r["counters"],
+               "coverage": float(w.read_off[-1]) / max(w.total_bp, 1), "n_k": len(ks),
+               "n_contigs": w.n_contigs, "device_bytes": r["device_bytes_in_use"], "n_jobs": 1,
+               "kernels": kt,
+               "output_checksum": {"bytes": sums[0][0], "word_sum": sums[0][1], "steps_compared": len(sums)},
+               "stream": {k: round(float(np.mean(v)), 2) for k, v in times.items()},
+               "input_bytes": int(w.read_off[-1]) + int(w.contig_off[-1]),
+               "gathered": last.get("gathered")}
+        res["polished"] = core.split_polished(r) if rank == 0 and world == 1 else None
+        # the two sets still in flight (uploaded beside the last timed steps) are drained untimed
+        pipe.collect(copy=False)
+        pipe.collect(copy=False)
+        pipe.close()
+        return res
+
+    def run(w, ks, steps, warmup, n_jobs):
+        """the same path with the inputs already resident in HBM and the output left there (rounds 1-2's
+        timed region), the rank's batches cut into n_jobs jobs of consecutive contigs"""
         params = core.default_params(k_values=ks)
         n_jobs = max(1, min(n_jobs, w.n_contigs))
         # shrinking jobs (4 : 3 : 2 : 1 ...): only the last job's back half is not hidden behind a
@@ -255,8 +407,7 @@ def main():
 
         def step():
             core.polish_jobs(jobs)
-            # the polished records, packed back to back in one HBM buffer in input order: what
-            # rank 0 ends a step with at every N (at N > 1 the other ranks' buffers arrive next to it)
+            # the polished records, packed back to back in one HBM buffer in input order
             lens = [j.lengths()[0] for j in jobs]
             sizes = [int(l.sum()) for l in lens]
             payload = torch.empty(max(sum(sizes), 1), dtype=torch.uint8, device="cuda")
@@ -267,30 +418,15 @@ def main():
                 at += n
             # every step must give the same bytes: a cheap checksum of the packed records on the GPU
             sums.append((sum(sizes), int(payload[:sum(sizes)].sum(dtype=torch.int64).item())))
-            if world > 1:
-                # device-to-device: packed on the GPU, sent from HBM over xGMI
-                all_lens = np.concatenate(lens)
-                lens_t = torch.from_numpy(all_lens.astype(np.int64)).cuda()
-                if not on_gpu:   # rehearsal: the same exchange over host memory
-                    lens_t, payload = lens_t.cpu(), payload.cpu()
-                gather_to_rank0(lens_t, payload[:sum(sizes)], rank, world)
 
         for _ in range(warmup):
             step()
-        if dist:
-            dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
         dt = time.perf_counter() - t0
-        if dist:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
         if len(set(sums)) != 1:
             raise SystemExit(f"bench.py: the polished output changed between steps: {sorted(set(sums))}")
         counters = {}
@@ -301,20 +437,18 @@ def main():
                "coverage": float(w.read_off[-1]) / max(w.total_bp, 1), "n_k": len(ks),
                "n_contigs": w.n_contigs, "device_bytes": core.device_bytes_in_use(), "n_jobs": n_jobs,
                "output_checksum": {"bytes": sums[0][0], "byte_sum": sums[0][1], "steps_compared": len(sums)}}
-        names = ("cbf_first_pass", "cbf_round", "cbf_census", "cbf_local", "ntedit_scan", "ntedit_walk", "mask",
-                 "sealer_bfs", "upper")
 
         def kernel_times():
-            kt = {n: {"ms": 0.0, "launches": 0, "units": 0} for n in names}
+            kt = {n: {"ms": 0.0, "launches": 0, "units": 0} for n in KERNELS}
             for j in jobs:
-                for name in names:
+                for name in KERNELS:
                     ms, n, units = j.kernel_time(name)
                     kt[name]["ms"] += ms
                     kt[name]["launches"] += n
                     kt[name]["units"] += units
             return kt
         res["kernels"] = kernel_times()          # the last timed step, kernels of several jobs side by side
-        res["polished"] = [x for j in jobs for x in j.sequences()] if rank == 0 and world == 1 else None
+        res["polished"] = None
         if n_jobs > 1:
             # every job once more, ONE AT A TIME: a launch's own duration with the chip to itself
             for j in jobs:
@@ -322,24 +456,6 @@ def main():
             res["kernels_alone"] = kernel_times()
         for j in jobs:
             j.close()
-        if want_cold:
-            # the same step with the hand-over included: host buffers -> pinned staging -> HBM
-            # (gp_job_create), the path, and the polished bytes copied back to host memory.
-            # Reported beside `value`, never as it.
-            t0 = time.perf_counter()
-            jobs2 = [core.Job(ctxs[i], params, **core.slice_workload(w, cuts[i], cuts[i + 1])) for i in range(n_jobs)]
-            t1 = time.perf_counter()
-            core.polish_jobs(jobs2)
-            for j in jobs2:
-                j.sequences()
-            t2 = time.perf_counter()
-            for j in jobs2:
-                j.close()
-            res["pcie_inclusive"] = {"value": round(w.total_bp / (t2 - t0) / 1e6, 3), "unit": "Mbp/s",
-                                     "upload_ms": round((t1 - t0) * 1e3, 2),
-                                     "path_and_download_ms": round((t2 - t1) * 1e3, 2),
-                                     "note": "one cold run: job creation (pinned staging + device "
-                                             "allocations + PCIe upload) + path + download"}
         for c in ctxs:
             c.close()
         return res
@@ -424,12 +540,12 @@ def main():
                               "frac": round(rate / ATOMIC_CEILING_GPS, 3)}
         return out
 
-    # One job per GPU.  (--jobs-per-gpu N cuts the batches into N jobs that gp_jobs_polish
-    # pipelines: +8 % while the filter build was one long latency-tolerant kernel, within noise
-    # since the census made stage A a chain of streaming kernels that compete with the other stages.)
-    n_jobs = args.jobs_per_gpu if args.jobs_per_gpu > 0 else 1
-    main_res = run(w_main, ks_main, args.steps, args.warmup, rank == 0 and world == 1, n_jobs)
+    main_res = run_stream(w_main, ks_main, args.steps, args.warmup)
     total_bp = main_res["bp_per_rank"] * world
+    if dist:
+        t = torch.tensor([main_res["bp_per_rank"]], dtype=torch.int64, device="cuda" if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total_bp = int(t.item())
     value = total_bp * args.steps / main_res["dt"] / 1e6
     line = {
         "metric": METRIC,
@@ -439,29 +555,51 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": desc_main,
-            "contigs_per_gpu": main_res["n_contigs"], "bp_per_gpu": main_res["bp_per_rank"],
+            "timed_region": "SURVEY 8d: reads + contigs resident in host memory -> polished bytes in host memory at "
+                            "rank 0, steady state: every step holds one upload (H2D, beside the polishing of the step "
+                            "before), the path, the download (D2H)" + (" and the RCCL gather" if world > 1 else ""),
+            "contigs_per_gpu": main_res["n_contigs"], "bp_per_gpu": main_res["bp_per_rank"], "bp_total": total_bp,
             "read_coverage": round(main_res["coverage"], 2), "k": ",".join(map(str, ks_main)),
-            "parallelism": f"batches sharded over {world} GPU(s), {main_res['n_jobs']} job(s) in flight per GPU "
-                           "(gp_jobs_polish), gather to rank 0",
+            "parallelism": f"batches sharded over {world} GPU(s), one process per GPU; gp_pipeline (upload | polish | "
+                           "collect) per GPU" + (", gather of polished records to rank 0 (RCCL)" if world > 1 else ""),
             "device_GiB_in_use": round(main_res["device_bytes"] / 2**30, 1),
+            **extra_cfg,
         },
     }
     if rank == 0:
-        line["roofline"] = roofline(main_res, args.workload)
+        line["roofline"] = roofline(main_res, kind)
         line["counters"] = main_res["counters"]
         line["output_checksum"] = main_res["output_checksum"]   # identical in every warm-up and timed step
-        if "pcie_inclusive" in main_res:
-            line["pcie_inclusive"] = main_res["pcie_inclusive"]
+        st = main_res["stream"]
+        line["stream"] = {
+            **st, "input_bytes_per_step": main_res["input_bytes"],
+            "upload_GBps": round(main_res["input_bytes"] / max(st["upload_ms"], 1e-9) / 1e6, 2),
+            "note": "per step, means over the timed steps: upload_ms = gp_job_create of the step (pinned staging + "
+                    "H2D), hidden behind the polishing of the step before when it is shorter than polish_ms + "
+                    "download_ms; ms_per_step is what the caller sees between two collects",
+        }
+        if main_res.get("gathered"):
+            line["stream"]["gathered_records_and_bytes_at_rank0"] = main_res["gathered"]
+    if world == 1 and rank == 0 and args.resident_steps > 0:
+        # beside it: the inputs already in HBM, the output left there (what rounds 1-2 reported as `value`)
+        rs = run(w_main, ks_main, args.resident_steps, 1, max(1, args.jobs_per_gpu))
+        line["hbm_resident"] = {
+            "value": round(rs["bp_per_rank"] * rs["steps"] / rs["dt"] / 1e6, 3), "unit": "Mbp/s",
+            "ms_per_step": round(rs["dt"] / rs["steps"] * 1e3, 3), "steps": rs["steps"],
+            "note": "the same path and workload with reads + contigs already resident in HBM and the polished "
+                    "records left packed in HBM: no PCIe in the timed region",
+            "same_output_bytes": rs["output_checksum"]["bytes"] == main_res["output_checksum"]["bytes"],
+        }
     if want_aux:
         w_aux, ks_aux, desc_aux = aux_in
-        aux = run(w_aux, ks_aux, max(1, min(args.steps, 5)), 1, False, 1)
+        aux = run_stream(w_aux, ks_aux, max(1, min(args.steps, 5)), 1)
         r = roofline(aux, "config2")
         line["aux"] = {
             "workload": desc_aux + " (its one pair of 10 MiB / 512 KiB filters saturates, as the "
                         "reference's would: ntEdit and Sealer find nothing to do, the step is the filter build)",
             "value": round(aux["bp_per_rank"] * aux["steps"] / aux["dt"] / 1e6, 3),
             "unit": "Mbp/s", "ms_per_step": round(aux["dt"] / aux["steps"] * 1e3, 2),
-            "roofline": r, "counters": aux["counters"],
+            "stream": aux["stream"], "roofline": r, "counters": aux["counters"],
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(w_main, ks_main, desc_main, main_res.get("polished"))

@@ -34,7 +34,9 @@ SYMBOLS = [
     "gp_mappings_load", "gp_mappings_get", "gp_mappings_destroy", "gp_job_create_from_files",
     "gp_target_extract", "gp_target_update_paf", "gp_target_reinsert",
     "gp_jobs_polish", "gp_filter_save", "gp_filter_save_btllib", "gp_filter_load", "gp_job_write_fasta",
-    "gp_sealer_consensus",
+    "gp_sealer_consensus", "gp_device_pool_bytes", "gp_device_pool_trim",
+    "gp_pipeline_create", "gp_pipeline_submit", "gp_pipeline_collect", "gp_pipeline_kernel_time",
+    "gp_pipeline_destroy",
 ]
 
 
@@ -76,6 +78,15 @@ class Counters(C.Structure):
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class Polished(C.Structure):
+    _fields_ = [
+        ("tag", C.c_uint64), ("n_contigs", C.c_uint32), ("lengths", u64p), ("dropped", u8p),
+        ("host_bytes", u8p), ("device_bytes", C.c_void_p), ("total_bytes", C.c_uint64),
+        ("counters", Counters), ("upload_ms", C.c_double), ("polish_ms", C.c_double),
+        ("download_ms", C.c_double), ("device_bytes_in_use", C.c_uint64),
+    ]
 
 
 def _share_hip_runtime_with_torch():
@@ -164,6 +175,14 @@ def load_library(path=None):
     L.gp_filter_save_btllib.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64, u8p]
     L.gp_filter_load.argtypes = [C.c_char_p, u32p, u32p, u64p, u8p, C.c_uint64]
     L.gp_sealer_consensus.argtypes = [C.c_void_p, C.c_uint32, u32p, u8p, u64p, u8p, C.c_uint64, u32p]
+    L.gp_device_pool_bytes.restype = C.c_uint64
+    L.gp_device_pool_trim.restype = None
+    L.gp_pipeline_create.argtypes = [C.c_int, C.POINTER(Params), C.c_uint32, vpp]
+    L.gp_pipeline_submit.argtypes = [C.c_void_p, C.POINTER(BatchSet), C.c_uint64]
+    L.gp_pipeline_collect.argtypes = [C.c_void_p, C.POINTER(Polished)]
+    L.gp_pipeline_kernel_time.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), u64p, u64p]
+    L.gp_pipeline_destroy.argtypes = [C.c_void_p]
+    L.gp_pipeline_destroy.restype = None
     return L
 
 
@@ -196,6 +215,14 @@ def default_params(k_values=None, **kw) -> Params:
 
 def device_bytes_in_use() -> int:
     return int(lib().gp_device_bytes_in_use())
+
+
+def device_pool_bytes() -> int:
+    return int(lib().gp_device_pool_bytes())
+
+
+def device_pool_trim():
+    lib().gp_device_pool_trim()
 
 
 def kmer_threshold(bases: int) -> int:
@@ -394,6 +421,102 @@ def slice_workload(w, c0, c1):
                 read_buf=w.read_buf[int(w.read_off[r0]):int(w.read_off[r1])],
                 read_off=w.read_off[r0:r1 + 1] - w.read_off[r0],
                 name_len=[len(n) for n in w.names[c0:c1]])
+
+
+def make_batch_set(*, contig_buf, contig_off, contig_read_begin, kmer_threshold, read_buf, read_off,
+                   batch_contig_begin=None, name_len=None):
+    """(BatchSet, arrays it points into -- keep them alive as long as the struct is used)"""
+    n_contigs = len(contig_off) - 1
+    if batch_contig_begin is None:
+        batch_contig_begin = np.arange(n_contigs + 1)
+    k = dict(
+        bcb=_arr(batch_contig_begin, np.uint32), cbuf=_arr(contig_buf, np.uint8),
+        coff=_arr(contig_off, np.uint64), crb=_arr(contig_read_begin, np.uint32),
+        thr=_arr(kmer_threshold, np.uint32), rbuf=_arr(read_buf, np.uint8),
+        roff=_arr(read_off, np.uint64),
+        nlen=_arr(name_len if name_len is not None else np.zeros(n_contigs), np.uint32))
+    bs = BatchSet()
+    bs.n_batches = len(k["bcb"]) - 1
+    bs.batch_contig_begin = k["bcb"].ctypes.data_as(u32p)
+    bs.n_contigs = n_contigs
+    bs.contig_buf = k["cbuf"].ctypes.data_as(u8p)
+    bs.contig_off = k["coff"].ctypes.data_as(u64p)
+    bs.contig_name_len = k["nlen"].ctypes.data_as(u32p)
+    bs.contig_read_begin = k["crb"].ctypes.data_as(u32p)
+    bs.contig_kmer_threshold = k["thr"].ctypes.data_as(u32p)
+    bs.n_reads = len(k["roff"]) - 1
+    bs.read_buf = k["rbuf"].ctypes.data_as(u8p)
+    bs.read_off = k["roff"].ctypes.data_as(u64p)
+    return bs, k
+
+
+def batch_set_of_workload(w):
+    return make_batch_set(contig_buf=w.contig_buf, contig_off=w.contig_off,
+                          contig_read_begin=w.contig_read_begin, kmer_threshold=w.kmer_threshold,
+                          read_buf=w.read_buf, read_off=w.read_off, name_len=[len(n) for n in w.names])
+
+
+class Pipeline:
+    """gp_pipeline_*: batch sets from host memory to polished bytes in host memory, the upload of
+    one set beside the polishing of the one before."""
+
+    def __init__(self, device, params: Params, depth=2):
+        self._h = C.c_void_p()
+        self.params = params
+        self._sets = {}
+        _check(lib().gp_pipeline_create(int(device), C.byref(params), int(depth), C.byref(self._h)))
+
+    def submit(self, batch_set, keep, tag):
+        """batch_set, keep = make_batch_set(...); the arrays stay referenced until the set is collected"""
+        self._sets[int(tag)] = (batch_set, keep)
+        _check(lib().gp_pipeline_submit(self._h, C.byref(batch_set), int(tag)))
+
+    def collect(self, copy=True):
+        """the oldest submitted set: dict with tag, lengths, dropped, bytes (numpy views of the
+        pipeline's pinned buffer -- valid until the next collect -- unless copy), counters, times"""
+        r = Polished()
+        rc = lib().gp_pipeline_collect(self._h, C.byref(r))
+        self._sets.pop(int(r.tag), None)
+        _check(rc)
+        n = int(r.n_contigs)
+        lengths = np.ctypeslib.as_array(r.lengths, shape=(n,)) if n else np.zeros(0, np.uint64)
+        dropped = np.ctypeslib.as_array(r.dropped, shape=(n,)) if n else np.zeros(0, np.uint8)
+        total = int(r.total_bytes)
+        data = np.ctypeslib.as_array(r.host_bytes, shape=(total,)) if total else np.zeros(0, np.uint8)
+        if copy:
+            lengths, dropped, data = lengths.copy(), dropped.copy(), data.copy()
+        return {"tag": int(r.tag), "lengths": lengths, "dropped": dropped, "bytes": data,
+                "device_ptr": int(r.device_bytes or 0), "total_bytes": total,
+                "counters": r.counters.as_dict(), "upload_ms": float(r.upload_ms),
+                "polish_ms": float(r.polish_ms), "download_ms": float(r.download_ms),
+                "device_bytes_in_use": int(r.device_bytes_in_use)}
+
+    def kernel_time(self, name: str):
+        ms, n, units = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().gp_pipeline_kernel_time(self._h, name.encode(), C.byref(ms), C.byref(n), C.byref(units)))
+        return ms.value, int(n.value), int(units.value)
+
+    def close(self):
+        if self._h:
+            lib().gp_pipeline_destroy(self._h)
+            self._h = C.c_void_p()
+        self._sets.clear()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def split_polished(res):
+    """list of bytes (None for dropped contigs) from a Pipeline.collect() result"""
+    out, at = [], 0
+    b = res["bytes"].tobytes()
+    for n, d in zip(res["lengths"], res["dropped"]):
+        out.append(None if d else b[at:at + int(n)])
+        at += int(n)
+    return out
 
 
 class Job:

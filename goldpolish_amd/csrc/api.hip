@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <iterator>
+#include <map>
 #include <mutex>
 #include <cmath>
 #include <cstdlib>
@@ -22,6 +24,102 @@ static std::atomic<long long> g_device_bytes{0};
 void track_device_bytes(long long delta) { g_device_bytes += delta; }
 
 void set_error(const std::string& msg) { g_err = msg; }
+
+// ---- device memory pool (see gp_internal.h) ---------------------------------------------------
+// Free blocks per device, keyed by size.  A request takes the smallest free block that holds it
+// and is at most an eighth larger; otherwise hipMalloc (after which, on failure, the pool is
+// emptied and hipMalloc tried once more).  What the pool may hold is capped (GP_POOL_GIB, default
+// 200; 0 turns pooling off): beyond it the largest free blocks go back to the driver.
+namespace {
+struct DevPool {
+    std::mutex mu;
+    std::multimap<size_t, void*> free_blocks[16];
+    size_t pooled = 0;
+};
+DevPool g_pool;
+std::atomic<long long> g_pool_bytes{0};
+
+size_t pool_cap()
+{
+    static const size_t cap = (size_t)env_u64("GP_POOL_GIB", 200) << 30;
+    return cap;
+}
+
+void pool_trim_locked(size_t keep)
+{
+    for (auto& m : g_pool.free_blocks)
+        while (!m.empty() && g_pool.pooled > keep) {
+            auto it = std::prev(m.end());
+            (void)hipFree(it->second);
+            g_pool.pooled -= it->first;
+            m.erase(it);
+        }
+    g_pool_bytes = (long long)g_pool.pooled;
+}
+} // namespace
+
+int dev_alloc(size_t bytes, void** out, size_t* cap_bytes)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (dev >= 0 && dev < 16 && pool_cap()) {
+        std::lock_guard<std::mutex> g(g_pool.mu);
+        auto& m = g_pool.free_blocks[dev];
+        auto it = m.lower_bound(bytes);
+        if (it != m.end() && it->first <= bytes + bytes / 8) {
+            *out = it->second;
+            *cap_bytes = it->first;
+            g_pool.pooled -= it->first;
+            g_pool_bytes = (long long)g_pool.pooled;
+            m.erase(it);
+            track_device_bytes((long long)*cap_bytes);
+            return GP_OK;
+        }
+    }
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> g(g_pool.mu);
+            pool_trim_locked(0);
+        }
+        e = hipMalloc(&q, bytes);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+        return GP_ERR_OOM;
+    }
+    *out = q;
+    *cap_bytes = bytes;
+    track_device_bytes((long long)bytes);
+    return GP_OK;
+}
+
+void dev_free(void* q, size_t cap_bytes)
+{
+    if (!q)
+        return;
+    track_device_bytes(-(long long)cap_bytes);
+    hipPointerAttribute_t attr{};
+    int dev = -1;
+    if (pool_cap() && hipPointerGetAttributes(&attr, q) == hipSuccess)
+        dev = attr.device;
+    else
+        (void)hipGetLastError();
+    if (dev >= 0 && dev < 16 && cap_bytes <= pool_cap()) {
+        std::lock_guard<std::mutex> g(g_pool.mu);
+        g_pool.free_blocks[dev].emplace(cap_bytes, q);
+        g_pool.pooled += cap_bytes;
+        if (g_pool.pooled > pool_cap())
+            pool_trim_locked(pool_cap());
+        g_pool_bytes = (long long)g_pool.pooled;
+        return;
+    }
+    (void)hipFree(q);
+}
 
 int hip_fail(hipError_t e, const char* what, const char* file, int line)
 {
@@ -64,6 +162,21 @@ uint64_t gp_device_bytes_in_use(void)
 {
     const long long v = g_device_bytes.load();
     return v > 0 ? (uint64_t)v : 0;
+}
+
+uint64_t gp_device_pool_bytes(void)
+{
+    const long long v = g_pool_bytes.load();
+    return v > 0 ? (uint64_t)v : 0;
+}
+
+void gp_device_pool_trim(void)
+{
+    try {
+        std::lock_guard<std::mutex> g(g_pool.mu);
+        pool_trim_locked(0);
+    } catch (...) {
+    }
 }
 
 void gp_default_params(gp_params* p)
@@ -129,6 +242,13 @@ void gp_ctx_destroy(gp_ctx* ctx)
 {
     if (!ctx)
         return;
+    (void)hipSetDevice(ctx->device);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->stage[i])
+            (void)hipHostFree(ctx->stage[i]);
+        if (ctx->stage_ev[i])
+            (void)hipEventDestroy(ctx->stage_ev[i]);
+    }
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -202,6 +322,26 @@ try {
         std::copy(load.begin(), load.end(), rank_load);
     return GP_OK;
 } GP_CATCH("gp_partition_batches")
+
+// the context's two pinned staging chunks (GP_STAGE_MIB each, default 64), made on first use
+static int ensure_staging(gp_ctx* ctx)
+{
+    if (ctx->stage[0] && ctx->stage[1])
+        return GP_OK;
+    const size_t bytes = (size_t)std::max<uint64_t>(1, env_u64("GP_STAGE_MIB", 64)) << 20;
+    for (int i = 0; i < 2; i++) {
+        if (!ctx->stage[i] && hipHostMalloc((void**)&ctx->stage[i], bytes) != hipSuccess) {
+            ctx->stage[i] = nullptr;
+            (void)hipGetLastError();
+            set_error("pinned staging allocation failed");
+            return GP_ERR_OOM;
+        }
+        if (!ctx->stage_ev[i])
+            GP_HIP(hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming));
+    }
+    ctx->stage_bytes = bytes;
+    return GP_OK;
+}
 
 static int check_params(const gp_params& p)
 {
@@ -349,88 +489,97 @@ try {
     }
     j->h_seg_start[set->n_contigs] = total;
     j->read_positions = total;
+    // Everything below goes through the context's stream (copies from the context's two pinned
+    // staging chunks, the host filling one while the other drains) and is waited for once, at the
+    // end: nothing here touches the default stream or allocates pinned memory per job, so a job
+    // can be created by one thread while another polishes on the same device.
+    hipStream_t s = ctx->stream;
+    if ((rc = ensure_staging(ctx)) != GP_OK)
+        return fail(rc);
+    if ((rc = j->d_reads.alloc(total + 64)) != GP_OK)
+        return fail(rc);
     {
-        uint8_t* stage = nullptr;
-        if (total) {
-            if (hipHostMalloc((void**)&stage, total) != hipSuccess) {
-                set_error("gp_job_create: pinned staging allocation failed");
-                return fail(GP_ERR_OOM);
-            }
-            uint64_t at = 0;
-            for (uint32_t c = 0; c < set->n_contigs; c++)
-                for (uint32_t r = set->contig_read_begin[c]; r < set->contig_read_begin[c + 1];
-                     r++) {
-                    uint64_t len = set->read_off[r + 1] - set->read_off[r];
-                    std::memcpy(stage + at, set->read_buf + set->read_off[r], len);
-                    at += len;
-                    stage[at++] = '\n';
+        int slot = 0;
+        size_t fill = 0;       // bytes in the chunk being filled
+        uint64_t sent = 0;     // bytes of d_reads already on their way
+        auto flush = [&]() -> int {
+            if (!fill)
+                return GP_OK;
+            GP_HIP(hipMemcpyAsync(j->d_reads.p + sent, ctx->stage[slot], fill, hipMemcpyHostToDevice, s));
+            GP_HIP(hipEventRecord(ctx->stage_ev[slot], s));
+            sent += fill;
+            fill = 0;
+            slot ^= 1;
+            GP_HIP(hipEventSynchronize(ctx->stage_ev[slot])); // the other chunk has drained
+            return GP_OK;
+        };
+        for (uint32_t c = 0; c < set->n_contigs; c++)
+            for (uint32_t r = set->contig_read_begin[c]; r < set->contig_read_begin[c + 1]; r++) {
+                const uint8_t* src = set->read_buf + set->read_off[r];
+                uint64_t left = set->read_off[r + 1] - set->read_off[r];
+                while (left) {
+                    const size_t n = (size_t)std::min<uint64_t>(left, ctx->stage_bytes - fill);
+                    std::memcpy(ctx->stage[slot] + fill, src, n);
+                    fill += n;
+                    src += n;
+                    left -= n;
+                    if (fill == ctx->stage_bytes && (rc = flush()) != GP_OK)
+                        return fail(rc);
                 }
+                ctx->stage[slot][fill++] = '\n';
+                if (fill == ctx->stage_bytes && (rc = flush()) != GP_OK)
+                    return fail(rc);
+            }
+        // the tail of the buffer (kernels stage a halo past the last position)
+        for (int i = 0; i < 64; i++) {
+            ctx->stage[slot][fill++] = '\n';
+            if (fill == ctx->stage_bytes && (rc = flush()) != GP_OK)
+                return fail(rc);
         }
-        if ((rc = j->d_reads.alloc(total + 64)) != GP_OK) {
-            if (stage)
-                (void)hipHostFree(stage);
+        if ((rc = flush()) != GP_OK)
             return fail(rc);
-        }
-        hipError_t e = hipMemset(j->d_reads.p, '\n', total + 64);
-        if (e == hipSuccess && total)
-            e = hipMemcpy(j->d_reads.p, stage, total, hipMemcpyHostToDevice);
-        if (stage)
-            (void)hipHostFree(stage);
-        if (e != hipSuccess)
-            return fail(hip_fail(e, "upload reads", __FILE__, __LINE__));
     }
     if ((rc = j->d_seg_start.alloc((size_t)set->n_contigs + 1)) != GP_OK ||
         (rc = j->d_seg_batch.alloc(set->n_contigs)) != GP_OK ||
         (rc = j->d_seg_thr.alloc(set->n_contigs)) != GP_OK)
         return fail(rc);
-    {
-        hipError_t e = hipMemcpy(j->d_seg_start.p, j->h_seg_start.data(),
-                                 j->h_seg_start.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess && set->n_contigs)
-            e = hipMemcpy(j->d_seg_batch.p, j->h_contig_batch.data(),
-                          set->n_contigs * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess && set->n_contigs)
-            e = hipMemcpy(j->d_seg_thr.p, j->h_contig_thr.data(), set->n_contigs * sizeof(uint32_t),
-                          hipMemcpyHostToDevice);
-        if (e != hipSuccess)
-            return fail(hip_fail(e, "upload segment tables", __FILE__, __LINE__));
+    // (the sources of these copies are vectors of the job: they outlive the copies)
+    GP_HIP(hipMemcpyAsync(j->d_seg_start.p, j->h_seg_start.data(), j->h_seg_start.size() * sizeof(uint64_t),
+                          hipMemcpyHostToDevice, s));
+    if (set->n_contigs) {
+        GP_HIP(hipMemcpyAsync(j->d_seg_batch.p, j->h_contig_batch.data(), set->n_contigs * sizeof(uint32_t),
+                              hipMemcpyHostToDevice, s));
+        GP_HIP(hipMemcpyAsync(j->d_seg_thr.p, j->h_contig_thr.data(), set->n_contigs * sizeof(uint32_t),
+                              hipMemcpyHostToDevice, s));
     }
 
     // ---- contigs
     {
-        uint64_t cb = j->h_contig_off[set->n_contigs];
+        const uint64_t base = set->n_contigs ? set->contig_off[0] : 0;
+        const uint64_t cb = j->h_contig_off[set->n_contigs] - base;
         if ((rc = j->d_contigs_in.alloc(cb + 64)) != GP_OK)
             return fail(rc);
-        if (set->n_contigs && cb > set->contig_off[0]) {
-            hipError_t e = hipMemcpy(j->d_contigs_in.p, set->contig_buf + set->contig_off[0],
-                                     cb - set->contig_off[0], hipMemcpyHostToDevice);
-            if (e != hipSuccess)
-                return fail(hip_fail(e, "upload contigs", __FILE__, __LINE__));
+        GP_HIP(hipEventSynchronize(ctx->stage_ev[0]));
+        GP_HIP(hipEventSynchronize(ctx->stage_ev[1]));
+        int slot = 0;
+        for (uint64_t at = 0; at < cb;) {
+            const size_t n = (size_t)std::min<uint64_t>(cb - at, ctx->stage_bytes);
+            GP_HIP(hipEventSynchronize(ctx->stage_ev[slot]));
+            std::memcpy(ctx->stage[slot], set->contig_buf + base + at, n);
+            GP_HIP(hipMemcpyAsync(j->d_contigs_in.p + at, ctx->stage[slot], n, hipMemcpyHostToDevice, s));
+            GP_HIP(hipEventRecord(ctx->stage_ev[slot], s));
+            at += n;
+            slot ^= 1;
         }
-        if (set->n_contigs && set->contig_off[0] != 0) {
-            uint64_t base = set->contig_off[0];
+        if (base)
             for (auto& o : j->h_contig_off)
                 o -= base;
-        }
     }
-
-    // ---- filters
-    // Bloom filters: one per (batch, k), they are results.  Counting filters: an arena of slots,
-    // scratch of the filter build (512 slots = 5 GiB at GoldPolish's 10 MiB; GP_STAGE_A_SLOTS)
-    const uint64_t streams = (uint64_t)set->n_batches * params->n_k;
-    {
-        const char* e = getenv("GP_STAGE_A_SLOTS");
-        uint64_t want = e && *e ? strtoull(e, nullptr, 10) : 512;
-        want = std::max<uint64_t>(want, params->n_k); // one batch at least
-        j->cbf_slots = (uint32_t)std::min<uint64_t>(streams, want);
-    }
-    if ((rc = j->d_cbf.alloc((uint64_t)j->cbf_slots * ((params->cbf_bytes + 15) / 16 * 16) + 64)) != GP_OK ||
-        (rc = j->d_bf.alloc(streams * (params->bf_bytes / 4))) != GP_OK)
-        return fail(rc);
-    if ((rc = stage_a_prepare(j)) != GP_OK)
-        return fail(rc);
-    if ((rc = stage_bc_prepare(j)) != GP_OK)
-        return fail(rc);
+    GP_HIP(hipStreamSynchronize(s));
+    // Filters and work buffers are allocated by the first call that needs them (ensure_work): a
+    // job that has only been created holds its inputs and nothing else, so the next job of a
+    // stream can be uploaded while the one before it is polished without both holding tens of
+    // GiB of work buffers.
     owner.j = nullptr;
     *out = j;
     return GP_OK;
@@ -478,13 +627,41 @@ static int finish(gp_job* job, int rc, int sync)
     return GP_OK;
 }
 
-// stages B and C keep their state in job->bc; it is gone only if growing the slots ran out of memory
-static int need_bc(const gp_job* job, const char* who)
+// Filters and work buffers, allocated by the first call that needs them (gp_job_create uploads the
+// inputs and nothing else).  They are gone for good only if growing the contig slots ran out of
+// memory half way (polish_back): later calls then get GP_ERR_STATE.
+static int ensure_work(gp_job* j, const char* who)
 {
-    if (job->bc)
+    if (j->work_state == 1 && j->bc)
         return GP_OK;
-    set_error(std::string(who) + ": the job lost its polishing state (allocation failed while growing the contig slots)");
-    return GP_ERR_STATE;
+    if (j->work_state != 0) {
+        set_error(std::string(who) + ": the job lost its polishing state (allocation failed while growing the contig slots)");
+        return GP_ERR_STATE;
+    }
+    const gp_params& p = j->prm;
+    // Bloom filters: one per (batch, k), they are results.  Counting filters: an arena of slots,
+    // scratch of the filter build (512 slots = 5 GiB at GoldPolish's 10 MiB; GP_STAGE_A_SLOTS)
+    const uint64_t streams = (uint64_t)j->n_batches * p.n_k;
+    {
+        uint64_t want = env_u64("GP_STAGE_A_SLOTS", 512);
+        want = std::max<uint64_t>(want, p.n_k); // one batch at least
+        j->cbf_slots = (uint32_t)std::min<uint64_t>(streams, want);
+    }
+    int rc;
+    if ((rc = j->d_cbf.alloc((uint64_t)j->cbf_slots * ((p.cbf_bytes + 15) / 16 * 16) + 64)) == GP_OK &&
+        (rc = j->d_bf.alloc(streams * (p.bf_bytes / 4))) == GP_OK && (rc = stage_a_prepare(j)) == GP_OK &&
+        (rc = stage_bc_prepare(j)) == GP_OK) {
+        j->work_state = 1;
+        return GP_OK;
+    }
+    // nothing half-built stays behind: the call may be tried again when memory has been freed
+    const std::string msg = gp_last_error();
+    stage_a_release(j);
+    stage_bc_release(j);
+    j->d_cbf.release();
+    j->d_bf.release();
+    set_error(msg);
+    return rc;
 }
 
 int gp_job_build_filters(gp_job* job, int sync)
@@ -492,6 +669,8 @@ try {
     if (!job)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
+    if (int rcw = ensure_work(job, "gp_job_build_filters"))
+        return rcw;
     return finish(job, stage_a_run(job), sync);
 } GP_CATCH("gp_job_build_filters")
 
@@ -504,7 +683,7 @@ try {
         return GP_ERR_STATE;
     }
     GP_HIP(hipSetDevice(job->ctx->device));
-    if (int rcb = need_bc(job, "gp_job_ntedit_pass"))
+    if (int rcb = ensure_work(job, "gp_job_ntedit_pass"))
         return rcb;
     int rc = GP_OK;
     if (k_index == 0)
@@ -519,7 +698,7 @@ try {
     if (!job)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
-    if (int rcb = need_bc(job, "gp_job_ntedit_guard"))
+    if (int rcb = ensure_work(job, "gp_job_ntedit_guard"))
         return rcb;
     return finish(job, stage_b_guard(job), sync);
 } GP_CATCH("gp_job_ntedit_guard")
@@ -529,7 +708,7 @@ try {
     if (!job)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
-    if (int rcb = need_bc(job, "gp_job_mask"))
+    if (int rcb = ensure_work(job, "gp_job_mask"))
         return rcb;
     return finish(job, stage_mask(job), sync);
 } GP_CATCH("gp_job_mask")
@@ -543,7 +722,7 @@ try {
         return GP_ERR_STATE;
     }
     GP_HIP(hipSetDevice(job->ctx->device));
-    if (int rcb = need_bc(job, "gp_job_sealer"))
+    if (int rcb = ensure_work(job, "gp_job_sealer"))
         return rcb;
     return finish(job, stage_c_run(job), sync);
 } GP_CATCH("gp_job_sealer")
@@ -553,7 +732,7 @@ try {
     if (!job)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
-    if (int rcb = need_bc(job, "gp_job_upper"))
+    if (int rcb = ensure_work(job, "gp_job_upper"))
         return rcb;
     return finish(job, stage_upper(job), sync);
 } GP_CATCH("gp_job_upper")
@@ -613,6 +792,7 @@ static int polish_back(gp_job* job)
         stage_bc_release(job);
         if ((rc = stage_bc_prepare(job)) != GP_OK) {
             stage_bc_release(job); // not a half-built state: later calls get GP_ERR_STATE
+            job->work_state = 2;
             break;
         }
     }
@@ -624,7 +804,7 @@ try {
     if (!job)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
-    if (int rcb = need_bc(job, "gp_job_polish"))
+    if (int rcb = ensure_work(job, "gp_job_polish"))
         return rcb;
     int rc = stage_a_run(job);
     if (rc == GP_OK)
@@ -682,7 +862,7 @@ try {
                 // thread waits for ever
                 int r;
                 try {
-                    r = need_bc(jobs[i], "gp_jobs_polish");
+                    r = ensure_work(jobs[i], "gp_jobs_polish");
                     if (r == GP_OK && hipSetDevice(jobs[i]->ctx->device) != hipSuccess) {
                         set_error("gp_jobs_polish: hipSetDevice failed");
                         r = GP_ERR_HIP;
@@ -751,6 +931,10 @@ try {
         return GP_ERR_INVALID_ARG;
     }
     GP_HIP(hipSetDevice(job->ctx->device));
+    if (!job->filters_ready) {
+        set_error("gp_job_get_filter: filters have not been built or set");
+        return GP_ERR_STATE;
+    }
     GP_HIP(hipStreamSynchronize(job->ctx->stream));
     const uint64_t words = job->prm.bf_bytes / 4;
     GP_HIP(hipMemcpy(out, job->d_bf.p + ((uint64_t)batch * job->prm.n_k + k_index) * words,
@@ -763,6 +947,8 @@ try {
     if (!job || !filters)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
+    if (int rcw = ensure_work(job, "gp_job_set_filters"))
+        return rcw;
     GP_HIP(hipStreamSynchronize(job->ctx->stream));
     GP_HIP(hipMemcpy(job->d_bf.p, filters,
                      (uint64_t)job->n_batches * job->prm.n_k * job->prm.bf_bytes,
@@ -776,7 +962,7 @@ try {
     if (!job)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
-    if (int rcb = need_bc(job, "gp_job_get_lengths"))
+    if (int rcb = ensure_work(job, "gp_job_get_lengths"))
         return rcb;
     return stage_lengths(job, lengths, dropped, total);
 } GP_CATCH("gp_job_get_lengths")
@@ -786,7 +972,7 @@ try {
     if (!job || !buf)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
-    if (int rcb = need_bc(job, "gp_job_get_sequences"))
+    if (int rcb = ensure_work(job, "gp_job_get_sequences"))
         return rcb;
     return stage_sequences(job, buf, buf_bytes);
 } GP_CATCH("gp_job_get_sequences")
@@ -796,7 +982,7 @@ try {
     if (!job || !device_buf)
         return GP_ERR_INVALID_ARG;
     GP_HIP(hipSetDevice(job->ctx->device));
-    if (int rcb = need_bc(job, "gp_job_get_sequences_device"))
+    if (int rcb = ensure_work(job, "gp_job_get_sequences_device"))
         return rcb;
     return stage_sequences_device(job, device_buf, buf_bytes);
 } GP_CATCH("gp_job_get_sequences_device")

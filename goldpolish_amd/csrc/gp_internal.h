@@ -39,24 +39,30 @@ inline uint64_t env_u64(const char* name, uint64_t dflt)
     return strtoull(v, nullptr, 10);
 }
 
+// Device memory comes from a per-device pool of blocks this library has freed before (api.hip):
+// a job of the same shape as an earlier one costs no hipMalloc (page tables for tens of GiB
+// take about a second) and no hipFree (which waits for the whole device), which is what a
+// stream of jobs through gp_pipeline_* needs.  Recycled blocks hold old bytes -- as hipMalloc'd
+// memory may -- so nothing may rely on fresh memory being zero.
+int dev_alloc(size_t bytes, void** p, size_t* cap_bytes);
+void dev_free(void* p, size_t cap_bytes);
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    size_t cap_bytes = 0; // size of the block behind p (>= n * sizeof(T): a pooled block may be larger)
     int alloc(size_t count)
     {
         release();
         if (count == 0)
             count = 1;
-        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
-        if (e != hipSuccess) {
-            p = nullptr;
-            set_error(std::string("hipMalloc of ") + std::to_string(count * sizeof(T)) +
-                      " bytes failed: " + hipGetErrorString(e));
-            return GP_ERR_OOM;
-        }
+        void* q = nullptr;
+        const int rc = dev_alloc(count * sizeof(T), &q, &cap_bytes);
+        if (rc != GP_OK)
+            return rc;
+        p = (T*)q;
         n = count;
-        track_device_bytes((long long)(count * sizeof(T)));
         return GP_OK;
     }
     // at least `count` elements, keeping what is there when it is enough (work buffers that
@@ -64,12 +70,11 @@ struct DevBuf {
     int ensure(size_t count) { return (p && n >= count) ? GP_OK : alloc(count); }
     void release()
     {
-        if (p) {
-            (void)hipFree(p);
-            track_device_bytes(-(long long)(n * sizeof(T)));
-        }
+        if (p)
+            dev_free(p, cap_bytes);
         p = nullptr;
         n = 0;
+        cap_bytes = 0;
     }
     ~DevBuf() { release(); }
     DevBuf() = default;
@@ -101,6 +106,11 @@ struct gp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop{};
+    // Two pinned staging chunks for uploads (gp_job_create), allocated on first use and kept for
+    // the context's life: the host fills one while the DMA engine drains the other.
+    uint8_t* stage[2] = { nullptr, nullptr };
+    hipEvent_t stage_ev[2] = { nullptr, nullptr };
+    size_t stage_bytes = 0;
 };
 
 // Per-k constants of the rolling hash, prepared on the host.
@@ -173,6 +183,9 @@ struct gp_job {
     gp::KernelTimer t_first_pass, t_round, t_local, t_census, t_scan, t_walk, t_bfs, t_mask, t_upper;
     gp_counters counters{};
     bool filters_ready = false;
+    // 0: only the inputs are on the device (gp_job_create); 1: filters and work buffers allocated
+    // (the first call that needs them); 2: lost -- an allocation failed while they were (re)built
+    int work_state = 0;
 };
 
 namespace gp {

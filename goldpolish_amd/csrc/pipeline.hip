@@ -1,0 +1,362 @@
+// pipeline.hip -- gp_pipeline_*: a stream of batch sets through one GPU, host memory to host
+// memory (SURVEY.md 8d's timed region: reads + contigs resident in host memory -> polished bytes
+// in host memory).  Host C++ only; the device work is gp_job_create / gp_job_polish.
+//
+// Three stages run side by side, each in a thread of its own, connected by bounded queues:
+//   upload   gp_job_create of set i + 1 on the pipeline's upload context (pinned staging, DMA on
+//            that context's stream) ...
+//   polish   ... while set i runs the whole path on the polishing context; its polished records
+//            are packed into an HBM buffer, copied to pinned host memory, and the job is destroyed
+//            (its device blocks go to the pool and are what the next job's first use takes) ...
+//   collect  ... while the caller still reads the result of set i - 1.
+// Results come back in submission order -- the ordered append of scripts/goldpolish-reaper:51-73.
+// The reference overlaps the same things with processes: its filter server builds the next
+// batches' filters while polishing workers run (scripts/goldpolish:496-514).
+#include "gp_internal.h"
+
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace gp;
+
+namespace {
+
+const char* const kTimerNames[] = { "cbf_first_pass", "cbf_round", "cbf_local", "cbf_census", "ntedit_scan",
+                                    "ntedit_walk",    "sealer_bfs", "mask",     "upper" };
+constexpr int kTimers = 9;
+
+struct Slot { // one finished set
+    uint64_t tag = 0;
+    int rc = GP_OK;
+    std::string msg;
+    std::vector<uint64_t> lengths;
+    std::vector<uint8_t> dropped;
+    uint64_t total = 0;
+    uint8_t* h_bytes = nullptr; // pinned, grows
+    uint64_t h_cap = 0;
+    DevBuf<uint8_t> d_bytes;
+    gp_counters counters{};
+    double upload_ms = 0, polish_ms = 0, download_ms = 0;
+    double t_ms[kTimers] = {};
+    uint64_t t_launches[kTimers] = {}, t_units[kTimers] = {};
+    uint64_t device_bytes = 0;
+};
+
+struct Item {
+    gp_batch_set set{};
+    uint64_t tag = 0;
+    gp_job* job = nullptr;
+    int rc = GP_OK;
+    std::string msg;
+    double upload_ms = 0;
+};
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+} // namespace
+
+struct gp_pipeline {
+    gp_ctx* up_ctx = nullptr;
+    gp_ctx* run_ctx = nullptr;
+    gp_params prm{};
+    uint32_t depth = 2;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Item> submitted; // waiting for the upload thread
+    std::deque<Item> uploaded;  // on the device, waiting for the polishing thread (one at most)
+    std::deque<int> done;       // slots ready for collect, oldest first
+    std::vector<int> free_slots;
+    Slot slots[3];
+    int held = -1;              // slot the caller is reading (released by the next collect)
+    uint32_t in_flight = 0;     // submitted and not yet collected
+    bool stop = false;
+    std::thread uploader, polisher;
+};
+
+static void upload_loop(gp_pipeline* p)
+{
+    for (;;) {
+        Item it;
+        {
+            std::unique_lock<std::mutex> g(p->mu);
+            p->cv.wait(g, [&] { return p->stop || (!p->submitted.empty() && p->uploaded.empty()); });
+            if (p->stop)
+                return;
+            it = std::move(p->submitted.front());
+            p->submitted.pop_front();
+        }
+        const double t0 = now_ms();
+        try {
+            it.rc = gp_job_create(p->up_ctx, &p->prm, &it.set, &it.job);
+            if (it.rc != GP_OK)
+                it.msg = gp_last_error();
+        } catch (...) {
+            it.rc = on_exception("gp_pipeline (upload)");
+        }
+        it.upload_ms = now_ms() - t0;
+        {
+            std::lock_guard<std::mutex> g(p->mu);
+            p->uploaded.push_back(std::move(it));
+        }
+        p->cv.notify_all();
+    }
+}
+
+static int polish_one(gp_pipeline* p, Item& it, Slot& s)
+{
+    gp_job* job = it.job;
+    job->ctx = p->run_ctx; // the upload is complete (gp_job_create waits for it); from here on the polishing context's stream
+    double t0 = now_ms();
+    int rc = gp_job_polish(job, 1);
+    if (rc != GP_OK)
+        return rc;
+    s.polish_ms = now_ms() - t0;
+    t0 = now_ms();
+    s.lengths.assign(job->n_contigs ? job->n_contigs : 1, 0);
+    s.dropped.assign(s.lengths.size(), 0);
+    if ((rc = gp_job_get_lengths(job, s.lengths.data(), s.dropped.data(), &s.total)) != GP_OK)
+        return rc;
+    if (s.h_cap < s.total || !s.h_bytes) {
+        if (s.h_bytes)
+            (void)hipHostFree(s.h_bytes);
+        s.h_bytes = nullptr;
+        s.h_cap = s.total + s.total / 8 + 4096;
+        if (hipHostMalloc((void**)&s.h_bytes, s.h_cap) != hipSuccess) {
+            s.h_bytes = nullptr;
+            s.h_cap = 0;
+            (void)hipGetLastError();
+            set_error("gp_pipeline: pinned result buffer allocation failed");
+            return GP_ERR_OOM;
+        }
+    }
+    if ((rc = s.d_bytes.ensure(s.total + 64)) != GP_OK)
+        return rc;
+    if (s.total) {
+        if ((rc = gp_job_get_sequences_device(job, s.d_bytes.p, s.total)) != GP_OK)
+            return rc;
+        GP_HIP(hipMemcpyAsync(s.h_bytes, s.d_bytes.p, s.total, hipMemcpyDeviceToHost, p->run_ctx->stream));
+        GP_HIP(hipStreamSynchronize(p->run_ctx->stream));
+    }
+    s.download_ms = now_ms() - t0;
+    s.counters = job->counters;
+    for (int i = 0; i < kTimers; i++)
+        (void)gp_job_kernel_time(job, kTimerNames[i], &s.t_ms[i], &s.t_launches[i], &s.t_units[i]);
+    s.device_bytes = gp_device_bytes_in_use();
+    return GP_OK;
+}
+
+static void polish_loop(gp_pipeline* p)
+{
+    for (;;) {
+        Item it;
+        int si;
+        {
+            std::unique_lock<std::mutex> g(p->mu);
+            p->cv.wait(g, [&] { return p->stop || (!p->uploaded.empty() && !p->free_slots.empty()); });
+            if (p->stop)
+                return;
+            it = std::move(p->uploaded.front());
+            p->uploaded.pop_front();
+            si = p->free_slots.back();
+            p->free_slots.pop_back();
+        }
+        p->cv.notify_all(); // the upload thread may start on the next set
+        Slot& s = p->slots[si];
+        s.tag = it.tag;
+        s.rc = it.rc;
+        s.msg = it.msg;
+        s.upload_ms = it.upload_ms;
+        s.total = 0;
+        if (it.rc == GP_OK) {
+            try {
+                (void)hipSetDevice(p->run_ctx->device);
+                s.rc = polish_one(p, it, s);
+                if (s.rc != GP_OK)
+                    s.msg = gp_last_error();
+            } catch (...) {
+                s.rc = on_exception("gp_pipeline (polish)");
+                try {
+                    s.msg = gp_last_error();
+                } catch (...) {
+                }
+            }
+        }
+        if (it.job) {
+            it.job->ctx = p->run_ctx;
+            gp_job_destroy(it.job); // its blocks go to the pool: the next job's work buffers
+        }
+        {
+            std::lock_guard<std::mutex> g(p->mu);
+            p->done.push_back(si);
+        }
+        p->cv.notify_all();
+    }
+}
+
+extern "C" {
+
+int gp_pipeline_create(int device, const gp_params* params, uint32_t depth, gp_pipeline** out)
+try {
+    if (!params || !out) {
+        set_error("gp_pipeline_create: NULL argument");
+        return GP_ERR_INVALID_ARG;
+    }
+    *out = nullptr;
+    gp_pipeline* p = new (std::nothrow) gp_pipeline();
+    if (!p)
+        return GP_ERR_OOM;
+    struct Owner {
+        gp_pipeline* p;
+        ~Owner()
+        {
+            if (p)
+                gp_pipeline_destroy(p);
+        }
+    } owner{ p };
+    int rc;
+    if ((rc = gp_ctx_create(device, &p->up_ctx)) != GP_OK || (rc = gp_ctx_create(device, &p->run_ctx)) != GP_OK)
+        return rc;
+    p->prm = *params;
+    p->depth = depth < 1 ? 1 : depth > 8 ? 8 : depth;
+    for (int i = 0; i < 3; i++)
+        p->free_slots.push_back(i);
+    p->uploader = std::thread(upload_loop, p);
+    p->polisher = std::thread(polish_loop, p);
+    owner.p = nullptr;
+    *out = p;
+    return GP_OK;
+} GP_CATCH("gp_pipeline_create")
+
+int gp_pipeline_submit(gp_pipeline* p, const gp_batch_set* set, uint64_t tag)
+try {
+    if (!p || !set) {
+        set_error("gp_pipeline_submit: NULL argument");
+        return GP_ERR_INVALID_ARG;
+    }
+    Item it;
+    it.set = *set;
+    it.tag = tag;
+    {
+        std::unique_lock<std::mutex> g(p->mu);
+        if (p->in_flight >= p->depth) {
+            // the caller is the one who collects: waiting here would never end
+            set_error("gp_pipeline_submit: " + std::to_string(p->depth) + " sets are in flight; collect one first");
+            return GP_ERR_STATE;
+        }
+        p->in_flight++;
+        p->submitted.push_back(std::move(it));
+    }
+    p->cv.notify_all();
+    return GP_OK;
+} GP_CATCH("gp_pipeline_submit")
+
+int gp_pipeline_collect(gp_pipeline* p, gp_polished* out)
+try {
+    if (!p || !out) {
+        set_error("gp_pipeline_collect: NULL argument");
+        return GP_ERR_INVALID_ARG;
+    }
+    std::memset(out, 0, sizeof *out);
+    int si;
+    {
+        std::unique_lock<std::mutex> g(p->mu);
+        if (p->held >= 0) { // the result of the collect before this one is released
+            p->free_slots.push_back(p->held);
+            p->held = -1;
+            p->cv.notify_all();
+        }
+        if (p->in_flight == 0) {
+            set_error("gp_pipeline_collect: nothing has been submitted");
+            return GP_ERR_STATE;
+        }
+        p->cv.wait(g, [&] { return !p->done.empty(); });
+        si = p->done.front();
+        p->done.pop_front();
+        p->held = si;
+        p->in_flight--;
+    }
+    const Slot& s = p->slots[si];
+    out->tag = s.tag;
+    out->upload_ms = s.upload_ms;
+    if (s.rc != GP_OK) {
+        set_error("set " + std::to_string(s.tag) + ": " + s.msg);
+        return s.rc;
+    }
+    out->n_contigs = (uint32_t)s.lengths.size();
+    out->lengths = s.lengths.data();
+    out->dropped = s.dropped.data();
+    out->host_bytes = s.h_bytes;
+    out->device_bytes = s.d_bytes.p;
+    out->total_bytes = s.total;
+    out->counters = s.counters;
+    out->polish_ms = s.polish_ms;
+    out->download_ms = s.download_ms;
+    out->device_bytes_in_use = s.device_bytes;
+    return GP_OK;
+} GP_CATCH("gp_pipeline_collect")
+
+int gp_pipeline_kernel_time(gp_pipeline* p, const char* kernel, double* total_ms, uint64_t* launches, uint64_t* units)
+try {
+    if (!p || !kernel)
+        return GP_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(p->mu);
+    if (p->held < 0) {
+        set_error("gp_pipeline_kernel_time: no collected set");
+        return GP_ERR_STATE;
+    }
+    const Slot& s = p->slots[p->held];
+    for (int i = 0; i < kTimers; i++)
+        if (!std::strcmp(kernel, kTimerNames[i])) {
+            if (total_ms)
+                *total_ms = s.t_ms[i];
+            if (launches)
+                *launches = s.t_launches[i];
+            if (units)
+                *units = s.t_units[i];
+            return GP_OK;
+        }
+    set_error("gp_pipeline_kernel_time: unknown kernel name");
+    return GP_ERR_INVALID_ARG;
+} GP_CATCH("gp_pipeline_kernel_time")
+
+void gp_pipeline_destroy(gp_pipeline* p)
+{
+    if (!p)
+        return;
+    try {
+        {
+            std::lock_guard<std::mutex> g(p->mu);
+            p->stop = true;
+        }
+        p->cv.notify_all();
+        if (p->uploader.joinable())
+            p->uploader.join();
+        if (p->polisher.joinable())
+            p->polisher.join();
+        for (Item& it : p->uploaded)
+            if (it.job)
+                gp_job_destroy(it.job);
+        if (p->run_ctx)
+            (void)hipSetDevice(p->run_ctx->device);
+        for (Slot& s : p->slots) {
+            if (s.h_bytes)
+                (void)hipHostFree(s.h_bytes);
+            s.d_bytes.release();
+        }
+        gp_ctx_destroy(p->up_ctx);
+        gp_ctx_destroy(p->run_ctx);
+        delete p;
+    } catch (...) {
+    }
+}
+
+} // extern "C"

@@ -203,16 +203,17 @@ def concat_workloads(parts) -> Workload:
 
 
 def make_workload_chunked(contig_lens, coverage: float, seed: int, chunk: int = 100, workers: int = 0,
-                          **kw) -> Workload:
+                          seeds=None, **kw) -> Workload:
     """make_workload for large assemblies: the contigs are cut into runs of `chunk`, each run is
-    generated by make_workload with its own seed (seed * 1000003 + run), in `workers` processes
-    (0 = one per core the process may use; started by fork, so call this BEFORE anything touches
-    the GPU).  The result depends on (contig_lens, coverage, seed, chunk) only, never on the
-    number of workers."""
+    generated by make_workload with its own seed (seed * 1000003 + run, or seeds[run]), in `workers`
+    processes (0 = one per core the process may use; started by fork, so call this BEFORE anything
+    touches the GPU).  The result depends on (contig_lens, coverage, seed(s), chunk) only, never on
+    the number of workers."""
     import multiprocessing as mp
     import os
     lens = [int(x) for x in contig_lens]
-    jobs = [(lens[i:i + chunk], coverage, seed * 1000003 + i // chunk, kw) for i in range(0, len(lens), chunk)]
+    jobs = [(lens[i:i + chunk], coverage, seeds[i // chunk] if seeds is not None else seed * 1000003 + i // chunk, kw)
+            for i in range(0, len(lens), chunk)]
     if workers <= 0:
         workers = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     workers = max(1, min(workers, len(jobs), 32))   # a GPU box shows every core of its node
@@ -220,5 +221,20 @@ def make_workload_chunked(contig_lens, coverage: float, seed: int, chunk: int = 
         parts = [_chunk_job(j) for j in jobs]
     else:
         with mp.get_context("fork").Pool(workers) as pool:
-            parts = pool.map(_chunk_job, jobs, chunksize=1)
+            parts = pool.map(_chunk_job, jobs, chunksize=max(1, min(64, len(jobs) // (4 * workers))))
     return concat_workloads(parts)
+
+
+def save_workload(w: Workload, path):
+    """a workload as one .npz file (bench.py --cache: generate once, then load without forking --
+    what a run under rocprofv3 needs, whose preloaded library has initialised the GPU already)"""
+    np.savez(path, names=np.array("\n".join(w.names)), contig_buf=w.contig_buf, contig_off=w.contig_off,
+             read_buf=w.read_buf, read_off=w.read_off, contig_read_begin=w.contig_read_begin,
+             kmer_threshold=w.kmer_threshold)
+
+
+def load_workload(path) -> Workload:
+    z = np.load(path)
+    return Workload(names=str(z["names"]).split("\n"), contig_buf=z["contig_buf"], contig_off=z["contig_off"],
+                    read_buf=z["read_buf"], read_off=z["read_off"], contig_read_begin=z["contig_read_begin"],
+                    kmer_threshold=z["kmer_threshold"])

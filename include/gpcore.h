@@ -134,6 +134,12 @@ int gp_version(void);
  * A job needs about n_batches * n_k * (cbf_bytes + bf_bytes) for the filters, 30 bytes per contig
  * base and 1 byte per read base, plus 13 GiB of Sealer search arenas per job with run_sealer. */
 uint64_t gp_device_bytes_in_use(void);
+/* Device memory the library keeps for re-use: blocks of destroyed jobs go to a pool, so that the
+ * next job of a like shape costs no hipMalloc / hipFree (a stream of jobs: gp_pipeline_*).  The
+ * pool never holds more than GP_POOL_GIB GiB (environment, default 200; 0 = no pooling) and is
+ * emptied before an allocation is allowed to fail; gp_device_pool_trim gives everything back. */
+uint64_t gp_device_pool_bytes(void);
+void gp_device_pool_trim(void);
 void gp_default_params(gp_params* p);
 int gp_ctx_create(int device, gp_ctx** out);
 void gp_ctx_destroy(gp_ctx* ctx);
@@ -160,8 +166,13 @@ int gp_partition_batches(uint32_t n_batches, const uint64_t* cost, uint32_t n_ra
                          uint32_t* rank_of, uint64_t* rank_load);
 
 /* ---- jobs --------------------------------------------------------------- */
-/* Copies the batch set to the device (host->HBM over PCIe; NOT part of the
- * polishing time) and allocates filters and work buffers. */
+/* Copies the batch set to the device (host -> HBM over PCIe, through the context's two pinned
+ * staging chunks and its stream; the call returns when the copies are complete).  Filters and
+ * work buffers are allocated by the first call that needs them (gp_job_polish, a stage, a
+ * getter), not here: a job that has only been created holds its inputs and nothing else, so it
+ * can be created beside another job's polishing (gp_pipeline_* does) without both holding tens
+ * of GiB.  An allocation failure therefore shows up at that first call (GP_ERR_OOM; the call may
+ * be repeated once memory has been freed). */
 int gp_job_create(gp_ctx* ctx, const gp_params* params, const gp_batch_set* set, gp_job** out);
 void gp_job_destroy(gp_job* job);
 /* The whole path for every batch of the job: filters -> ntEdit cascade (+guard)
@@ -202,6 +213,46 @@ int gp_job_sync(gp_job* job);
 int gp_sealer_consensus(gp_ctx* ctx, uint32_t n_sets, const uint32_t* set_seq_begin,
                         const uint8_t* seq_buf, const uint64_t* seq_off, uint8_t* out_buf,
                         uint64_t out_stride, uint32_t* out_len);
+
+/* ---- a stream of batch sets, host memory to host memory ------------------------------------
+ * SURVEY.md 8d's timed region -- reads, mappings and contigs resident in host memory to polished
+ * bytes in host memory -- with the three things that can overlap overlapping: while set i is
+ * polished, set i + 1 is uploaded (gp_job_create on a second context: pinned staging, DMA on its
+ * own stream) and the caller still reads the result of set i - 1.  Results come back in
+ * submission order (the ordered collection of scripts/goldpolish-reaper:51-73).  The reference
+ * overlaps the same steps with processes: its filter server works on the next batches while the
+ * polishing workers run (scripts/goldpolish:496-514).
+ *
+ * gp_pipeline_submit never blocks: with `depth` sets submitted and not yet collected it returns
+ * GP_ERR_STATE.  The arrays of a submitted gp_batch_set must stay valid and unchanged until the
+ * gp_pipeline_collect that returns that set.  gp_pipeline_collect blocks until the oldest
+ * submitted set is done; what it hands out (pinned host memory and an HBM copy of the same bytes,
+ * e.g. for an RCCL send) belongs to the pipeline and stays valid until the next
+ * gp_pipeline_collect or gp_pipeline_destroy.  A set that failed gives its status and message
+ * here, prefixed with its tag; the pipeline goes on with the next one.  One thread at a time may
+ * use a pipeline. */
+typedef struct gp_pipeline gp_pipeline;
+typedef struct gp_polished {
+    uint64_t tag;                /* as submitted */
+    uint32_t n_contigs;
+    const uint64_t* lengths;     /* [n_contigs], 0 for a contig ntEdit dropped */
+    const uint8_t* dropped;      /* [n_contigs] */
+    const uint8_t* host_bytes;   /* polished sequences back to back, in contig order (pinned host memory) */
+    const void* device_bytes;    /* the same bytes in HBM */
+    uint64_t total_bytes;
+    gp_counters counters;
+    double upload_ms;            /* gp_job_create of this set (ran beside the polishing of the set before) */
+    double polish_ms;            /* the whole path on the device */
+    double download_ms;          /* packing + the copy to host_bytes */
+    uint64_t device_bytes_in_use;/* gp_device_bytes_in_use() when this set was done */
+} gp_polished;
+int gp_pipeline_create(int device, const gp_params* params, uint32_t depth, gp_pipeline** out);
+int gp_pipeline_submit(gp_pipeline* p, const gp_batch_set* set, uint64_t tag);
+int gp_pipeline_collect(gp_pipeline* p, gp_polished* out);
+/* gp_job_kernel_time for the set the last gp_pipeline_collect returned */
+int gp_pipeline_kernel_time(gp_pipeline* p, const char* kernel, double* total_ms, uint64_t* launches,
+                            uint64_t* units);
+void gp_pipeline_destroy(gp_pipeline* p);
 
 /* ---- results (device -> host copies) ------------------------------------ */
 /* Bloom filter of batch b for k[k_index]: bf_bytes bytes into out. */

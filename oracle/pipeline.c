@@ -57,11 +57,35 @@ int gpo_polish_batch(const gpo_batch_params* bp, unsigned n_contigs, const char*
     memset(st, 0, sizeof *st);
 
     /* ---- stage A: one counting filter + one Bloom filter per k, shared by the batch */
+    /* (the reference constructs fresh filters per batch, goldpolish_targeted_bfs.cpp:70-77; here every
+     * thread keeps its arrays and clears them: with a calloc per batch the batch-parallel driver
+     * below got slower with more cores -- 42 MiB of fresh pages per batch and thread, all faulted in
+     * under one address-space lock -- which would have made cpu_baseline an unfairly low bar) */
+    static _Thread_local uint8_t* t_cbf[8];
+    static _Thread_local uint8_t* t_bf[8];
+    static _Thread_local size_t t_cbf_bytes, t_bf_bytes;
+    if (t_cbf_bytes != bp->cbf_bytes || t_bf_bytes != bp->bf_bytes) {
+        for (unsigned i = 0; i < 8; i++) {
+            free(t_cbf[i]);
+            free(t_bf[i]);
+            t_cbf[i] = t_bf[i] = NULL;
+        }
+        t_cbf_bytes = bp->cbf_bytes;
+        t_bf_bytes = bp->bf_bytes;
+    }
     uint8_t* cbfs[8];
     uint8_t* bfs[8];
     for (unsigned i = 0; i < nk; i++) {
-        cbfs[i] = (uint8_t*)calloc(bp->cbf_bytes, 1);
-        bfs[i] = (uint8_t*)calloc(bp->bf_bytes, 1);
+        if (!t_cbf[i])
+            t_cbf[i] = (uint8_t*)malloc(bp->cbf_bytes);
+        if (!t_bf[i])
+            t_bf[i] = (uint8_t*)malloc(bp->bf_bytes);
+        if (!t_cbf[i] || !t_bf[i])
+            return -3;
+        cbfs[i] = t_cbf[i];
+        bfs[i] = t_bf[i];
+        memset(cbfs[i], 0, bp->cbf_bytes);
+        memset(bfs[i], 0, bp->bf_bytes);
     }
     for (unsigned c = 0; c < n_contigs; c++) {
         for (uint32_t r = read_begin[c]; r < read_begin[c + 1]; r++) {
@@ -73,9 +97,6 @@ int gpo_polish_batch(const gpo_batch_params* bp, unsigned n_contigs, const char*
                     st->a_ops += read_lens[r] - bp->k_values[i] + 1;
         }
     }
-    for (unsigned i = 0; i < nk; i++)
-        free(cbfs[i]);
-
     /* ---- stage B: ntEdit cascade over the whole batch file */
     char** cur = (char**)calloc(n_contigs, sizeof(char*));
     uint64_t* cur_len = (uint64_t*)calloc(n_contigs, sizeof(uint64_t));
@@ -167,7 +188,6 @@ int gpo_polish_batch(const gpo_batch_params* bp, unsigned n_contigs, const char*
     for (unsigned i = 0; i < nk; i++) {
         if (out_bfs && out_bfs[i])
             memcpy(out_bfs[i], bfs[i], bp->bf_bytes);
-        free(bfs[i]);
     }
     free(cur);
     free(cur_len);

@@ -190,15 +190,19 @@ def test_a_thousand_short_contigs_whole_path(gp, oracle):
 
 
 def test_device_memory_is_accounted_and_released(gp):
-    """gp_device_bytes_in_use follows job creation, the capacity retry and destruction (no leak)"""
+    """gp_device_bytes_in_use follows job creation (inputs only), the first polish (filters + work
+    buffers), the capacity retry and destruction (no leak; freed blocks wait in the pool)"""
     core, ctx = gp
     base = core.device_bytes_in_use()
     w = synth.make_workload([20_000, 8_000], 20, seed=5)
     p = core.default_params()
     with core.Job.from_workload(ctx, p, w) as job:
+        inputs = core.device_bytes_in_use() - base
+        assert 0 < inputs < (16 << 20)                   # reads + contigs + small tables, nothing else yet
+        job.polish()
         held = core.device_bytes_in_use() - base
         filters = 2 * p.n_k * (p.cbf_bytes + p.bf_bytes)
-        assert held > filters + 3 * (1 << 30)           # filters + the Sealer's search arenas (256 workers for a small job)
+        assert held > filters + 1 * (1 << 30)            # filters + the Sealer's search arenas for a small job
         assert held < filters + 6 * (1 << 30)
         job.polish()
         assert core.device_bytes_in_use() - base >= held
