@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <ctime>
 
 namespace gp {
 
@@ -1292,11 +1293,10 @@ __global__ __launch_bounds__(64) void sealer_consensus(CArgs a)
 // same worker layout and the same nw_consensus as sealer_consensus above
 __global__ __launch_bounds__(64) void consensus_sets(const uint8_t* seq, const uint64_t* seq_off,
                                                      const uint32_t* set_begin, uint32_t n_sets, int32_t* nw,
-                                                     uint32_t* head, uint8_t* out, uint32_t* out_len,
-                                                     uint32_t* err)
+                                                     uint8_t* out, uint32_t* out_len, uint32_t* err,
+                                                     volatile uint32_t* progress)
 {
     __shared__ NwLds L;
-    __shared__ uint32_t item;
     const uint32_t wid = blockIdx.x, lane = threadIdx.x;
     const uint64_t mat_words = 3ull * (kNwMax + 1) * (kNwMax + 1);
     const uint64_t stride = mat_words + 2 * (2 * kNwMax + 64) / 4 + 64;
@@ -1304,29 +1304,18 @@ __global__ __launch_bounds__(64) void consensus_sets(const uint8_t* seq, const u
     int32_t* mat = nw + (uint64_t)wid * stride;
     uint8_t* bufA = (uint8_t*)(mat + mat_words);
     uint8_t* bufB = bufA + 2 * kNwMax + 64;
-    for (;;) {
-        if (lane == 0)
-            item = atomicAdd(head, 1u);
-        __syncthreads();
-        const uint32_t it = item;
-        __syncthreads();
-        if (it >= n_sets)
-            break;
+    // the sets are dealt round the workers (no queue: every worker knows its sets from its number)
+    for (uint32_t it = wid; it < n_sets; it += gridDim.x) {
         const uint32_t s0 = set_begin[it], s1 = set_begin[it + 1];
         bool ok = s1 - s0 >= 2;
         for (uint32_t p = s0; p < s1; p++)
             ok &= seq_off[p + 1] - seq_off[p] <= kNwMax && seq_off[p + 1] > seq_off[p];
-        if (!ok) { // (uniform)
-            if (lane == 0) {
-                atomicOr(err, 256u);
-                out_len[it] = 0;
-            }
-            continue;
-        }
-        uint32_t lc = nw_consensus(L, seq + seq_off[s0], (uint32_t)(seq_off[s0 + 1] - seq_off[s0]),
-                                   seq + seq_off[s0 + 1], (uint32_t)(seq_off[s0 + 2] - seq_off[s0 + 1]), mat, bufA);
+        uint32_t lc = 0;
         uint8_t* cur = bufA;
         uint8_t* nxt = bufB;
+        if (ok) // (uniform: every lane read the same offsets)
+            lc = nw_consensus(L, seq + seq_off[s0], (uint32_t)(seq_off[s0 + 1] - seq_off[s0]), seq + seq_off[s0 + 1],
+                              (uint32_t)(seq_off[s0 + 2] - seq_off[s0 + 1]), mat, bufA);
         for (uint32_t p = s0 + 2; p < s1 && ok; p++) {
             if (lc > kNwMax) {
                 ok = false;
@@ -1337,17 +1326,15 @@ __global__ __launch_bounds__(64) void consensus_sets(const uint8_t* seq, const u
             cur = nxt;
             nxt = t;
         }
-        if (!ok) {
-            if (lane == 0) {
+        if (ok)
+            for (uint32_t i = lane; i < lc; i += 64)
+                out[(uint64_t)it * out_stride + i] = cur[i];
+        if (lane == 0) {
+            out_len[it] = ok ? lc : 0u;
+            if (!ok)
                 atomicOr(err, 256u);
-                out_len[it] = 0;
-            }
-            continue;
+            progress[wid] = it + 1; // (mapped host memory: what the host reports if the launch does not come back)
         }
-        for (uint32_t i = lane; i < lc; i += 64)
-            out[(uint64_t)it * out_stride + i] = cur[i];
-        if (lane == 0)
-            out_len[it] = lc;
     }
 }
 
@@ -1360,31 +1347,66 @@ int sealer_consensus_sets(gp_ctx* ctx, uint32_t n_sets, const uint32_t* set_seq_
     const uint32_t workers = std::min<uint32_t>(kNwWorkers, std::max<uint32_t>(1u, n_sets));
     DevBuf<uint8_t> d_seq, d_out;
     DevBuf<uint64_t> d_off;
-    DevBuf<uint32_t> d_begin, d_len, d_misc;
+    DevBuf<uint32_t> d_begin, d_len, d_err;
     DevBuf<int32_t> d_nw;
     int rc;
     if ((rc = d_seq.alloc(bytes)) != GP_OK || (rc = d_off.alloc((size_t)n_seqs + 1)) != GP_OK ||
         (rc = d_begin.alloc((size_t)n_sets + 1)) != GP_OK || (rc = d_len.alloc(n_sets)) != GP_OK ||
-        (rc = d_out.alloc((uint64_t)n_sets * dev_stride)) != GP_OK || (rc = d_misc.alloc(2)) != GP_OK ||
+        (rc = d_out.alloc((uint64_t)n_sets * dev_stride)) != GP_OK || (rc = d_err.alloc(1)) != GP_OK ||
         (rc = d_nw.alloc((uint64_t)workers *
                          (3ull * (kNwMax + 1) * (kNwMax + 1) + 2 * (2 * kNwMax + 64) / 4 + 64))) != GP_OK)
         return rc;
+    // progress words in mapped host memory, one per worker
+    uint32_t* h_prog = nullptr;
+    GP_HIP(hipHostMalloc((void**)&h_prog, kNwWorkers * sizeof(uint32_t), hipHostMallocMapped));
+    struct FreeProg {
+        uint32_t* p;
+        ~FreeProg() { (void)hipHostFree(p); }
+    } free_prog{ h_prog };
+    std::memset(h_prog, 0, kNwWorkers * sizeof(uint32_t));
+    uint32_t* d_prog = nullptr;
+    GP_HIP(hipHostGetDevicePointer((void**)&d_prog, h_prog, 0));
+    const bool dbg = getenv("GP_CONSENSUS_DEBUG") != nullptr;
     hipStream_t s = ctx->stream;
     GP_HIP(hipMemcpyAsync(d_seq.p, seq_buf, bytes, hipMemcpyHostToDevice, s));
     GP_HIP(hipMemcpyAsync(d_off.p, seq_off, ((size_t)n_seqs + 1) * 8, hipMemcpyHostToDevice, s));
     GP_HIP(hipMemcpyAsync(d_begin.p, set_seq_begin, ((size_t)n_sets + 1) * 4, hipMemcpyHostToDevice, s));
-    GP_HIP(hipMemsetAsync(d_misc.p, 0, 8, s));
+    GP_HIP(hipMemsetAsync(d_err.p, 0, 4, s));
+    GP_HIP(hipStreamSynchronize(s));
+    if (dbg)
+        fprintf(stderr, "consensus: %u sets, %u sequences, %llu bytes uploaded; launching %u workers\n", n_sets, n_seqs,
+                (unsigned long long)bytes, workers);
     hipLaunchKernelGGL(consensus_sets, dim3(workers), dim3(64), 0, s, d_seq.p, d_off.p, d_begin.p, n_sets, d_nw.p,
-                       d_misc.p, d_out.p, d_len.p, d_misc.p + 1);
+                       d_out.p, d_len.p, d_err.p, d_prog);
     GP_HIP(hipGetLastError());
+    // a consensus takes milliseconds; a launch that has not come back after a minute is reported,
+    // with how far every worker got, instead of waited for
+    for (int waited_ms = 0;; waited_ms += 2) {
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess)
+            break;
+        if (q != hipErrorNotReady)
+            return hip_fail(q, "consensus_sets", __FILE__, __LINE__);
+        if (waited_ms >= 60000) {
+            std::string msg = "gp_sealer_consensus: the device did not finish within a minute; sets done per worker:";
+            for (uint32_t w = 0; w < workers; w++)
+                msg += " " + std::to_string(h_prog[w]);
+            set_error(msg);
+            return GP_ERR_HIP;
+        }
+        struct timespec ts = { 0, 2000000 };
+        nanosleep(&ts, nullptr);
+    }
+    if (dbg)
+        fprintf(stderr, "consensus: kernel done\n");
     std::vector<uint32_t> h_len(n_sets);
     std::vector<uint8_t> h_out((size_t)n_sets * dev_stride);
-    uint32_t h_misc[2] = { 0, 0 };
+    uint32_t h_err = 0;
     GP_HIP(hipMemcpyAsync(h_len.data(), d_len.p, (size_t)n_sets * 4, hipMemcpyDeviceToHost, s));
     GP_HIP(hipMemcpyAsync(h_out.data(), d_out.p, h_out.size(), hipMemcpyDeviceToHost, s));
-    GP_HIP(hipMemcpyAsync(h_misc, d_misc.p, 8, hipMemcpyDeviceToHost, s));
+    GP_HIP(hipMemcpyAsync(&h_err, d_err.p, 4, hipMemcpyDeviceToHost, s));
     GP_HIP(hipStreamSynchronize(s));
-    if (h_misc[1]) {
+    if (h_err) {
         set_error("gp_sealer_consensus: a set with fewer than two sequences, an empty sequence, or a sequence / "
                   "running consensus longer than " + std::to_string(kNwMax) + " bases");
         return GP_ERR_UNSUPPORTED;
