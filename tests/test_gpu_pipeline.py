@@ -79,6 +79,7 @@ def test_pool_recycles_device_blocks():
     from goldpolish_amd import core
     p = core.default_params()
     w = synth.make_workload([20000, 8000], 20, seed=5)
+    core.device_pool_trim()             # what earlier tests left behind
     with core.Context(0) as ctx:
         with core.Job.from_workload(ctx, p, w) as job:
             job.polish()
