@@ -97,8 +97,32 @@ def node_share(world, rank, seed=4):
                                        "rank_contigs": int(len(mine))}
 
 
+def survey_lengths(total_bp, mean_bp, seed):
+    """contig lengths ~ log-normal with the given mean (sigma 0.6), clipped to [mean/8, 6 mean], until total_bp"""
+    rng = np.random.default_rng(seed)
+    sigma = 0.6
+    mu = np.log(mean_bp) - sigma ** 2 / 2
+    out, got = [], 0
+    while got < total_bp:
+        n = int(np.clip(rng.lognormal(mu, sigma), mean_bp / 8, 6 * mean_bp))
+        n = min(n, total_bp - got) if total_bp - got > mean_bp / 8 else n
+        out.append(n)
+        got += n
+    return out
+
+
 def make_workload(kind, seed):
     from goldpolish_amd import synth
+    if kind == "survey3":   # SURVEY 8d config 3 in its own shape: the long-contig regime (filters fill up)
+        lens, cov, ks = survey_lengths(100_000_000, 2_000_000, 3), 40, [32, 28, 24, 20]
+        desc = ("SURVEY 8d config 3's shape: 100 Mbp in %d contigs ~ log-normal(mean 2 Mbp) + 40x reads, k=32,28,24,20, "
+                "bsize=1 (every batch saturates its 10 MiB / 512 KiB filters: the grid-wide schedule)" % len(lens))
+        return synth.make_workload_chunked(lens, cov, seed=seed, chunk=1), ks, desc
+    if kind == "survey4share":   # a rank's share of SURVEY 8d config 4: N50 10-20 Mbp
+        lens, cov, ks = survey_lengths(375_000_000, 12_000_000, 4), 30, [32, 28, 24, 20]
+        desc = ("a rank's share of SURVEY 8d config 4: 375 Mbp in %d contigs ~ log-normal(mean 12 Mbp) + 30x reads, "
+                "k=32,28,24,20, bsize=1" % len(lens))
+        return synth.make_workload_chunked(lens, cov, seed=seed, chunk=1), ks, desc
     if kind == "ragged":   # 20 Mbp of fixture-shaped contigs: thousands of short, ragged batches
         lens, cov, ks = fixture_like_lengths(20_000_000, seed), 40, [32, 28, 24, 20]
         desc = "20 Mbp in contigs shaped like the reference's fixture (2-45 kbp, median 7 kbp) + 40x reads, full cascade"
