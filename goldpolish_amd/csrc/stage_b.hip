@@ -69,6 +69,7 @@ struct WalkArgs {
     SiteRec* site_rec;                 // [slot position] what the trials at a confirmed site decide (or null)
     uint32_t* err;
     unsigned long long* stats;
+    unsigned long long* prof;          // development aid (GP_WALK_PROFILE): per contig, 100 MHz ticks and trips per request type
 };
 
 __device__ inline uint32_t __reduce_or_sync_compat(uint32_t v)
@@ -157,6 +158,8 @@ struct Shared {
     alignas(16) uint8_t c_seq[kCacheBases];
     uint64_t scan_fh[kWalkThreads], scan_rh[kWalkThreads];
     uint32_t wave_min[kWalkThreads / 64];
+    unsigned long long prof_t[8], prof_n[8], prof_last;
+    int32_t prof_req;
 };
 
 enum { REQ_DONE = 0, REQ_SCAN, REQ_SITE, REQ_NEXT, REQ_BITSCAN, REQ_REFILL, REQ_SWEEP };
@@ -1249,7 +1252,20 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
     // walker forward over the sequence as edited so far -- at most len positions plus one per
     // node (an inserted base is a node) -- so this many passes is a bug trap, never a limit.
     const uint64_t trip_trap = 8ull * ((uint64_t)len + c.node_cap) + 4096ull;
+    if (a.prof && tid == 0) {
+        for (int i = 0; i < 8; i++)
+            S.prof_t[i] = S.prof_n[i] = 0;
+        S.prof_last = wall_clock64();
+        S.prof_req = REQ_NEXT;
+    }
     for (uint64_t trip = 0;; trip++) {
+        if (a.prof && tid == 0) {
+            const unsigned long long now = wall_clock64();
+            S.prof_t[S.prof_req & 7] += now - S.prof_last;
+            S.prof_n[S.prof_req & 7]++;
+            S.prof_last = now;
+            S.prof_req = S.request; // what the trip that starts here works on (thread 0's decision below belongs to it)
+        }
         if (trip > trip_trap) {
             if (tid == 0) {
                 atomicOr(a.err, 4u);
@@ -1948,6 +1964,11 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             a.n_nodes[cid] = 0;
         }
         a.len_next[cid] = o;
+        if (a.prof)
+            for (int i = 0; i < 8; i++) {
+                a.prof[(uint64_t)cid * 16 + i] = S.prof_t[i];
+                a.prof[(uint64_t)cid * 16 + 8 + i] = S.prof_n[i];
+            }
         atomicAdd(&a.stats[0], S.st_scan);
         atomicAdd(&a.stats[1], S.st_sites);
         atomicAdd(&a.stats[2], S.st_probes);
@@ -2731,6 +2752,13 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     // 2. the ordered walk, one workgroup per contig; 3. copy the edited contigs out
     if ((rc = job->t_walk.begin(s, job->h_contig_off[job->n_contigs])) != GP_OK)
         return rc;
+    DevBuf<unsigned long long> d_prof;
+    if (getenv("GP_WALK_PROFILE")) {
+        if ((rc = d_prof.alloc((uint64_t)job->n_contigs * 16)) != GP_OK)
+            return rc;
+        GP_HIP(hipMemsetAsync(d_prof.p, 0, (uint64_t)job->n_contigs * 16 * 8, s));
+        a.prof = d_prof.p;
+    }
     if (job->n_contigs > 3 * 256)
         hipLaunchKernelGGL(ntedit_walk<6>, dim3(job->n_contigs), dim3(kWalkThreads), 0, s, a);
     else
@@ -2743,6 +2771,29 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     GP_HIP(hipGetLastError());
     if ((rc = job->t_walk.end(s)) != GP_OK)
         return rc;
+    if (a.prof) {
+        // development aid: the contigs whose walk took longest, and on which requests
+        GP_HIP(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h((size_t)job->n_contigs * 16);
+        GP_HIP(hipMemcpy(h.data(), d_prof.p, h.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> order(job->n_contigs);
+        std::vector<double> tot(job->n_contigs, 0);
+        for (uint32_t c = 0; c < job->n_contigs; c++) {
+            order[c] = c;
+            for (int i = 0; i < 8; i++)
+                tot[c] += (double)h[(size_t)c * 16 + i] / 1e5; // ms at 100 MHz
+        }
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return tot[x] > tot[y]; });
+        static const char* names[8] = { "done", "scan", "site", "next", "bitscan", "refill", "sweep", "-" };
+        for (uint32_t r = 0; r < std::min<uint32_t>(6, job->n_contigs); r++) {
+            const uint32_t c = order[r];
+            fprintf(stderr, "WALKPROF k=%u contig %u len %llu: %.1f ms =", a.k, c,
+                    (unsigned long long)(job->h_contig_off[c + 1] - job->h_contig_off[c]), tot[c]);
+            for (int i = 1; i < 7; i++)
+                fprintf(stderr, " %s %.1f ms / %llu", names[i], (double)h[(size_t)c * 16 + i] / 1e5, h[(size_t)c * 16 + 8 + i]);
+            fprintf(stderr, "\n");
+        }
+    }
     b->cur ^= 1;
     return GP_OK;
 }

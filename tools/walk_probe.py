@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""development aid: a few mid-size contigs (the long-contig regime's slow ones) through the path,
+with the walker's per-request clocks (GP_WALK_PROFILE=1) and the stage timers"""
+import os, sys, time, pathlib
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+from goldpolish_amd import synth
+lens = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1000000,1300000,600000,2000000").split(",")]
+w = synth.make_workload_chunked(lens, 40, seed=3, chunk=1)
+from goldpolish_amd import core
+p = core.default_params()
+with core.Context(0) as ctx, core.Job.from_workload(ctx, p, w) as job:
+    for rep in range(2):
+        t = time.time()
+        job.polish()
+        print("polish", round(time.time() - t, 3), "s", {n: round(job.kernel_time(n)[0], 1) for n in
+              ("cbf_first_pass", "cbf_round", "ntedit_scan", "ntedit_walk", "sealer_bfs", "mask")}, flush=True)
+    print(job.counters())
