@@ -95,6 +95,7 @@ struct AArgs {
     unsigned long long* kset;
     uint32_t kset_mask;                     // entries per table - 1 (0: none)
     uint32_t nib;        // 1: two 4-bit counters per byte (every threshold <= 15)
+    uint32_t ctr_vbits;  // cbf_local: bits of a counter byte that hold the value; the rest is the pair's epoch tag (0: no tags)
     uint32_t bf_words;
     FastMod cbf_mod, bf_mod;
     KConsts kc[GP_MAX_K_VALUES];
@@ -1109,9 +1110,12 @@ constexpr int kLocalSlots = 1 << kLocalSlotBits; // >= 2 x the counter touches o
 constexpr uint32_t kLocalEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kLSetBits = 1u << 17;   // LDS filter in front of the settled table: a candidate whose bit is clear is not in it
 
-__device__ inline void kset_put(unsigned long long* kset, uint32_t* s_kbits, uint32_t slot, uint64_t base)
+// `entry` = the k-mer's mixed hash with the bits its slot already fixes replaced by the pair's
+// epoch (see cbf_local)
+__device__ inline void kset_put(unsigned long long* kset, uint32_t* s_kbits, uint32_t slot, uint64_t base,
+                                unsigned long long entry)
 {
-    kset[slot] = base;
+    kset[slot] = entry;
     const uint32_t kb = (uint32_t)((base * 0x9E3779B97F4A7C15ULL) >> 10) & (kLSetBits - 1u);
     atomicOr(&s_kbits[kb >> 5], 1u << (kb & 31u));
 }
@@ -1137,6 +1141,21 @@ __global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first,
     fill_seed_table(seed_t); // (the barriers at the top of the pair loop come before its first use)
     const int t0 = threadIdx.x * kLPer;
     bool slot_clean = false; // uniform: the previous pair was short and has been unwound
+    const uint32_t vb = a.nib ? 0u : a.ctr_vbits, vmask = (1u << vb) - 1u, n_ep = vb ? (256u >> vb) - 1u : 0u;
+    uint32_t ep = 0, ep_k = 0; // epoch tags of the counters and of the settled table (0: not cleared yet)
+    // a counter of this workgroup's slot, as the current pair sees it / one step up
+    auto ctr_get = [&](uint32_t idx) -> uint32_t {
+        if (!vb)
+            return ctr_load<false>(a, cb, idx);
+        const uint32_t raw = cb[idx];
+        return (raw >> vb) == ep ? raw & vmask : 0u;
+    };
+    auto ctr_up = [&](uint32_t idx, uint32_t v) {
+        if (!vb)
+            ctr_increment(a, cb, idx, v);
+        else
+            cb[idx] = (uint8_t)((ep << vb) | (v + 1u));
+    };
 
     for (;;) {
     uint32_t n_ops = 0, n_ordered = 0, n_positions = 0, n_rounds = 0, n_replayed = 0, n_hits = 0;
@@ -1158,8 +1177,21 @@ __global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first,
     const uint32_t pmode = a.pair_mode ? a.pair_mode[pair] : 0u; // 0 plain, 1 census, 2 plain after a census that overflowed
     const uint32_t census = pmode == 1u ? 1u : 0u;
     const unsigned long long* const cand_bits = census ? a.cand + (a.pair_bit_off[pair] >> 6) : nullptr;
-    if (!slot_clean)
+    // Counter bytes carry the pair's epoch in their upper bits (ctr_vbits value bits below it: no
+    // counter passes its threshold): a byte whose tag is not the current pair's reads as zero, so
+    // the slot is cleared once per 2^(8 - vbits) - 1 pairs, not before every pair -- clearing 10 MiB
+    // for each of 16 000 pairs was 168 GB of writes per configs[2] step, more than the algorithmic
+    // bytes of the whole step.
+    if (vb) {
+        if (ep == 0 || ep == n_ep) {
+            zero_slot(cb, a.cbf_stride);
+            ep = 1;
+        } else {
+            ep++;
+        }
+    } else if (!slot_clean) {
         zero_slot(cb, a.cbf_stride);
+    }
     // Census pairs: the candidates are mostly later copies of k-mers that reached their threshold
     // long ago -- four counter look-ups and four filter look-ups each to learn that nothing is
     // left to do.  Once an operation finds ALL its counters >= S-1 (rule (b) at the top of the
@@ -1175,11 +1207,21 @@ __global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first,
         seg_lo < seg_hi ? (a.seg_thr[seg_lo] - 2 + ki - 1) | ((a.seg_smax[seg_lo] - 2 + ki - 1) << 16) : 0u;
     unsigned long long* const kset =
         census && a.kset_mask ? a.kset + (uint64_t)blockIdx.x * ((uint64_t)a.kset_mask + 1) : nullptr;
+    // The table's entries are epoch-tagged too, exactly: an entry is the k-mer's mixed hash (a
+    // bijection of the 64-bit hash) with bits 32.. -- which the slot index already fixes -- replaced
+    // by the pair's ordinal, so an entry of an earlier pair never compares equal and the 2 MiB table
+    // is cleared once per launch, not per pair.
     if (kset) {
-        zero_slot(reinterpret_cast<uint8_t*>(kset), ((uint64_t)a.kset_mask + 1) * 8);
+        if (ep_k == 0 || ep_k == a.kset_mask) {
+            zero_slot(reinterpret_cast<uint8_t*>(kset), ((uint64_t)a.kset_mask + 1) * 8);
+            ep_k = 1;
+        } else {
+            ep_k++;
+        }
         for (uint32_t i = threadIdx.x; i < kLSetBits / 32; i += kLBlock)
             s_kbits[i] = 0; // (the barrier at the top of the first turn comes before its first use)
     }
+    const unsigned long long kfield = (unsigned long long)a.kset_mask << 32, ktag = (unsigned long long)ep_k << 32;
 
     // A turn of this loop replays up to 512 operations, two per lane, in serial order.  Plain
     // pairs: the next 512 positions.  Census pairs: the next 512 CANDIDATES of a 2048-position
@@ -1192,6 +1234,7 @@ __global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first,
         uint32_t op_idx[kLPer][4] = {};
         uint64_t op_base[kLPer] = {};
         uint32_t op_set[kLPer] = {};
+        unsigned long long op_tag[kLPer] = {};
         __syncthreads(); // everyone is done with the previous turn (codes, table)
         if (!census) {
         if (next0 >= b_end)
@@ -1255,7 +1298,7 @@ __global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first,
                         break;
                     const uint64_t hv = h ? ext_hash(op_base[j], k, h) : op_base[j];
                     op_idx[j][h] = (uint32_t)fastmod(hv, a.cbf_mod);
-                    pack |= ctr_load<false>(a, cb, op_idx[j][h]) << (8 * h);
+                    pack |= ctr_get(op_idx[j][h]) << (8 * h);
                 }
                 op_c[j] = pack;
             }
@@ -1339,6 +1382,7 @@ __global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first,
                 const uint32_t kb = (uint32_t)(mix >> 10) & (kLSetBits - 1u);
                 // (more than half of the candidates are not in the table: most of them learn it here)
                 seen[j] = (s_kbits[kb >> 5] >> (kb & 31u)) & 1u ? kset[op_set[j]] : 0ull;
+                op_tag[j] = (mix & ~kfield) | ktag;
             }
         }
 #pragma unroll
@@ -1346,7 +1390,7 @@ __global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first,
             if (!op_state[j])
                 continue;
             n_replayed++;
-            if (kset && seen[j] == op_base[j] && op_base[j] != 0) {
+            if (kset && seen[j] == op_tag[j]) {
                 op_state[j] = 0; // settled for good and in the filter
                 n_hits++;
                 continue;
@@ -1370,7 +1414,7 @@ __global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first,
                     break;
                 const uint64_t hv = h ? ext_hash(op_base[j], k, h) : op_base[j];
                 op_idx[j][h] = (uint32_t)fastmod(hv, a.cbf_mod);
-                pack |= ctr_load<false>(a, cb, op_idx[j][h]) << (8 * h);
+                pack |= ctr_get(op_idx[j][h]) << (8 * h);
             }
             op_c[j] = pack;
         }
@@ -1393,7 +1437,7 @@ __global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first,
                     uint32_t m = 255;
                     for (uint32_t h = 0; h < a.hash_num; h++) {
                         const uint32_t c = round == 0 ? (op_c[j] >> (8 * h)) & 255u
-                                                      : ctr_load<false>(a, cb, op_idx[j][h]);
+                                                      : ctr_get(op_idx[j][h]);
                         m = min(m, c);
                     }
                     if (m >= (op_thr[j] & 0xFFFFu) || m + 1 >= (op_thr[j] >> 16)) {
@@ -1403,7 +1447,7 @@ __global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first,
                             hv[i] = ext_hash(op_base[j], k, i);
                         bf_insert(a, stream, hv);
                         if (kset && m + 1 >= (op_thr[j] >> 16))
-                            kset_put(kset, s_kbits, op_set[j], op_base[j]);
+                            kset_put(kset, s_kbits, op_set[j], op_base[j], op_tag[j]);
                         op_state[j] = 0;
                         continue;
                     }
@@ -1449,7 +1493,7 @@ __global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first,
                     continue;
                 uint32_t c[4], m = 255;
                 for (uint32_t h = 0; h < a.hash_num; h++) {
-                    c[h] = round == 0 ? (op_c[j] >> (8 * h)) & 255u : ctr_load<false>(a, cb, op_idx[j][h]);
+                    c[h] = round == 0 ? (op_c[j] >> (8 * h)) & 255u : ctr_get(op_idx[j][h]);
                     m = min(m, c[h]);
                 }
                 const uint32_t thr = op_thr[j] & 0xFFFFu;
@@ -1459,7 +1503,7 @@ __global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first,
                         for (uint32_t g = 0; g < h; g++)
                             first &= op_idx[j][g] != op_idx[j][h]; // a counter hit twice still moves by one
                         if (first)
-                            ctr_increment(a, cb, op_idx[j][h], m);
+                            ctr_up(op_idx[j][h], m);
                     }
                     m++;
                 }
@@ -1470,7 +1514,7 @@ __global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first,
                         hv[h] = ext_hash(op_base[j], k, h);
                     bf_insert(a, stream, hv);
                     if (kset && m + 1 >= (op_thr[j] >> 16))
-                        kset_put(kset, s_kbits, op_set[j], op_base[j]); // every counter is >= m now
+                        kset_put(kset, s_kbits, op_set[j], op_base[j], op_tag[j]); // every counter is >= m now
                 }
                 op_state[j] = 0;
             }
@@ -1487,7 +1531,7 @@ __global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first,
     if (n_hits)
         atomicAdd(&s_stats[6], (unsigned long long)n_hits);
     // fewer counter lines touched than a quarter of the slot holds: unwind instead of clearing
-    slot_clean = (b_end - b_start) * a.hash_num * 64 * 4 < a.cbf_stride;
+    slot_clean = !vb && (b_end - b_start) * a.hash_num * 64 * 4 < a.cbf_stride;
     if (slot_clean) {
         __syncthreads(); // the pair's last stores are done
         unwind_slot(a.reads, a.n_pos, cb, k, a.hash_num, a.cbf_mod, a.nib, b_start, b_end);
@@ -1676,6 +1720,12 @@ int stage_a_run(gp_job* job)
         // turns every increment into an atomic; end to end it is 1.5 % (config 2) to 4 %
         // (25 kbp contigs) slower, so it is opt-in: GP_STAGE_A_NIBBLE=1.
         a.nib = (max_thr <= 15 && env_u64("GP_STAGE_A_NIBBLE", 0)) ? 1u : 0u;
+        // cbf_local's epoch tags: the bits a counter value needs, the rest of the byte is the tag
+        // (GP_STAGE_A_EPOCH=0: none, every pair clears its slot)
+        uint32_t vbits = 1;
+        while ((1u << vbits) <= max_thr)
+            vbits++;
+        a.ctr_vbits = (vbits <= 6 && !a.nib && env_u64("GP_STAGE_A_EPOCH", 1)) ? vbits : 0u;
         a.cbf_stride = ((a.nib ? (p.cbf_bytes + 1) / 2 : p.cbf_bytes) + 15) / 16 * 16;
     }
     a.bf_words = (uint32_t)(p.bf_bytes / 4);

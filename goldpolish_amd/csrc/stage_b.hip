@@ -160,6 +160,11 @@ struct Shared {
     uint32_t wave_min[kWalkThreads / 64];
     unsigned long long prof_t[8], prof_n[8], prof_last;
     int32_t prof_req;
+    // make_edit's work arrays (thread 0 only): in private memory they were 1.2 KB of scratch for
+    // every lane of every workgroup
+    int32_t me_lps[224];
+    uint8_t me_prev[224];
+    uint8_t me_kmer[kMaxK];
 };
 
 enum { REQ_DONE = 0, REQ_SCAN, REQ_SITE, REQ_NEXT, REQ_BITSCAN, REQ_REFILL, REQ_SWEEP };
@@ -590,8 +595,8 @@ __device__ void make_edit(const Ctx& c, Shared& S, uint8_t draft, Best& b)
     case 2: {
         bool skipped = false;
         // run of inserted chars just left of the tail, nearest first, complemented
-        uint8_t prev[224];
-        int lps[224];
+        uint8_t* const prev = S.me_prev;
+        int* const lps = S.me_lps;
         uint32_t np = 0;
         {
             uint32_t tn = S.tn;
@@ -609,7 +614,7 @@ __device__ void make_edit(const Ctx& c, Shared& S, uint8_t draft, Best& b)
             }
         }
         if (np + b.indel_len >= k) {
-            uint8_t kmer[kMaxK];
+            uint8_t* const kmer = S.me_kmer;
             if (is_repeat_insertion(prev, (int)np, lps) ||
                 np + b.indel_len >= c.a->insertion_cap) {
                 drop_repeat_nodes(c, S, S.tn, S.ti, np);
@@ -2759,8 +2764,15 @@ int stage_b_pass(gp_job* job, uint32_t ki)
         GP_HIP(hipMemsetAsync(d_prof.p, 0, (uint64_t)job->n_contigs * 16 * 8, s));
         a.prof = d_prof.p;
     }
-    if (job->n_contigs > 3 * 256)
+    // waves per SIMD the walk is compiled for: many contigs -> more workgroups per CU at fewer
+    // registers (GP_WALK_WAVES overrides: 1, 4, 5 or 6)
+    const uint64_t walk_waves = env_u64("GP_WALK_WAVES", job->n_contigs > 3 * 256 ? 6 : 1);
+    if (walk_waves >= 6)
         hipLaunchKernelGGL(ntedit_walk<6>, dim3(job->n_contigs), dim3(kWalkThreads), 0, s, a);
+    else if (walk_waves == 5)
+        hipLaunchKernelGGL(ntedit_walk<5>, dim3(job->n_contigs), dim3(kWalkThreads), 0, s, a);
+    else if (walk_waves == 4)
+        hipLaunchKernelGGL(ntedit_walk<4>, dim3(job->n_contigs), dim3(kWalkThreads), 0, s, a);
     else
         hipLaunchKernelGGL(ntedit_walk<1>, dim3(job->n_contigs), dim3(kWalkThreads), 0, s, a);
     hipLaunchKernelGGL(materialize_kernel, dim3(b->n_tiles), dim3(256), 0, s,
