@@ -82,7 +82,8 @@ def node_share(world, rank, seed=4):
     exactly its own share of the same assembly, whatever the number of ranks."""
     from goldpolish_amd import core, synth
     rng = np.random.default_rng(seed)
-    lens = np.clip(rng.lognormal(np.log(22_000.0), 0.5, size=15000 * world), 5_000, 100_000).astype(np.int64)
+    per_gpu = int(os.environ.get("GP_BENCH_NODE_CONTIGS", "15000"))   # (a rehearsal on one GPU takes fewer)
+    lens = np.clip(rng.lognormal(np.log(22_000.0), 0.5, size=per_gpu * world), 5_000, 100_000).astype(np.int64)
     cov = 30
     cost = (lens * (1 + cov)).astype(np.uint64)
     rank_of, load = core.partition_batches(cost, world)
@@ -204,6 +205,21 @@ def split_records(lens, payload):
     for n in l:
         out.append(b[at:at + int(n)])
         at += int(n)
+    return out
+
+
+def input_order(rank_of, per_rank_records):
+    """The gathered records back in the assembly's order (the ordered collection of
+    scripts/goldpolish-reaper:51-73): batch b went to rank rank_of[b], and every rank polishes and
+    sends its batches in ascending batch order, so rank r's i-th record is the i-th batch with
+    rank_of == r.  per_rank_records[r] = list of records of rank r."""
+    nxt = [0] * len(per_rank_records)
+    out = []
+    for r in rank_of:
+        r = int(r)
+        out.append(per_rank_records[r][nxt[r]])
+        nxt[r] += 1
+    assert all(n == len(x) for n, x in zip(nxt, per_rank_records)), "records and partition do not match"
     return out
 
 

@@ -59,6 +59,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <thread>
 
 namespace gp {
 
@@ -2109,9 +2110,18 @@ int stage_a_run(gp_job* job)
             const uint32_t i = ring_tail % kRing;
             const uint32_t want_seq = ring_tail + 1;
             if (block) {
-                uint64_t spins = 0;
+                // the report of a step arrives within its few hundred microseconds: spin briefly, then
+                // yield the core between looks, and give up after a wall-clock minute
+                // (GP_STAGE_A_FEEDBACK_TIMEOUT_S), not after a number of iterations
+                uint32_t spins = 0;
+                const auto t_wait = std::chrono::steady_clock::now();
+                const double limit_s = (double)env_u64("GP_STAGE_A_FEEDBACK_TIMEOUT_S", 60);
                 while (hring[4 * i] != want_seq) {
-                    if (++spins > (1ull << 34)) {
+                    if (++spins < 4096)
+                        continue;
+                    std::this_thread::yield();
+                    if ((spins & 1023u) == 0 &&
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count() > limit_s) {
                         set_error("stage A: device stopped reporting step feedback");
                         return GP_ERR_STATE;
                     }

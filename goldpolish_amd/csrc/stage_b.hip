@@ -1429,7 +1429,15 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             }
         }
         __syncthreads();
+        // THE REQUEST PROTOCOL.  Thread 0 alone writes S.request: above (a REQ_NEXT turned into what
+        // reaches the next k-mer) and at the end of a branch below.  Every thread reads it exactly
+        // once per trip, here, between two barriers: the first makes thread 0's decision (and
+        // everything the previous trip wrote) visible, the second keeps thread 0 from rewriting it
+        // -- in ANY branch, at any point -- before the slowest wave has read it.  (Round 2 relied on
+        // each branch happening to contain a barrier ahead of its write; REQ_NEXT did not, and a wave
+        // that fell behind while another job's kernel held its CU took the next trip's branch.)
         const int req = S.request;
+        __syncthreads();
         if (req == REQ_DONE)
             break;
 
@@ -1694,15 +1702,8 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             continue;
         }
 
-        if (req == REQ_NEXT) {
-            // Everybody has read S.request before thread 0 may rewrite it at the top of the loop.
-            // Without this barrier a wave that fell behind (suspended while another job's kernel
-            // had its CU) read the NEXT request and took another branch than the rest of its
-            // workgroup: the walker's pass-count trap, once a silently different output, about one
-            // run in a hundred with a second job's filter build in flight; never seen alone.
-            __syncthreads();
-            continue;
-        }
+        if (req == REQ_NEXT)
+            continue; // thread 0 takes it from the top of the loop (the barrier after the read above covers this trip)
 
         // ------------------------------------------------------------ REQ_SITE
         if (tid == 0) {
@@ -2766,7 +2767,7 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     }
     // waves per SIMD the walk is compiled for: many contigs -> more workgroups per CU at fewer
     // registers (GP_WALK_WAVES overrides: 1, 4, 5 or 6)
-    const uint64_t walk_waves = env_u64("GP_WALK_WAVES", job->n_contigs > 3 * 256 ? 6 : 1);
+    const uint64_t walk_waves = env_u64("GP_WALK_WAVES", job->n_contigs > 3 * 256 ? 4 : 1); // (measured on 1000 x 25 kbp: 6 -> 52 ms, 5 -> 50, 4 -> 45, 1 -> 63)
     if (walk_waves >= 6)
         hipLaunchKernelGGL(ntedit_walk<6>, dim3(job->n_contigs), dim3(kWalkThreads), 0, s, a);
     else if (walk_waves == 5)

@@ -93,3 +93,21 @@ def test_pool_recycles_device_blocks():
         assert abs(core.device_pool_bytes() - pooled) < (64 << 20)
         core.device_pool_trim()
         assert core.device_pool_bytes() == 0
+
+
+def test_device_copy_of_a_result_is_what_rccl_would_send():
+    """bench.py's multi-GPU step sends the pipeline's HBM copy of the polished bytes (wrapped as a
+    torch tensor without copying): it must be the bytes the host copy holds"""
+    import torch
+    import bench
+    from goldpolish_amd import core
+    p = core.default_params(k_values=[32, 24])
+    w = synth.make_workload([12000, 90, 7000], 25, seed=91)
+    with core.Pipeline(0, p) as pipe:
+        pipe.submit(*core.batch_set_of_workload(w), tag=5)
+        r = pipe.collect(copy=False)
+        n = r["total_bytes"]
+        assert n > 15000 and r["device_ptr"]
+        t = torch.as_tensor(bench._DevView(r["device_ptr"], n), device="cuda")
+        assert t.is_cuda and t.numel() == n and t.dtype == torch.uint8
+        assert np.array_equal(t.cpu().numpy(), r["bytes"])

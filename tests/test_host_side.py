@@ -63,6 +63,52 @@ def test_gather_of_polished_segments_gloo_world2(tmp_path):
     assert "GATHER_OK" in outs[0]
 
 
+_PART_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[3])
+import torch.distributed as dist
+import bench
+from goldpolish_amd import core
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[4], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+import numpy as np, torch
+# one fixed assembly of 23 single-contig batches; every rank computes the same partition by itself
+rng = np.random.default_rng(11)
+lens = rng.integers(40, 400, size=23)
+contigs = [bytes(rng.choice(list(b"acgt"), size=int(n)).astype(np.uint8)) for n in lens]
+cost = (lens * 31).astype(np.uint64)
+rank_of, load = core.partition_batches(cost, world)
+mine = [b for b in range(len(contigs)) if rank_of[b] == rank]          # ascending: the order a rank polishes in
+polished = [contigs[b].upper() if b % 7 else b"" for b in mine]         # stand-in for the GPU path; every 7th dropped
+lens_t = torch.tensor([len(x) for x in polished], dtype=torch.int64)
+payload = torch.from_numpy(np.frombuffer(b"".join(polished) or b"\0", dtype=np.uint8).copy())[:sum(len(x) for x in polished)]
+out = bench.gather_to_rank0(lens_t, payload, rank, world)
+if rank == 0:
+    per_rank = [bench.split_records(*out[r]) for r in range(world)]
+    whole = bench.input_order(rank_of, per_rank)
+    assert whole == [c.upper() if b % 7 else b"" for b, c in enumerate(contigs)]
+    assert sorted(int(x) for x in load) == sorted(int(cost[rank_of == r].sum()) for r in range(world))
+    print("PARTITION_GATHER_OK", [int(x) for x in np.bincount(rank_of, minlength=world)])
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_partition_polish_order_gather_gloo_world2(tmp_path):
+    """the multi-GPU flow end to end on CPU ranks: gp_partition_batches (same answer on every rank)
+    -> each rank's batches in ascending order -> variable-length gather -> input order at rank 0"""
+    script = tmp_path / "part_worker.py"
+    script.write_text(_PART_WORKER)
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(ROOT), port],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "PARTITION_GATHER_OK" in outs[0]
+
+
 _ASAN = r'''
 import sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
