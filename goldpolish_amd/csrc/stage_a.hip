@@ -781,11 +781,14 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
     // record slots of its run, base a multiple of four: a record whose slot lies in it goes to the
     // ring, any other (a tile that brings a range more than the ring holds) straight to memory, so
     // a group of four is always written by one of the two ways only.
-    extern __shared__ uint32_t ring[]; // [ranges][8]
+    // (ring, counters and group bases are sized by the pair's ranges, not by the most a pair may
+    // have: 1280 ranges at GoldPolish's 10 MiB make 51 KB with the rest, three workgroups per CU
+    // where the static 2048-range arrays left room for two)
+    extern __shared__ uint32_t ring[]; // [ranges][8], then hist[ranges], then gbase[ranges] (bytes)
     __shared__ uint8_t codes[kTile + kHalo];
     __shared__ uint64_t seed_t[kSeedTableWords];
-    __shared__ uint32_t hist[kCBuckets];
-    __shared__ uint8_t gbase[kCBuckets]; // groups of four of the run that are not the ring's any more (base / 4)
+    uint32_t* const hist = ring + (size_t)c.n_buckets * 8;
+    uint8_t* const gbase = reinterpret_cast<uint8_t*>(hist + c.n_buckets); // groups of four of the run that are not the ring's any more (base / 4)
     const uint32_t pair = c.wg_pair[blockIdx.x];
     const uint32_t b = c.pair_batch[pair], ki = c.pair_ki[pair];
     const KConsts& kc = a.kc[ki];
@@ -1958,7 +1961,7 @@ int stage_a_run(gp_job* job)
                 // census_scatter: a ring of eight record slots per range in LDS (40 KB at 1280 ranges:
                 // two workgroups per CU, which is also what it likes best -- with eight per CU and
                 // records stored one by one it had 670 MB of half-written runs in flight)
-                const size_t scatter_lds = (size_t)n_buckets * 8 * sizeof(uint32_t);
+                const size_t scatter_lds = (size_t)n_buckets * (8 + 1) * sizeof(uint32_t) + ((size_t)n_buckets + 3) / 4 * 4;
                 hipStream_t sm = n_sets > 1 ? job->a_stream2 : s; // mark and pack
                 for (size_t ci = 0; ci < cohorts.size(); ci++) {
                     Cohort& co = cohorts[ci];
