@@ -9,7 +9,13 @@ import pathlib
 import shutil
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+# MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports exactly half the bytes of a WIDE COALESCED
+# STREAMING read; random 1-byte loads are reported at their 64-byte line (calibrated with
+# tools/probes/random_rmw_probe: profiles/r02_probe_pmc_traffic.json).  These kernels stream their
+# input (records, bitmaps, sequence tiles): their FETCH_SIZE is doubled in "FETCH_SIZE_corrected".
+STREAMING = ("gp::census_mark", "gp::census_pack", "gp::ntedit_scan", "gp::materialize_kernel", "gp::mask_kernel",
+             "gp::upper_kernel", "gp::copy_contigs", "gp::copy_flagged", "gp::pack_kernel", "gp::classify_kernel")
 raw = pathlib.Path("gpurun_out/profiles_raw")
 out = pathlib.Path("profiles")
 out.mkdir(exist_ok=True)
@@ -36,6 +42,11 @@ for name in ("config3", "config2", "probe"):
             for k, (n, v) in agg.items():
                 traffic.setdefault(k, {})[counter] = {"launches": n, "sum_KB": round(v, 1),
                                                       "per_launch_KB": round(v / n, 1)}
+    for k, t in traffic.items():
+        if k in STREAMING and "FETCH_SIZE" in t:
+            t["FETCH_SIZE_corrected"] = {"per_launch_KB": round(2 * t["FETCH_SIZE"]["per_launch_KB"], 1),
+                                         "sum_KB": round(2 * t["FETCH_SIZE"]["sum_KB"], 1),
+                                         "why": "wide coalesced streaming read: x2 (MI355X_MICROARCH.md, HBM)"}
     (out / f"{rnd}_{name}_pmc_traffic.json").write_text(json.dumps(traffic, indent=1, sort_keys=True))
     b = raw / f"{name}_bench.json"
     if b.exists():

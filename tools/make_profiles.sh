@@ -7,14 +7,20 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles_raw
 rm -rf $OUT && mkdir -p $OUT
+# The workloads are generated first, by an unprofiled run that only writes them to a cache: the
+# generator forks worker processes, which a process rocprofv3 has already GPU-initialised must not
+# do (round 2's profiles were full of "Aborted ... SIGTERM" from the torn-down pool).
+CACHE=gpurun_out/bench_cache
+python3 bench.py --prepare-only --cache $CACHE || exit 1
+python3 bench.py --prepare-only --cache $CACHE --workload config2 || exit 1
 # the headline workload (BASELINE.json configs[2]); two steps keep the traces small
-CMD="python3 bench.py --steps 2 --warmup 1 --no-aux --no-cpu-baseline"
+CMD="python3 bench.py --steps 2 --warmup 1 --no-aux --no-cpu-baseline --resident-steps 0 --cache $CACHE"
 timeout -k 10 500 $CMD > $OUT/config3_bench.json 2> $OUT/config3_bench.err || exit 1
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/config3_trace -- $CMD > $OUT/config3_trace.log 2>&1 || exit 1
 timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/config3_fetch -- $CMD > $OUT/config3_fetch.log 2>&1 || exit 1
 timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/config3_write -- $CMD > $OUT/config3_write.log 2>&1 || exit 1
 # configs[1] (aux in the bench line)
-C2="python3 bench.py --steps 5 --warmup 1 --no-aux --no-cpu-baseline --workload config2"
+C2="python3 bench.py --steps 5 --warmup 1 --no-aux --no-cpu-baseline --resident-steps 0 --workload config2 --cache $CACHE"
 timeout -k 10 300 $C2 > $OUT/config2_bench.json 2> $OUT/config2_bench.err || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/config2_trace -- $C2 > $OUT/config2_trace.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/config2_fetch -- $C2 > $OUT/config2_fetch.log 2>&1 || exit 1
