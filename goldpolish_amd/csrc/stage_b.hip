@@ -70,7 +70,39 @@ struct WalkArgs {
     uint32_t* err;
     unsigned long long* stats;
     unsigned long long* prof;          // development aid (GP_WALK_PROFILE): per contig, 100 MHz ticks and trips per request type
+    // long contigs walked as segments (see SegDesc); null: every contig by one workgroup
+    const struct SegDesc* segs;
+    struct SegOut* seg_out;
+    const uint32_t* contig_mode;       // per contig: 0 = walk it whole, 1 = walked as segments (the whole-contig workgroup leaves),
+                                       // 2 = a segment failed, walk it whole now (second launch)
+    uint32_t walk_phase;               // 0: first launch (whole contigs with mode 0, segments); 1: the rerun of contigs with mode 2
 };
+
+// A LONG CONTIG AS SEGMENTS.  The walk is serial per contig -- an edit changes the k-mers after it --
+// and one workgroup per contig leaves a chip of 256 CUs idle when contigs are megabases long
+// (SURVEY 8d's configs 3 and 4: 47 s per 100 Mbp, 37 of them in this kernel).  But while everything
+// right of the walker's head is untouched contig and the head is past what the last edit touched
+// ("clean"), the walker has no memory: what happens from a k-mer start p on depends on p, the
+// bases from p on and the site records alone.  So a contig is cut at positions chosen inside long
+// stretches where no record says "edit" (pick_boundaries), every segment [p_begin, p_end) is
+// walked by a workgroup of its own starting clean at p_begin, and a segment's walk is VALID only
+// if it reaches p_end clean without having worked on anything within kSegGuard of it -- then it
+// arrives exactly as its right neighbour assumed.  A segment that does not (an edit chain running
+// into the boundary) fails its contig: the contig's bases are restored from the copy the pass
+// keeps in the output slot and the contig is walked whole (second launch).  k-mer starts
+// [p_begin, p_end) map to bases [p_begin + k - 1, p_end + k - 1): a k-mer's edits touch its LAST
+// base, so neighbouring segments write disjoint bases and the node lists concatenate.
+struct SegDesc {
+    uint32_t cid;
+    uint32_t p_begin, p_end;   // k-mer starts of the segment; p_end == 0xFFFFFFFF: to the end of the contig
+    uint32_t node_first;       // first node slot of the segment inside the contig's node region
+    uint32_t node_cap;
+};
+struct SegOut {
+    uint32_t failed, n_nodes, out_len, pad;
+    unsigned long long st[4];  // scan, sites, probes, edits
+};
+constexpr uint32_t kSegGuard = 2 * kMaxK + 16 + 2 * kWalkThreads; // what the walker may read or touch ahead of its head, and then some
 
 __device__ inline uint32_t __reduce_or_sync_compat(uint32_t v)
 {
@@ -165,6 +197,7 @@ struct Shared {
     int32_t me_lps[224];
     uint8_t me_prev[224];
     uint8_t me_kmer[kMaxK];
+    uint32_t seg_failed;      // a segment's walk worked on something too close to its end: its contig is walked whole
 };
 
 enum { REQ_DONE = 0, REQ_SCAN, REQ_SITE, REQ_NEXT, REQ_BITSCAN, REQ_REFILL, REQ_SWEEP };
@@ -1164,12 +1197,26 @@ __global__ __launch_bounds__(kWalkThreads, 6) void ntedit_site_eval(WalkArgs a, 
 // fastest single walk); 6 = 80 registers (six per CU; some spills).  With thousands of contigs
 // the walk is throughput-bound on resident workgroups and the tight build is 17 % faster; with a
 // few hundred it is latency-bound and the roomy one is 8 % faster (stage_b_pass picks).
-template <int kMinWaves>
+template <int kMinWaves, bool SEG>
 __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs a)
 {
     __shared__ Shared S;
-    const uint32_t cid = blockIdx.x;
     const uint32_t tid = threadIdx.x;
+    uint32_t cid = blockIdx.x;
+    uint32_t seg_begin = 0, seg_end = 0xFFFFFFFFu, seg_index = 0; // k-mer starts this workgroup walks
+    if (SEG) {
+        seg_index = blockIdx.x;
+        const SegDesc sd = a.segs[seg_index];
+        if (sd.p_begin == sd.p_end)
+            return; // unused slot
+        cid = sd.cid;
+        seg_begin = sd.p_begin;
+        seg_end = sd.p_end;
+    } else if (a.contig_mode) {
+        const uint32_t mode = a.contig_mode[cid];
+        if (a.walk_phase == 0 ? mode != 0u : mode != 2u)
+            return; // walked as segments / nothing to do again
+    }
     if (a.dropped[cid])
         return;
     const uint32_t len = a.len_cur[cid];
@@ -1186,12 +1233,57 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
     c.seq = a.seq + a.off[cid];
     c.nd = a.nodes + a.node_off[cid];
     c.node_cap = (uint32_t)(a.node_off[cid + 1] - a.node_off[cid]);
+    if (SEG) {
+        c.nd += a.segs[seg_index].node_first;
+        c.node_cap = a.segs[seg_index].node_cap;
+    }
     c.bf = a.bf + ((uint64_t)a.contig_batch[cid] * a.n_k + a.ki) * a.bf_words;
     c.len = len;
     c.k = a.k;
     const uint32_t k = a.k, jump = a.jump;
+    // the last k-mer start the sweep of this workgroup settles (a whole contig: every one)
+    const bool seg_open = SEG && seg_end != 0xFFFFFFFFu; // a right neighbour takes over at seg_end
 
-    if (tid == 0) {
+    if (tid == 0)
+        S.seg_failed = 0;
+    if (SEG && seg_begin != 0) {
+        // start clean at seg_begin: the head parked just left of it, everything from it on untouched
+        if (tid == 0) {
+            for (uint32_t code = 0; code < 5; code++) {
+                uint64_t s = code < 4 ? seed_of_code(code) : 0ULL;
+                S.ht.f[code] = s;
+                S.ht.r[code] = s;
+                S.ht.fk[code] = sroln(s, k);
+                S.ht.rk[code] = sroln(s, k);
+            }
+            S.st_scan = S.st_sites = S.st_probes = S.st_edits = 0;
+            S.hi = seg_begin - 1;
+            S.ti = S.hi + k - 1;
+            S.hn = S.tn = 0;
+            S.nn = 1;
+            Node root;
+            root.type = 0;
+            root.s = seg_begin - 1;
+            root.e = len - 1;
+            root.c = 0;
+            c.nd[0] = root;
+            S.fh = S.rh = 0;
+            S.char_in = 0;
+            S.cur_tested = 1;
+            S.min_tested_ti = 0;
+            S.clean_from = 0;
+            S.need_hash = 0;
+            S.fast_head = 0;
+            S.confirmed = 0;
+            S.nc_next = 0;
+            S.cw0 = 0;
+            S.cwn = 0;
+            S.cp0 = 0;
+            S.cpn = 0;
+            nd_cache_drop(S);
+            S.request = REQ_NEXT;
+        }
+    } else if (tid == 0) {
         for (uint32_t code = 0; code < 5; code++) {
             uint64_t s = code < 4 ? seed_of_code(code) : 0ULL;
             S.ht.f[code] = s;
@@ -1288,7 +1380,12 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             // (the first k-mer looked at starts at hi, or at hi + 1 when the one at hi has been tested)
             const bool clean = plain && S.hn == S.tn && S.hi + (S.cur_tested ? 1u : 0u) >= S.clean_from &&
                                a.bm_site != nullptr;
-            if (clean && a.site_rec != nullptr) {
+            if (SEG && seg_open && !(clean && a.site_rec != nullptr) && (uint64_t)S.hi + kSegGuard >= seg_end) {
+                // the walker is still among what an edit touched this close to the segment's end: it
+                // would not arrive there the way the next segment assumed
+                S.seg_failed = 1;
+                S.request = REQ_DONE;
+            } else if (clean && a.site_rec != nullptr) {
                 // everything from the head on is untouched contig and every site there has its
                 // record: all lanes sweep forward to the first site that ends in an edit
                 S.bit_from = S.hi + (S.cur_tested ? 1u : 0u);
@@ -1447,7 +1544,8 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             // behind (a reverted trial writes the draft base back in upper case, soft masking
             // lower-cases it), all independent of each other, so every lane settles its own; the
             // first site that ends in an edit stops the sweep and thread 0 applies it.
-            const uint32_t last_p = len - k, p_start = S.bit_from;
+            const uint32_t p_start = S.bit_from;
+            const uint32_t last_p = (SEG && seg_open) ? min(len - k, seg_end - 1) : len - k; // last k-mer start this workgroup settles
             const uint64_t base_bit = a.off[cid];
             uint32_t p = p_start, first = 0xFFFFFFFFu;
             uint32_t my_sites = 0;
@@ -1533,7 +1631,10 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                 if (first == 0xFFFFFFFFu) {
                     if (p_start <= last_p)
                         S.st_scan += last_p + 1 - p_start;
-                    S.request = REQ_DONE; // nothing left that the reference could act on
+                    S.request = REQ_DONE; // nothing left that the reference could act on (a segment: arrived clean at its end)
+                } else if (SEG && seg_open && (uint64_t)first + kSegGuard >= seg_end) {
+                    S.seg_failed = 1; // an edit this close to the segment's end
+                    S.request = REQ_DONE;
                 } else {
                     S.st_scan += first - p_start + 1;
                     const SiteRec r = a.site_rec[base_bit + first];
@@ -1938,6 +2039,50 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
     // ---- lay the edited contig out: every live node learns where its bytes go
     // (materialize_kernel then copies with the whole chip)
     __syncthreads();
+    if (SEG) {
+        // a segment's nodes with offsets from the segment's own start; merge_segments puts the
+        // segments of a contig behind one another.  Bases [b_lo, b_hi) are this segment's.
+        if (tid == 0) {
+            const uint32_t b_lo = seg_begin ? seg_begin + k - 1 : 0u, b_hi = seg_open ? seg_end + k - 1 : len;
+            uint32_t o = 0, live = 0;
+            const uint32_t nn = S.nn;
+            for (uint32_t ni = 0; ni < nn; ni++) {
+                Node n = c.nd[ni];
+                if (n.type == -1)
+                    break;
+                live++;
+                if (n.type == 0) {
+                    uint32_t lo = max(n.s, b_lo), hi_ex = 0;
+                    if (n.s <= len) {
+                        uint32_t cnt = n.e - n.s + 1;
+                        if (cnt > len - n.s)
+                            cnt = len - n.s;
+                        hi_ex = min(n.s + cnt, b_hi);
+                    }
+                    if (hi_ex < lo)
+                        hi_ex = lo;
+                    c.nd[ni].s = lo;
+                    c.nd[ni].c = o;
+                    c.nd[ni].e = hi_ex; // exclusive
+                    o += hi_ex - lo;
+                } else {
+                    c.nd[ni].s = o;
+                    o++;
+                }
+            }
+            SegOut so;
+            so.failed = S.seg_failed;
+            so.n_nodes = live;
+            so.out_len = o;
+            so.pad = 0;
+            so.st[0] = S.st_scan;
+            so.st[1] = S.st_sites;
+            so.st[2] = S.st_probes;
+            so.st[3] = S.st_edits;
+            a.seg_out[seg_index] = so;
+        }
+        return;
+    }
     if (tid == 0) {
         uint32_t o = 0, live = 0;
         const uint32_t nn = S.nn;
@@ -1982,6 +2127,139 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
     }
 }
 
+
+// ---- long contigs as segments (SegDesc): where to cut, and how the pieces come back together
+struct BoundaryReq {
+    uint32_t cid, nominal, half_window, pad;
+};
+
+// One workgroup per wanted cut: the longest stretch of k-mer starts within half_window of `nominal`
+// whose site records all say "no edit" (the sweep passes such sites without stopping); the cut goes
+// to the END of that stretch, so that the whole stretch lies between the left segment's last edit
+// and the cut.  0xFFFFFFFF: no stretch of kSegGuard + 64 quiet starts there -- the two segments stay one.
+__global__ __launch_bounds__(256) void pick_boundaries(WalkArgs a, const BoundaryReq* req, uint32_t* cut)
+{
+    __shared__ unsigned long long stops[256]; // a bit per k-mer start of the window: its record says "edit"
+    const BoundaryReq r = req[blockIdx.x];
+    const uint32_t len = a.len_cur[r.cid], k = a.k;
+    const uint64_t base = a.off[r.cid];
+    const uint32_t lo = r.nominal > r.half_window ? r.nominal - r.half_window : 1u;
+    const uint32_t span = min(2u * r.half_window, 256u * 64u);
+    const uint32_t hi = min(lo + span, len > 2 * k ? len - 2 * k : 0u); // exclusive
+    unsigned long long m = 0;
+    for (uint32_t i = 0; i < 64; i++) {
+        const uint32_t p = lo + threadIdx.x * 64 + i;
+        if (p < hi) {
+            const SiteRec rec = a.site_rec[base + p];
+            if ((rec.flags & 1u) && rec.type != 0)
+                m |= 1ull << i;
+        } else {
+            m |= 1ull << i; // outside the window: ends a stretch
+        }
+    }
+    stops[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t best_len = 0, best_end = 0, run = 0;
+        for (uint32_t i = 0; i < 256u * 64u; i++) {
+            const bool stop = (stops[i >> 6] >> (i & 63)) & 1ull;
+            if (stop) {
+                if (run > best_len) {
+                    best_len = run;
+                    best_end = lo + i; // the first start past the stretch
+                }
+                run = 0;
+            } else {
+                run++;
+            }
+        }
+        if (run > best_len) {
+            best_len = run;
+            best_end = lo + 256u * 64u;
+        }
+        cut[blockIdx.x] = best_len >= kSegGuard + 64 ? best_end : 0xFFFFFFFFu;
+    }
+}
+
+struct SegContig {
+    uint32_t cid, seg_first, n_seg, pad;
+};
+
+// One workgroup per segmented contig, after its segments' walks.  All valid: the segments' node
+// lists move to the head of the contig's node region, one behind the other, with their output
+// offsets shifted, and the contig's length, node count and counters are set as one walk would have
+// set them.  Any failed: the contig's bases come back from the copy in its output slot and the
+// contig is marked for the whole-contig walk that follows.
+__global__ __launch_bounds__(256) void merge_segments(WalkArgs a, const SegContig* list, uint32_t* contig_mode)
+{
+    __shared__ uint32_t s_fail, s_nodes, s_len;
+    const SegContig sc = list[blockIdx.x];
+    const uint32_t cid = sc.cid, tid = threadIdx.x;
+    if (a.dropped[cid])
+        return;
+    if (tid == 0) {
+        uint32_t f = 0, nn = 0, ol = 0;
+        for (uint32_t j = 0; j < sc.n_seg; j++) {
+            const SegOut& so = a.seg_out[sc.seg_first + j];
+            f |= so.failed;
+            nn += so.n_nodes;
+            ol += so.out_len;
+        }
+        s_fail = f;
+        s_nodes = nn;
+        s_len = ol;
+    }
+    __syncthreads();
+    const uint32_t len = a.len_cur[cid];
+    if (s_fail) {
+        const uint8_t* bak = a.out + a.off[cid];
+        uint8_t* seq = a.seq + a.off[cid];
+        for (uint32_t i = tid; i < len; i += 256)
+            seq[i] = bak[i];
+        if (tid == 0)
+            contig_mode[cid] = 2u;
+        return;
+    }
+    Node* const nd = a.nodes + a.node_off[cid];
+    uint32_t dst0 = 0, out0 = 0;
+    for (uint32_t j = 0; j < sc.n_seg; j++) {
+        const SegOut so = a.seg_out[sc.seg_first + j];
+        const uint32_t src0 = a.segs[sc.seg_first + j].node_first;
+        for (uint32_t i0 = 0; i0 < so.n_nodes; i0 += 256) {
+            const uint32_t i = i0 + tid;
+            Node n{};
+            if (i < so.n_nodes)
+                n = nd[src0 + i];
+            __syncthreads(); // dst <= src: the chunk is read before any of it is overwritten
+            if (i < so.n_nodes) {
+                if (n.type == 0)
+                    n.c += out0;
+                else
+                    n.s += out0;
+                nd[dst0 + i] = n;
+            }
+            __syncthreads();
+        }
+        dst0 += so.n_nodes;
+        out0 += so.out_len;
+    }
+    if (tid == 0) {
+        uint32_t o = s_len;
+        a.n_nodes[cid] = s_nodes;
+        if ((uint64_t)o > a.off[cid + 1] - a.off[cid]) {
+            atomicOr(a.err, 1024u); // the edited contig no longer fits its slot (as in the walk's own layout)
+            o = 0;
+            a.n_nodes[cid] = 0;
+        }
+        a.len_next[cid] = o;
+        unsigned long long st[4] = { 0, 0, 0, 0 };
+        for (uint32_t j = 0; j < sc.n_seg; j++)
+            for (int q = 0; q < 4; q++)
+                st[q] += a.seg_out[sc.seg_first + j].st[q];
+        for (int q = 0; q < 4; q++)
+            atomicAdd(&a.stats[q], st[q]);
+    }
+}
 
 // copies output tile blockIdx.x of contig blockIdx.y
 __global__ __launch_bounds__(256) void materialize_kernel(const uint8_t* seq, uint8_t* out,
@@ -2758,6 +3036,97 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     // 2. the ordered walk, one workgroup per contig; 3. copy the edited contigs out
     if ((rc = job->t_walk.begin(s, job->h_contig_off[job->n_contigs])) != GP_OK)
         return rc;
+    // 2a. contigs of several segment lengths are cut into segments, each walked by a workgroup of
+    // its own (SegDesc above).  GP_WALK_SEG: k-mer starts per segment (0: never cut), default 65536.
+    const uint64_t seg_len = env_u64("GP_WALK_SEG", 65536);
+    std::vector<SegDesc> h_segs;
+    std::vector<SegContig> h_segc;
+    {
+        bool any_long = false;
+        for (uint32_t c = 0; seg_len && a.site_rec && c < job->n_contigs && !any_long; c++)
+            any_long = job->h_contig_off[c + 1] - job->h_contig_off[c] >= 2 * seg_len;
+        if (any_long) {
+            // the contigs' current lengths (edits of the earlier passes have changed them)
+            std::vector<uint32_t> h_len(job->n_contigs);
+            std::vector<uint8_t> h_drop(job->n_contigs);
+            GP_HIP(hipMemcpyAsync(h_len.data(), a.len_cur, (size_t)job->n_contigs * 4, hipMemcpyDeviceToHost, s));
+            GP_HIP(hipMemcpyAsync(h_drop.data(), a.dropped, job->n_contigs, hipMemcpyDeviceToHost, s));
+            GP_HIP(hipStreamSynchronize(s));
+            const uint32_t half_window = (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(1024, seg_len / 8));
+            std::vector<BoundaryReq> h_req;
+            std::vector<uint32_t> req_first(job->n_contigs + 1, 0);
+            for (uint32_t c = 0; c < job->n_contigs; c++) {
+                req_first[c] = (uint32_t)h_req.size();
+                if (h_drop[c] || h_len[c] < 2 * seg_len)
+                    continue;
+                for (uint64_t p = seg_len; p + seg_len <= h_len[c]; p += seg_len)
+                    h_req.push_back({ c, (uint32_t)p, half_window, 0 });
+            }
+            req_first[job->n_contigs] = (uint32_t)h_req.size();
+            if (!h_req.empty()) {
+                std::vector<uint32_t> h_cut(h_req.size());
+                if ((rc = b->seg_req.ensure(h_req.size() * sizeof(BoundaryReq))) != GP_OK ||
+                    (rc = b->seg_cut.ensure(h_req.size())) != GP_OK)
+                    return rc;
+                GP_HIP(hipMemcpyAsync(b->seg_req.p, h_req.data(), h_req.size() * sizeof(BoundaryReq), hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(pick_boundaries, dim3((unsigned)h_req.size()), dim3(256), 0, s, a,
+                                   reinterpret_cast<const BoundaryReq*>(b->seg_req.p), b->seg_cut.p);
+                GP_HIP(hipGetLastError());
+                GP_HIP(hipMemcpyAsync(h_cut.data(), b->seg_cut.p, h_cut.size() * 4, hipMemcpyDeviceToHost, s));
+                GP_HIP(hipStreamSynchronize(s));
+                const uint32_t force = (uint32_t)env_u64("GP_WALK_SEG_FORCE", 0); // tests: cut at the nominal positions whatever the records say
+                for (uint32_t c = 0; c < job->n_contigs; c++) {
+                    std::vector<uint32_t> cuts;
+                    for (uint32_t i = req_first[c]; i < req_first[c + 1]; i++) {
+                        const uint32_t at = force ? h_req[i].nominal : h_cut[i];
+                        const uint32_t prev = cuts.empty() ? 0u : cuts.back();
+                        if (at != 0xFFFFFFFFu && at >= prev + 4 * kSegGuard && (uint64_t)at + 4 * kSegGuard < h_len[c])
+                            cuts.push_back(at);
+                    }
+                    if (cuts.empty())
+                        continue;
+                    const uint64_t region = b->h_node_off[c + 1] - b->h_node_off[c];
+                    SegContig sc{ c, (uint32_t)h_segs.size(), (uint32_t)cuts.size() + 1, 0 };
+                    auto node_at = [&](uint32_t p) { return (uint32_t)(region * (uint64_t)p / h_len[c]); };
+                    for (size_t j = 0; j <= cuts.size(); j++) {
+                        SegDesc d;
+                        d.cid = c;
+                        d.p_begin = j ? cuts[j - 1] : 0u;
+                        d.p_end = j < cuts.size() ? cuts[j] : 0xFFFFFFFFu;
+                        d.node_first = node_at(d.p_begin);
+                        d.node_cap = (j < cuts.size() ? node_at(cuts[j]) : (uint32_t)region) - d.node_first;
+                        h_segs.push_back(d);
+                    }
+                    h_segc.push_back(sc);
+                }
+            }
+        }
+    }
+    if (!h_segs.empty()) {
+        std::vector<uint32_t> h_mode(job->n_contigs, 0);
+        for (const SegContig& sc : h_segc)
+            h_mode[sc.cid] = 1;
+        if ((rc = b->seg_desc.ensure(h_segs.size() * sizeof(SegDesc))) != GP_OK ||
+            (rc = b->seg_out.ensure(h_segs.size() * sizeof(SegOut))) != GP_OK ||
+            (rc = b->seg_contigs.ensure(h_segc.size() * sizeof(SegContig))) != GP_OK ||
+            (rc = b->contig_mode.ensure(job->n_contigs)) != GP_OK)
+            return rc;
+        GP_HIP(hipMemcpyAsync(b->seg_desc.p, h_segs.data(), h_segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice, s));
+        GP_HIP(hipMemcpyAsync(b->seg_contigs.p, h_segc.data(), h_segc.size() * sizeof(SegContig), hipMemcpyHostToDevice, s));
+        GP_HIP(hipMemcpyAsync(b->contig_mode.p, h_mode.data(), h_mode.size() * 4, hipMemcpyHostToDevice, s));
+        GP_HIP(hipMemsetAsync(b->seg_out.p, 0, h_segs.size() * sizeof(SegOut), s));
+        // the pass's input of every segmented contig, kept in its (still unused) output slot: what a
+        // failed segment's contig is walked from again
+        for (const SegContig& sc : h_segc) {
+            const uint64_t o = b->h_off[sc.cid];
+            GP_HIP(hipMemcpyAsync(a.out + o, a.seq + o, b->h_off[sc.cid + 1] - o, hipMemcpyDeviceToDevice, s));
+        }
+        GP_HIP(hipStreamSynchronize(s)); // the host vectors above are gone when this function returns
+        a.segs = reinterpret_cast<const SegDesc*>(b->seg_desc.p);
+        a.seg_out = reinterpret_cast<SegOut*>(b->seg_out.p);
+        a.contig_mode = b->contig_mode.p;
+        a.walk_phase = 0;
+    }
     DevBuf<unsigned long long> d_prof;
     if (getenv("GP_WALK_PROFILE")) {
         if ((rc = d_prof.alloc((uint64_t)job->n_contigs * 16)) != GP_OK)
@@ -2766,16 +3135,24 @@ int stage_b_pass(gp_job* job, uint32_t ki)
         a.prof = d_prof.p;
     }
     // waves per SIMD the walk is compiled for: many contigs -> more workgroups per CU at fewer
-    // registers (GP_WALK_WAVES overrides: 1, 4, 5 or 6)
+    // registers (GP_WALK_WAVES overrides: 1 or 4)
     const uint64_t walk_waves = env_u64("GP_WALK_WAVES", job->n_contigs > 3 * 256 ? 4 : 1); // (measured on 1000 x 25 kbp: 6 -> 52 ms, 5 -> 50, 4 -> 45, 1 -> 63)
-    if (walk_waves >= 6)
-        hipLaunchKernelGGL(ntedit_walk<6>, dim3(job->n_contigs), dim3(kWalkThreads), 0, s, a);
-    else if (walk_waves == 5)
-        hipLaunchKernelGGL(ntedit_walk<5>, dim3(job->n_contigs), dim3(kWalkThreads), 0, s, a);
-    else if (walk_waves == 4)
-        hipLaunchKernelGGL(ntedit_walk<4>, dim3(job->n_contigs), dim3(kWalkThreads), 0, s, a);
-    else
-        hipLaunchKernelGGL(ntedit_walk<1>, dim3(job->n_contigs), dim3(kWalkThreads), 0, s, a);
+    auto launch_walk = [&](unsigned grid, bool seg) {
+        if (seg)
+            hipLaunchKernelGGL((ntedit_walk<1, true>), dim3(grid), dim3(kWalkThreads), 0, s, a);
+        else if (walk_waves >= 4)
+            hipLaunchKernelGGL((ntedit_walk<4, false>), dim3(grid), dim3(kWalkThreads), 0, s, a);
+        else
+            hipLaunchKernelGGL((ntedit_walk<1, false>), dim3(grid), dim3(kWalkThreads), 0, s, a);
+    };
+    launch_walk(job->n_contigs, false);
+    if (!h_segs.empty()) {
+        launch_walk((unsigned)h_segs.size(), true);
+        hipLaunchKernelGGL(merge_segments, dim3((unsigned)h_segc.size()), dim3(256), 0, s, a,
+                           reinterpret_cast<const SegContig*>(b->seg_contigs.p), b->contig_mode.p);
+        a.walk_phase = 1; // contigs a failed segment sent back: whole, from the restored bases
+        launch_walk(job->n_contigs, false);
+    }
     hipLaunchKernelGGL(materialize_kernel, dim3(b->n_tiles), dim3(256), 0, s,
                        (const uint8_t*)a.seq, a.out, a.off, (const uint32_t*)a.len_next,
                        (const uint8_t*)a.dropped, (const Node*)a.nodes, a.node_off,

@@ -10,7 +10,7 @@ rm -rf $OUT && mkdir -p $OUT
 # The workloads are generated first, by an unprofiled run that only writes them to a cache: the
 # generator forks worker processes, which a process rocprofv3 has already GPU-initialised must not
 # do (round 2's profiles were full of "Aborted ... SIGTERM" from the torn-down pool).
-CACHE=gpurun_out/bench_cache
+CACHE=/tmp/gp_bench_cache   # (not under gpurun_out/: 4 GB of generated reads must not travel back)
 python3 bench.py --prepare-only --cache $CACHE || exit 1
 python3 bench.py --prepare-only --cache $CACHE --workload config2 || exit 1
 # the headline workload (BASELINE.json configs[2]); two steps keep the traces small
