@@ -29,6 +29,8 @@
 #include "gp_internal.h"
 #include "gp_bc.h"
 
+#include <chrono>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -1633,7 +1635,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                         S.st_scan += last_p + 1 - p_start;
                     S.request = REQ_DONE; // nothing left that the reference could act on (a segment: arrived clean at its end)
                 } else if (SEG && seg_open && (uint64_t)first + kSegGuard >= seg_end) {
-                    S.seg_failed = 1; // an edit this close to the segment's end
+                    S.seg_failed = 2; // an edit this close to the segment's end
                     S.request = REQ_DONE;
                 } else {
                     S.st_scan += first - p_start + 1;
@@ -3074,6 +3076,12 @@ int stage_b_pass(gp_job* job, uint32_t ki)
                 GP_HIP(hipGetLastError());
                 GP_HIP(hipMemcpyAsync(h_cut.data(), b->seg_cut.p, h_cut.size() * 4, hipMemcpyDeviceToHost, s));
                 GP_HIP(hipStreamSynchronize(s));
+                if (getenv("GP_WALK_SEG_DEBUG")) {
+                    size_t found = 0;
+                    for (uint32_t x : h_cut)
+                        found += x != 0xFFFFFFFFu;
+                    fprintf(stderr, "WALKSEG k=%u: %zu cuts wanted, %zu found\n", a.k, h_cut.size(), found);
+                }
                 const uint32_t force = (uint32_t)env_u64("GP_WALK_SEG_FORCE", 0); // tests: cut at the nominal positions whatever the records say
                 for (uint32_t c = 0; c < job->n_contigs; c++) {
                     std::vector<uint32_t> cuts;
@@ -3145,13 +3153,47 @@ int stage_b_pass(gp_job* job, uint32_t ki)
         else
             hipLaunchKernelGGL((ntedit_walk<1, false>), dim3(grid), dim3(kWalkThreads), 0, s, a);
     };
+    const bool seg_dbg = getenv("GP_WALK_SEG_DEBUG") != nullptr;
+    auto lap = [&](const char* what) { // development aid: wall time of a step of the segmented walk
+        static thread_local std::chrono::steady_clock::time_point t0;
+        if (!seg_dbg)
+            return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        if (what)
+            fprintf(stderr, "WALKSEG k=%u: %s %.2f ms\n", a.k, what, std::chrono::duration<double, std::milli>(now - t0).count());
+        t0 = now;
+    };
+    lap(nullptr);
     launch_walk(job->n_contigs, false);
+    lap("whole contigs");
     if (!h_segs.empty()) {
         launch_walk((unsigned)h_segs.size(), true);
+        lap("segments");
         hipLaunchKernelGGL(merge_segments, dim3((unsigned)h_segc.size()), dim3(256), 0, s, a,
                            reinterpret_cast<const SegContig*>(b->seg_contigs.p), b->contig_mode.p);
+        lap("merge");
         a.walk_phase = 1; // contigs a failed segment sent back: whole, from the restored bases
         launch_walk(job->n_contigs, false);
+        lap("rerun");
+        if (getenv("GP_WALK_SEG_DEBUG")) {
+            GP_HIP(hipStreamSynchronize(s));
+            std::vector<SegOut> so(h_segs.size());
+            GP_HIP(hipMemcpy(so.data(), b->seg_out.p, so.size() * sizeof(SegOut), hipMemcpyDeviceToHost));
+            uint32_t f1 = 0, f2 = 0, bad_contigs = 0;
+            for (const SegContig& sc : h_segc) {
+                bool bad = false;
+                for (uint32_t j = 0; j < sc.n_seg; j++) {
+                    f1 += so[sc.seg_first + j].failed == 1;
+                    f2 += so[sc.seg_first + j].failed == 2;
+                    bad |= so[sc.seg_first + j].failed != 0;
+                }
+                bad_contigs += bad;
+            }
+            fprintf(stderr, "WALKSEG k=%u: %zu contigs in %zu segments; failed segments: %u (walker not clean near the end) + %u "
+                            "(edit near the end); contigs walked whole again: %u\n",
+                    a.k, h_segc.size(), h_segs.size(), f1, f2, bad_contigs);
+        }
     }
     hipLaunchKernelGGL(materialize_kernel, dim3(b->n_tiles), dim3(256), 0, s,
                        (const uint8_t*)a.seq, a.out, a.off, (const uint32_t*)a.len_next,
