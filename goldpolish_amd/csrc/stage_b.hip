@@ -677,7 +677,15 @@ __device__ void make_edit(const Ctx& c, Shared& S, uint8_t draft, Best& b)
             S.st_edits++;
             S.clean_from = max(S.clean_from, S.ti); // k-mers from the draft base on are untouched
         } else {
-            S.clean_from = c.len;
+            // The insertion was refused (it would have repeated what was inserted just before) and
+            // the walker moved on to the next accepted k-mer, [hi, ti], which it does not test
+            // (the reference's loop rolls on from it).  That k-mer starts at or right of the old
+            // tail, the refused insertion wrote nothing there, and drop_repeat_nodes only took
+            // nodes left of it: k-mers from hi + 1 on are untouched contig again, the records hold.
+            // (Rounds 1-2 gave up here -- clean_from = len -- and worked every later site of the
+            // contig out on the spot: on a near-saturated filter, where such refusals are common,
+            // that was most of a long contig's walk.)
+            S.clean_from = max(S.clean_from, S.hi < c.len ? S.hi + 1 : c.len);
         }
         break;
     }
