@@ -88,7 +88,7 @@ struct WalkArgs {
 // bases from p on and the site records alone.  So a contig is cut at positions chosen inside long
 // stretches where no record says "edit" (pick_boundaries), every segment [p_begin, p_end) is
 // walked by a workgroup of its own starting clean at p_begin, and a segment's walk is VALID only
-// if it reaches p_end clean without having worked on anything within kSegGuard of it -- then it
+// if it reaches p_end clean without having worked on anything within seg_guard(k) of it -- then it
 // arrives exactly as its right neighbour assumed.  A segment that does not (an edit chain running
 // into the boundary) fails its contig: the contig's bases are restored from the copy the pass
 // keeps in the output slot and the contig is walked whole (second launch).  k-mer starts
@@ -104,7 +104,13 @@ struct SegOut {
     uint32_t failed, n_nodes, out_len, pad;
     unsigned long long st[4];  // scan, sites, probes, edits
 };
-constexpr uint32_t kSegGuard = 2 * kMaxK + 16 + 2 * kWalkThreads; // what the walker may read or touch ahead of its head, and then some
+// How close to its end a segment's walker may still WORK (anything but sweep over records): the
+// base a k-mer start q owns is q + k - 1, the right neighbour writes bases from seg_end + k - 1 on,
+// and a site worked out at head h reads bases up to h + 2k + 12 (a deletion up to 10 past the
+// tail).  With h + k + 32 < seg_end nothing the walker reads or writes can be the neighbour's;
+// scans near the end are shortened to match (see REQ_SCAN's n).
+__host__ __device__ inline uint32_t seg_guard(uint32_t k) { return k + 32; }
+constexpr uint32_t kSegGuard = kMaxK + 32; // its largest value (host-side spacing of cuts)
 
 __device__ inline uint32_t __reduce_or_sync_compat(uint32_t v)
 {
@@ -1390,9 +1396,11 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             // (the first k-mer looked at starts at hi, or at hi + 1 when the one at hi has been tested)
             const bool clean = plain && S.hn == S.tn && S.hi + (S.cur_tested ? 1u : 0u) >= S.clean_from &&
                                a.bm_site != nullptr;
-            if (SEG && seg_open && !(clean && a.site_rec != nullptr) && (uint64_t)S.hi + kSegGuard >= seg_end) {
-                // the walker is still among what an edit touched this close to the segment's end: it
-                // would not arrive there the way the next segment assumed
+            if (SEG && seg_open &&
+                ((clean && a.site_rec != nullptr) ? S.hi + (S.cur_tested ? 1u : 0u) > seg_end
+                                                  : (uint64_t)S.hi + seg_guard(k) >= seg_end)) {
+                // the walker is still among what an edit touched this close to the segment's end (or
+                // has jumped past the end): it does not arrive there the way the next segment assumed
                 S.seg_failed = 1;
                 S.request = REQ_DONE;
             } else if (clean && a.site_rec != nullptr) {
@@ -1494,6 +1502,8 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                     // from clean_from on the records answer -- hash only what an edit has touched
                     if (S.hn == S.tn && S.clean_from > S.hi + j0 && a.site_rec != nullptr)
                         n = min(n, S.clean_from - (S.hi + j0));
+                    if (SEG && seg_open) // a site this scan finds must be workable inside the segment (hi + guard < seg_end holds here)
+                        n = min(n, seg_end - (k + 13) - (S.hi + j0));
                     if (n == 0) {
                         S.request = REQ_DONE; // the next roll would fail: end of contig
                     } else {
@@ -1642,7 +1652,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                     if (p_start <= last_p)
                         S.st_scan += last_p + 1 - p_start;
                     S.request = REQ_DONE; // nothing left that the reference could act on (a segment: arrived clean at its end)
-                } else if (SEG && seg_open && (uint64_t)first + kSegGuard >= seg_end) {
+                } else if (SEG && seg_open && (uint64_t)first + seg_guard(k) >= seg_end) {
                     S.seg_failed = 2; // an edit this close to the segment's end
                     S.request = REQ_DONE;
                 } else {
@@ -2146,7 +2156,7 @@ struct BoundaryReq {
 // One workgroup per wanted cut: the longest stretch of k-mer starts within half_window of `nominal`
 // whose site records all say "no edit" (the sweep passes such sites without stopping); the cut goes
 // to the END of that stretch, so that the whole stretch lies between the left segment's last edit
-// and the cut.  0xFFFFFFFF: no stretch of kSegGuard + 64 quiet starts there -- the two segments stay one.
+// and the cut.  0xFFFFFFFF: no stretch of seg_guard(k) + 16 quiet starts there -- the two segments stay one.
 __global__ __launch_bounds__(256) void pick_boundaries(WalkArgs a, const BoundaryReq* req, uint32_t* cut)
 {
     __shared__ unsigned long long stops[256]; // a bit per k-mer start of the window: its record says "edit"
@@ -2187,7 +2197,7 @@ __global__ __launch_bounds__(256) void pick_boundaries(WalkArgs a, const Boundar
             best_len = run;
             best_end = lo + 256u * 64u;
         }
-        cut[blockIdx.x] = best_len >= kSegGuard + 64 ? best_end : 0xFFFFFFFFu;
+        cut[blockIdx.x] = best_len >= seg_guard(k) + 16 ? best_end : 0xFFFFFFFFu;
     }
 }
 
