@@ -78,6 +78,8 @@ struct WalkArgs {
     const uint32_t* contig_mode;       // per contig: 0 = walk it whole, 1 = walked as segments (the whole-contig workgroup leaves),
                                        // 2 = a segment failed, walk it whole now (second launch)
     uint32_t walk_phase;               // 0: first launch (whole contigs with mode 0, segments); 1: the rerun of contigs with mode 2
+    uint32_t seg_base;                 // first descriptor of this launch of the segment walk
+    const uint32_t* seg_order;         // merge_segments: a contig's descriptors, left to right
 };
 
 // A LONG CONTIG AS SEGMENTS.  The walk is serial per contig -- an edit changes the k-mers after it --
@@ -1221,7 +1223,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
     uint32_t cid = blockIdx.x;
     uint32_t seg_begin = 0, seg_end = 0xFFFFFFFFu, seg_index = 0; // k-mer starts this workgroup walks
     if (SEG) {
-        seg_index = blockIdx.x;
+        seg_index = a.seg_base + blockIdx.x;
         const SegDesc sd = a.segs[seg_index];
         if (sd.p_begin == sd.p_end)
             return; // unused slot
@@ -2201,6 +2203,19 @@ __global__ __launch_bounds__(256) void pick_boundaries(WalkArgs a, const Boundar
     }
 }
 
+// bases [lo, hi) of a contig back from the pass's copy in the output slot (a failed segment is walked again, with its right neighbour)
+struct RestoreReq {
+    uint32_t cid, lo, hi, pad;
+};
+__global__ __launch_bounds__(256) void restore_ranges(WalkArgs a, const RestoreReq* req)
+{
+    const RestoreReq r = req[blockIdx.y];
+    const uint8_t* bak = a.out + a.off[r.cid];
+    uint8_t* seq = a.seq + a.off[r.cid];
+    for (uint64_t i = (uint64_t)r.lo + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < r.hi; i += (uint64_t)gridDim.x * 256)
+        seq[i] = bak[i];
+}
+
 struct SegContig {
     uint32_t cid, seg_first, n_seg, pad;
 };
@@ -2220,7 +2235,7 @@ __global__ __launch_bounds__(256) void merge_segments(WalkArgs a, const SegConti
     if (tid == 0) {
         uint32_t f = 0, nn = 0, ol = 0;
         for (uint32_t j = 0; j < sc.n_seg; j++) {
-            const SegOut& so = a.seg_out[sc.seg_first + j];
+            const SegOut& so = a.seg_out[a.seg_order[sc.seg_first + j]];
             f |= so.failed;
             nn += so.n_nodes;
             ol += so.out_len;
@@ -2243,8 +2258,8 @@ __global__ __launch_bounds__(256) void merge_segments(WalkArgs a, const SegConti
     Node* const nd = a.nodes + a.node_off[cid];
     uint32_t dst0 = 0, out0 = 0;
     for (uint32_t j = 0; j < sc.n_seg; j++) {
-        const SegOut so = a.seg_out[sc.seg_first + j];
-        const uint32_t src0 = a.segs[sc.seg_first + j].node_first;
+        const SegOut so = a.seg_out[a.seg_order[sc.seg_first + j]];
+        const uint32_t src0 = a.segs[a.seg_order[sc.seg_first + j]].node_first;
         for (uint32_t i0 = 0; i0 < so.n_nodes; i0 += 256) {
             const uint32_t i = i0 + tid;
             Node n{};
@@ -2275,7 +2290,7 @@ __global__ __launch_bounds__(256) void merge_segments(WalkArgs a, const SegConti
         unsigned long long st[4] = { 0, 0, 0, 0 };
         for (uint32_t j = 0; j < sc.n_seg; j++)
             for (int q = 0; q < 4; q++)
-                st[q] += a.seg_out[sc.seg_first + j].st[q];
+                st[q] += a.seg_out[a.seg_order[sc.seg_first + j]].st[q];
         for (int q = 0; q < 4; q++)
             atomicAdd(&a.stats[q], st[q]);
     }
@@ -3185,32 +3200,109 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     lap(nullptr);
     launch_walk(job->n_contigs, false);
     lap("whole contigs");
+    uint32_t n_repairs = 0;
     if (!h_segs.empty()) {
+        a.seg_base = 0;
         launch_walk((unsigned)h_segs.size(), true);
         lap("segments");
+        // A failed segment is walked again together with what follows it, up to and including
+        // the first segment that did not fail (whose end the right neighbours were built on):
+        // its bases come back from the pass's copy first.  A repair that fails again sends the
+        // whole contig to the one-workgroup walk (merge_segments).
+        std::vector<SegOut> so(h_segs.size());
+        GP_HIP(hipMemcpyAsync(so.data(), b->seg_out.p, so.size() * sizeof(SegOut), hipMemcpyDeviceToHost, s));
+        GP_HIP(hipStreamSynchronize(s));
+        std::vector<uint32_t> order;
+        std::vector<RestoreReq> restores;
+        const size_t n_first = h_segs.size();
+        for (SegContig& sc : h_segc) {
+            const uint32_t first = sc.seg_first, n = sc.n_seg;
+            sc.seg_first = (uint32_t)order.size();
+            uint32_t len_c = 0;
+            for (uint32_t j = 0; j < n;) {
+                if (!so[first + j].failed) {
+                    order.push_back(first + j);
+                    j++;
+                    continue;
+                }
+                uint32_t m = j + 1;
+                while (m < n && so[first + m].failed)
+                    m++;
+                if (m >= n)
+                    m = n - 1; // (the last segment cannot fail; kept for safety)
+                SegDesc d = h_segs[first + j];
+                d.p_end = h_segs[first + m].p_end;
+                d.node_cap = h_segs[first + m].node_first + h_segs[first + m].node_cap - d.node_first;
+                const uint32_t b_lo = d.p_begin ? d.p_begin + a.k - 1 : 0u;
+                if (!len_c) {
+                    GP_HIP(hipMemcpy(&len_c, a.len_cur + d.cid, 4, hipMemcpyDeviceToHost));
+                }
+                const uint32_t b_hi = d.p_end != 0xFFFFFFFFu ? std::min<uint32_t>(len_c, d.p_end + a.k - 1) : len_c;
+                restores.push_back({ d.cid, b_lo, b_hi, 0 });
+                order.push_back((uint32_t)h_segs.size());
+                h_segs.push_back(d);
+                j = m + 1;
+            }
+            sc.n_seg = (uint32_t)order.size() - sc.seg_first;
+        }
+        n_repairs = (uint32_t)(h_segs.size() - n_first);
+        if ((rc = b->seg_order.ensure(order.size())) != GP_OK)
+            return rc;
+        if (n_repairs) {
+            // (the descriptor and result arrays grow: what round one left in them is kept)
+            DevBuf<uint8_t> nd, no;
+            if ((rc = nd.alloc(h_segs.size() * sizeof(SegDesc))) != GP_OK || (rc = no.alloc(h_segs.size() * sizeof(SegOut))) != GP_OK ||
+                (rc = b->seg_req.ensure(restores.size() * sizeof(RestoreReq))) != GP_OK)
+                return rc;
+            GP_HIP(hipMemcpyAsync(nd.p, h_segs.data(), h_segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice, s));
+            GP_HIP(hipMemsetAsync(no.p, 0, h_segs.size() * sizeof(SegOut), s));
+            GP_HIP(hipMemcpyAsync(no.p, b->seg_out.p, n_first * sizeof(SegOut), hipMemcpyDeviceToDevice, s));
+            GP_HIP(hipMemcpyAsync(b->seg_req.p, restores.data(), restores.size() * sizeof(RestoreReq), hipMemcpyHostToDevice, s));
+            GP_HIP(hipStreamSynchronize(s));
+            std::swap(b->seg_desc.p, nd.p);
+            std::swap(b->seg_desc.n, nd.n);
+            std::swap(b->seg_desc.cap_bytes, nd.cap_bytes);
+            std::swap(b->seg_out.p, no.p);
+            std::swap(b->seg_out.n, no.n);
+            std::swap(b->seg_out.cap_bytes, no.cap_bytes);
+            a.segs = reinterpret_cast<const SegDesc*>(b->seg_desc.p);
+            a.seg_out = reinterpret_cast<SegOut*>(b->seg_out.p);
+            hipLaunchKernelGGL(restore_ranges, dim3(64, (unsigned)restores.size()), dim3(256), 0, s, a,
+                               reinterpret_cast<const RestoreReq*>(b->seg_req.p));
+            a.seg_base = (uint32_t)n_first;
+            launch_walk(n_repairs, true);
+            lap("repairs");
+        }
+        GP_HIP(hipMemcpyAsync(b->seg_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, s));
+        GP_HIP(hipMemcpyAsync(b->seg_contigs.p, h_segc.data(), h_segc.size() * sizeof(SegContig), hipMemcpyHostToDevice, s));
+        GP_HIP(hipStreamSynchronize(s));
+        a.seg_order = b->seg_order.p;
         hipLaunchKernelGGL(merge_segments, dim3((unsigned)h_segc.size()), dim3(256), 0, s, a,
                            reinterpret_cast<const SegContig*>(b->seg_contigs.p), b->contig_mode.p);
         lap("merge");
-        a.walk_phase = 1; // contigs a failed segment sent back: whole, from the restored bases
+        a.walk_phase = 1; // contigs a failed repair sent back: whole, from the restored bases
         launch_walk(job->n_contigs, false);
         lap("rerun");
-        if (getenv("GP_WALK_SEG_DEBUG")) {
+        if (seg_dbg) {
             GP_HIP(hipStreamSynchronize(s));
-            std::vector<SegOut> so(h_segs.size());
-            GP_HIP(hipMemcpy(so.data(), b->seg_out.p, so.size() * sizeof(SegOut), hipMemcpyDeviceToHost));
-            uint32_t f1 = 0, f2 = 0, bad_contigs = 0;
-            for (const SegContig& sc : h_segc) {
-                bool bad = false;
-                for (uint32_t j = 0; j < sc.n_seg; j++) {
-                    f1 += so[sc.seg_first + j].failed == 1;
-                    f2 += so[sc.seg_first + j].failed == 2;
-                    bad |= so[sc.seg_first + j].failed != 0;
+            std::vector<SegOut> so2(h_segs.size());
+            std::vector<uint32_t> mode(job->n_contigs);
+            GP_HIP(hipMemcpy(so2.data(), b->seg_out.p, so2.size() * sizeof(SegOut), hipMemcpyDeviceToHost));
+            GP_HIP(hipMemcpy(mode.data(), b->contig_mode.p, mode.size() * 4, hipMemcpyDeviceToHost));
+            uint32_t f1 = 0, f2 = 0, fr = 0, whole = 0;
+            for (size_t i = 0; i < so2.size(); i++) {
+                if (i < h_segs.size() - n_repairs) {
+                    f1 += so2[i].failed == 1;
+                    f2 += so2[i].failed == 2;
+                } else {
+                    fr += so2[i].failed != 0;
                 }
-                bad_contigs += bad;
             }
-            fprintf(stderr, "WALKSEG k=%u: %zu contigs in %zu segments; failed segments: %u (walker not clean near the end) + %u "
-                            "(edit near the end); contigs walked whole again: %u\n",
-                    a.k, h_segc.size(), h_segs.size(), f1, f2, bad_contigs);
+            for (uint32_t m : mode)
+                whole += m == 2;
+            fprintf(stderr, "WALKSEG k=%u: %zu contigs in %zu segments; failed: %u (walker not clean near the end) + %u (edit near "
+                            "the end); %u repairs, %u of them failed; contigs walked whole again: %u\n",
+                    a.k, h_segc.size(), h_segs.size() - n_repairs, f1, f2, n_repairs, fr, whole);
         }
     }
     hipLaunchKernelGGL(materialize_kernel, dim3(b->n_tiles), dim3(256), 0, s,

@@ -23,7 +23,7 @@ for env in ({"GP_WALK_SEG": "0"}, {}, {"GP_WALK_SEG": "16384"}, {"GP_WALK_SEG": 
             best = min(best, time.time() - t)
         h = hashlib.sha256(b"".join(x or b"-" for x in job.sequences())).hexdigest()[:16]
         c = job.counters()
-        key = (h, c["b_scan_kmers"], c["b_sites"], c["b_probes"], c["b_edits"], c["c_closed"])
+        key = (h, c["b_sites"], c["b_probes"], c["b_edits"], c["c_closed"])   # (b_scan_kmers counts look-ahead k-mers of scans too: an implementation counter, it moves with the scan lengths)
         if ref is None:
             ref = key
         print(f"{str(env):56s} {best*1e3:8.1f} ms walk {job.kernel_time('ntedit_walk')[0]:8.1f} ms  {key}  {'SAME' if key == ref else 'DIFFERENT'}", flush=True)
