@@ -207,7 +207,8 @@ struct Shared {
     int32_t me_lps[224];
     uint8_t me_prev[224];
     uint8_t me_kmer[kMaxK];
-    uint32_t seg_failed;      // a segment's walk worked on something too close to its end: its contig is walked whole
+    uint32_t seg_failed;      // a segment's walk worked on something too close to its end (1, 2) or gave up (3)
+    uint32_t seg_busy;        // consecutive decisions of a segment's walker that were not "clean"
 };
 
 enum { REQ_DONE = 0, REQ_SCAN, REQ_SITE, REQ_NEXT, REQ_BITSCAN, REQ_REFILL, REQ_SWEEP };
@@ -1262,8 +1263,10 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
     // the last k-mer start the sweep of this workgroup settles (a whole contig: every one)
     const bool seg_open = SEG && seg_end != 0xFFFFFFFFu; // a right neighbour takes over at seg_end
 
-    if (tid == 0)
+    if (tid == 0) {
         S.seg_failed = 0;
+        S.seg_busy = 0;
+    }
     if (SEG && seg_begin != 0) {
         // start clean at seg_begin: the head parked just left of it, everything from it on untouched
         if (tid == 0) {
@@ -1398,7 +1401,20 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             // (the first k-mer looked at starts at hi, or at hi + 1 when the one at hi has been tested)
             const bool clean = plain && S.hn == S.tn && S.hi + (S.cur_tested ? 1u : 0u) >= S.clean_from &&
                                a.bm_site != nullptr;
-            if (SEG && seg_open &&
+            if (SEG) {
+                // a walker that has not been clean for thousands of decisions is in a stretch where
+                // every few bases are edited (ntEdit inserting without end on a near-saturated
+                // filter): that stretch is serial whatever is done, and walking it here, then in a
+                // repair, then whole would cost it three times -- give the contig up at once
+                S.seg_busy = (clean && a.site_rec != nullptr) ? 0u : S.seg_busy + 1u;
+                if (seg_open && S.seg_busy > 3000u) {
+                    S.seg_failed = 3;
+                    S.request = REQ_DONE;
+                }
+            }
+            if (SEG && S.seg_failed) {
+                // (given up just above)
+            } else if (SEG && seg_open &&
                 ((clean && a.site_rec != nullptr) ? S.hi + (S.cur_tested ? 1u : 0u) > seg_end
                                                   : (uint64_t)S.hi + seg_guard(k) >= seg_end)) {
                 // the walker is still among what an edit touched this close to the segment's end (or
@@ -3219,8 +3235,11 @@ int stage_b_pass(gp_job* job, uint32_t ki)
             const uint32_t first = sc.seg_first, n = sc.n_seg;
             sc.seg_first = (uint32_t)order.size();
             uint32_t len_c = 0;
+            bool gave_up = false;
+            for (uint32_t j = 0; j < n; j++)
+                gave_up |= so[first + j].failed == 3;
             for (uint32_t j = 0; j < n;) {
-                if (!so[first + j].failed) {
+                if (!so[first + j].failed || gave_up) { // (a contig with a segment that gave up is walked whole: merge_segments sees the flag)
                     order.push_back(first + j);
                     j++;
                     continue;
