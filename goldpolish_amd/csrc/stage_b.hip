@@ -78,6 +78,7 @@ struct WalkArgs {
     const uint32_t* contig_mode;       // per contig: 0 = walk it whole, 1 = walked as segments (the whole-contig workgroup leaves),
                                        // 2 = a segment failed, walk it whole now (second launch)
     uint32_t walk_phase;               // 0: first launch (whole contigs with mode 0, segments); 1: the rerun of contigs with mode 2
+    uint32_t n_prof_contigs;           // GP_WALK_PROFILE: rows of `prof` before the segments' rows
     uint32_t seg_base;                 // first descriptor of this launch of the segment walk
     const uint32_t* seg_order;         // merge_segments: a contig's descriptors, left to right
 };
@@ -2118,6 +2119,11 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             so.st[2] = S.st_probes;
             so.st[3] = S.st_edits;
             a.seg_out[seg_index] = so;
+            if (a.prof && seg_index < 8192u)
+                for (int i = 0; i < 8; i++) {
+                    a.prof[((uint64_t)a.n_prof_contigs + seg_index) * 16 + i] = S.prof_t[i];
+                    a.prof[((uint64_t)a.n_prof_contigs + seg_index) * 16 + 8 + i] = S.prof_n[i];
+                }
         }
         return;
     }
@@ -3186,10 +3192,11 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     }
     DevBuf<unsigned long long> d_prof;
     if (getenv("GP_WALK_PROFILE")) {
-        if ((rc = d_prof.alloc((uint64_t)job->n_contigs * 16)) != GP_OK)
+        if ((rc = d_prof.alloc(((uint64_t)job->n_contigs + 8192) * 16)) != GP_OK)
             return rc;
-        GP_HIP(hipMemsetAsync(d_prof.p, 0, (uint64_t)job->n_contigs * 16 * 8, s));
+        GP_HIP(hipMemsetAsync(d_prof.p, 0, ((uint64_t)job->n_contigs + 8192) * 16 * 8, s));
         a.prof = d_prof.p;
+        a.n_prof_contigs = job->n_contigs;
     }
     // waves per SIMD the walk is compiled for: many contigs -> more workgroups per CU at fewer
     // registers (GP_WALK_WAVES overrides: 1 or 4)
@@ -3337,6 +3344,25 @@ int stage_b_pass(gp_job* job, uint32_t ki)
         GP_HIP(hipStreamSynchronize(s));
         std::vector<unsigned long long> h((size_t)job->n_contigs * 16);
         GP_HIP(hipMemcpy(h.data(), d_prof.p, h.size() * 8, hipMemcpyDeviceToHost));
+        if (!h_segs.empty()) {
+            const size_t ns = std::min<size_t>(h_segs.size(), 8192);
+            std::vector<unsigned long long> hs(ns * 16);
+            GP_HIP(hipMemcpy(hs.data(), d_prof.p + (size_t)job->n_contigs * 16, hs.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<std::pair<double, size_t>> t;
+            for (size_t i = 0; i < ns; i++) {
+                double ms = 0;
+                for (int q = 0; q < 8; q++)
+                    ms += (double)hs[i * 16 + q] / 1e5;
+                t.push_back({ ms, i });
+            }
+            std::sort(t.rbegin(), t.rend());
+            for (size_t r = 0; r < std::min<size_t>(5, t.size()); r++) {
+                const size_t i = t[r].second;
+                fprintf(stderr, "WALKPROF k=%u segment %zu (contig %u, starts %u..%u)%s: %.1f ms = site %.1f ms / %llu, next %.1f ms / %llu\n", a.k, i,
+                        h_segs[i].cid, h_segs[i].p_begin, h_segs[i].p_end, i >= h_segs.size() - n_repairs ? " [repair]" : "", t[r].first,
+                        (double)hs[i * 16 + 2] / 1e5, hs[i * 16 + 8 + 2], (double)hs[i * 16 + 3] / 1e5, hs[i * 16 + 8 + 3]);
+            }
+        }
         std::vector<uint32_t> order(job->n_contigs);
         std::vector<double> tot(job->n_contigs, 0);
         for (uint32_t c = 0; c < job->n_contigs; c++) {

@@ -8,5 +8,5 @@ p = core.default_params()
 os.environ["GP_WALK_SEG"] = sys.argv[2] if len(sys.argv) > 2 else "65536"
 with core.Context(0) as ctx, core.Job.from_workload(ctx, p, w) as job:
     job.polish()
-    os.environ["GP_WALK_SEG_DEBUG"] = "1"
+    os.environ["GP_WALK_SEG_DEBUG"] = "1"; os.environ["GP_WALK_PROFILE"] = "1"
     t = time.time(); job.polish(); print("polish", time.time() - t, {n: round(job.kernel_time(n)[0], 1) for n in ("ntedit_scan", "ntedit_walk", "sealer_bfs")}, flush=True)
