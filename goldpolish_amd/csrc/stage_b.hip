@@ -2221,7 +2221,15 @@ __global__ __launch_bounds__(256) void pick_boundaries(WalkArgs a, const Boundar
             best_len = run;
             best_end = lo + 256u * 64u;
         }
-        cut[blockIdx.x] = best_len >= seg_guard(k) + 16 ? best_end : 0xFFFFFFFFu;
+        cut[2 * blockIdx.x] = best_len >= seg_guard(k) + 16 ? best_end : 0xFFFFFFFFu;
+        // how many records of the window say "edit": the host leaves contigs that are edited every
+        // few dozen bases (a near-saturated filter) to the one-workgroup walk -- their segments
+        // would rarely arrive clean, and every failed one is walked twice
+        uint32_t n_stop = 0;
+        for (uint32_t w = 0; w < 256; w++)
+            n_stop += (uint32_t)__popcll(stops[w]);
+        const uint32_t outside = 256u * 64u - (hi > lo ? hi - lo : 0u);
+        cut[2 * blockIdx.x + 1] = n_stop - min(n_stop, outside);
     }
 }
 
@@ -3121,9 +3129,9 @@ int stage_b_pass(gp_job* job, uint32_t ki)
             }
             req_first[job->n_contigs] = (uint32_t)h_req.size();
             if (!h_req.empty()) {
-                std::vector<uint32_t> h_cut(h_req.size());
+                std::vector<uint32_t> h_cut(2 * h_req.size());
                 if ((rc = b->seg_req.ensure(h_req.size() * sizeof(BoundaryReq))) != GP_OK ||
-                    (rc = b->seg_cut.ensure(h_req.size())) != GP_OK)
+                    (rc = b->seg_cut.ensure(2 * h_req.size())) != GP_OK)
                     return rc;
                 GP_HIP(hipMemcpyAsync(b->seg_req.p, h_req.data(), h_req.size() * sizeof(BoundaryReq), hipMemcpyHostToDevice, s));
                 hipLaunchKernelGGL(pick_boundaries, dim3((unsigned)h_req.size()), dim3(256), 0, s, a,
@@ -3133,15 +3141,22 @@ int stage_b_pass(gp_job* job, uint32_t ki)
                 GP_HIP(hipStreamSynchronize(s));
                 if (getenv("GP_WALK_SEG_DEBUG")) {
                     size_t found = 0;
-                    for (uint32_t x : h_cut)
-                        found += x != 0xFFFFFFFFu;
-                    fprintf(stderr, "WALKSEG k=%u: %zu cuts wanted, %zu found\n", a.k, h_cut.size(), found);
+                    for (size_t i = 0; i < h_req.size(); i++)
+                        found += h_cut[2 * i] != 0xFFFFFFFFu;
+                    fprintf(stderr, "WALKSEG k=%u: %zu cuts wanted, %zu found\n", a.k, h_req.size(), found);
                 }
                 const uint32_t force = (uint32_t)env_u64("GP_WALK_SEG_FORCE", 0); // tests: cut at the nominal positions whatever the records say
+                // records saying "edit" per window position above which a contig is not cut (GP_WALK_SEG_DENSE: one in so many)
+                const uint64_t dense = std::max<uint64_t>(1, env_u64("GP_WALK_SEG_DENSE", 150));
                 for (uint32_t c = 0; c < job->n_contigs; c++) {
                     std::vector<uint32_t> cuts;
+                    uint64_t stops = 0;
+                    for (uint32_t i = req_first[c]; i < req_first[c + 1]; i++)
+                        stops += h_cut[2 * i + 1];
+                    if (!force && stops * dense > (uint64_t)(req_first[c + 1] - req_first[c]) * 2 * half_window)
+                        continue;
                     for (uint32_t i = req_first[c]; i < req_first[c + 1]; i++) {
-                        const uint32_t at = force ? h_req[i].nominal : h_cut[i];
+                        const uint32_t at = force ? h_req[i].nominal : h_cut[2 * i];
                         const uint32_t prev = cuts.empty() ? 0u : cuts.back();
                         if (at != 0xFFFFFFFFu && at >= prev + 4 * kSegGuard && (uint64_t)at + 4 * kSegGuard < h_len[c])
                             cuts.push_back(at);
