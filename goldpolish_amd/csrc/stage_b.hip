@@ -3147,13 +3147,16 @@ int stage_b_pass(gp_job* job, uint32_t ki)
                 }
                 const uint32_t force = (uint32_t)env_u64("GP_WALK_SEG_FORCE", 0); // tests: cut at the nominal positions whatever the records say
                 // records saying "edit" per window position above which a contig is not cut (GP_WALK_SEG_DENSE: one in so many)
-                const uint64_t dense = std::max<uint64_t>(1, env_u64("GP_WALK_SEG_DENSE", 150));
+                // (off by default: on SURVEY 8d's 100 Mbp of 0.3-12 Mbp contigs the contigs that cost most ARE
+                // the densely edited ones, and cutting them took the walk from 37 s to 6 s per step
+                // in spite of their failed segments; leaving them whole gave the 37 s back)
+                const uint64_t dense = env_u64("GP_WALK_SEG_DENSE", 0);
                 for (uint32_t c = 0; c < job->n_contigs; c++) {
                     std::vector<uint32_t> cuts;
                     uint64_t stops = 0;
                     for (uint32_t i = req_first[c]; i < req_first[c + 1]; i++)
                         stops += h_cut[2 * i + 1];
-                    if (!force && stops * dense > (uint64_t)(req_first[c + 1] - req_first[c]) * 2 * half_window)
+                    if (!force && dense && stops * dense > (uint64_t)(req_first[c + 1] - req_first[c]) * 2 * half_window)
                         continue;
                     for (uint32_t i = req_first[c]; i < req_first[c + 1]; i++) {
                         const uint32_t at = force ? h_req[i].nominal : h_cut[2 * i];
