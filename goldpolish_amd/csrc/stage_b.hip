@@ -3217,11 +3217,13 @@ int stage_b_pass(gp_job* job, uint32_t ki)
         a.n_prof_contigs = job->n_contigs;
     }
     // waves per SIMD the walk is compiled for: many contigs -> more workgroups per CU at fewer
-    // registers (GP_WALK_WAVES overrides: 1 or 4)
+    // registers (GP_WALK_WAVES overrides: 1, 4 or 6)
     const uint64_t walk_waves = env_u64("GP_WALK_WAVES", job->n_contigs > 3 * 256 ? 4 : 1); // (measured on 1000 x 25 kbp: 6 -> 52 ms, 5 -> 50, 4 -> 45, 1 -> 63)
     auto launch_walk = [&](unsigned grid, bool seg) {
         if (seg)
             hipLaunchKernelGGL((ntedit_walk<1, true>), dim3(grid), dim3(kWalkThreads), 0, s, a);
+        else if (walk_waves >= 6)
+            hipLaunchKernelGGL((ntedit_walk<6, false>), dim3(grid), dim3(kWalkThreads), 0, s, a);
         else if (walk_waves >= 4)
             hipLaunchKernelGGL((ntedit_walk<4, false>), dim3(grid), dim3(kWalkThreads), 0, s, a);
         else
