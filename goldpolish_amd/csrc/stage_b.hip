@@ -175,7 +175,7 @@ struct Shared {
     // site window as prefix XORs of rotated seeds: any k-mer hash of the window in O(1)
     uint64_t PF[2 * kMaxK + 16], QR[2 * kMaxK + 16];
     uint64_t wave_f[kWalkThreads / 64], wave_r[kWalkThreads / 64];
-    int32_t request;
+    int32_t req[2];           // this trip's request and the next one's (see THE REQUEST PROTOCOL in ntedit_walk)
     uint32_t nz;              // chars available in Z
     uint32_t scan_j0, scan_n; // first k-mer index / number of k-mers of the scan
     uint32_t draft;
@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             S.cp0 = 0;
             S.cpn = 0;
             nd_cache_drop(S);
-            S.request = REQ_NEXT;
+            S.req[0] = REQ_NEXT;
         }
     } else if (tid == 0) {
         for (uint32_t code = 0; code < 5; code++) {
@@ -1360,9 +1360,9 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
         if (hi + k - 1 < len) {
             hash_kmer(S.ht, c.seq + hi, k, S.fh, S.rh);
             S.char_in = c.seq[S.ti];
-            S.request = REQ_NEXT;
+            S.req[0] = REQ_NEXT;
         } else {
-            S.request = REQ_DONE;
+            S.req[0] = REQ_DONE;
         }
     }
     __syncthreads();
@@ -1378,25 +1378,26 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
         S.prof_req = REQ_NEXT;
     }
     for (uint64_t trip = 0;; trip++) {
+        const uint32_t cur = (uint32_t)trip & 1u, nxt = cur ^ 1u; // the request slot of this trip / of the next one
         if (a.prof && tid == 0) {
             const unsigned long long now = wall_clock64();
             S.prof_t[S.prof_req & 7] += now - S.prof_last;
             S.prof_n[S.prof_req & 7]++;
             S.prof_last = now;
-            S.prof_req = S.request; // what the trip that starts here works on (thread 0's decision below belongs to it)
+            S.prof_req = S.req[cur]; // what the trip that starts here works on (thread 0's decision below belongs to it)
         }
         if (trip > trip_trap) {
             if (tid == 0) {
                 atomicOr(a.err, 4u);
                 if (atomicCAS(a.err + 1, 0u, cid + 1) == 0u) { // the first one leaves a note (words 1..3 of err)
-                    a.err[2] = (uint32_t)S.request;
+                    a.err[2] = (uint32_t)S.req[cur];
                     a.err[3] = S.hi;
                 }
             }
             break;
         }
         // ---------------- thread 0: decide how to reach the next untested k-mer
-        if (tid == 0 && S.request == REQ_NEXT) {
+        if (tid == 0 && S.req[cur] == REQ_NEXT) {
             Node tnode = nd_cached(c, S, S.tn);
             const bool plain = tnode.type == 0 && tnode.e == len - 1 && S.ti <= tnode.e;
             // (the first k-mer looked at starts at hi, or at hi + 1 when the one at hi has been tested)
@@ -1410,7 +1411,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                 S.seg_busy = (clean && a.site_rec != nullptr) ? 0u : S.seg_busy + 1u;
                 if (seg_open && S.seg_busy > 3000u) {
                     S.seg_failed = 3;
-                    S.request = REQ_DONE;
+                    S.req[cur] = REQ_DONE;
                 }
             }
             if (SEG && S.seg_failed) {
@@ -1421,12 +1422,12 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                 // the walker is still among what an edit touched this close to the segment's end (or
                 // has jumped past the end): it does not arrive there the way the next segment assumed
                 S.seg_failed = 1;
-                S.request = REQ_DONE;
+                S.req[cur] = REQ_DONE;
             } else if (clean && a.site_rec != nullptr) {
                 // everything from the head on is untouched contig and every site there has its
                 // record: all lanes sweep forward to the first site that ends in an edit
                 S.bit_from = S.hi + (S.cur_tested ? 1u : 0u);
-                S.request = REQ_SWEEP;
+                S.req[cur] = REQ_SWEEP;
             } else if (clean) {
                 // everything from the head on is untouched contig: the precomputed bitmaps
                 // say where the next testable, absent k-mer starts AND whether the k k-mers
@@ -1449,7 +1450,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                     S.cw0 + S.cwn <= ((base_bit + len - 1) >> 6)) {
                     // the head is leaving the window (or there is none yet): every lane fetches the next
                     S.bit_from = p;
-                    S.request = REQ_REFILL;
+                    S.req[cur] = REQ_REFILL;
                     p = last_p + 1; // skip the scan below; it resumes after the refill
                     next_req = REQ_REFILL;
                 }
@@ -1505,14 +1506,14 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                     S.bit_from = p;
                 // REQ_DONE here means the scan ran off the end of the contig: nothing is left
                 // that the reference could act on
-                S.request = next_req;
+                S.req[cur] = next_req;
             } else if (plain) {
                 // scan: current k-mer chars via the cursor, lookahead straight from the contig
                 Node hnode = nd_cached(c, S, S.hn);
                 S.fast_head = (hnode.type == 0 && S.hi + k - 1 <= hnode.e) ? 1u : 0u;
                 uint32_t got = S.fast_head ? k : gather_plan(c, S, S.Z, k);
                 if (got < k) {
-                    S.request = REQ_DONE; // cannot happen while the tail is in range
+                    S.req[cur] = REQ_DONE; // cannot happen while the tail is in range
                 } else {
                     uint32_t ahead = len - 1 - S.ti;
                     uint32_t j0 = S.cur_tested ? 1u : 0u;
@@ -1524,12 +1525,12 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                     if (SEG && seg_open) // a site this scan finds must be workable inside the segment (hi + guard < seg_end holds here)
                         n = min(n, seg_end - (k + 13) - (S.hi + j0));
                     if (n == 0) {
-                        S.request = REQ_DONE; // the next roll would fail: end of contig
+                        S.req[cur] = REQ_DONE; // the next roll would fail: end of contig
                     } else {
                         S.scan_j0 = j0;
                         S.scan_n = n;
                         S.nz = k + min(ahead, j0 + n - 1);
-                        S.request = REQ_SCAN;
+                        S.req[cur] = REQ_SCAN;
                     }
                 }
             } else {
@@ -1553,27 +1554,28 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                     S.min_tested_ti = 0;
                 }
                 if (!go || S.hi + k - 1 >= len) {
-                    S.request = REQ_DONE;
+                    S.req[cur] = REQ_DONE;
                 } else {
                     S.cur_tested = 1;
                     S.st_probes++;
                     if (!bf_contains(a, c.bf, S.fh + S.rh))
-                        S.request = REQ_SITE;
+                        S.req[cur] = REQ_SITE;
                     else
-                        S.request = REQ_NEXT;
+                        S.req[cur] = REQ_NEXT;
                 }
             }
         }
         __syncthreads();
-        // THE REQUEST PROTOCOL.  Thread 0 alone writes S.request: above (a REQ_NEXT turned into what
-        // reaches the next k-mer) and at the end of a branch below.  Every thread reads it exactly
-        // once per trip, here, between two barriers: the first makes thread 0's decision (and
-        // everything the previous trip wrote) visible, the second keeps thread 0 from rewriting it
-        // -- in ANY branch, at any point -- before the slowest wave has read it.  (Round 2 relied on
-        // each branch happening to contain a barrier ahead of its write; REQ_NEXT did not, and a wave
-        // that fell behind while another job's kernel held its CU took the next trip's branch.)
-        const int req = S.request;
-        __syncthreads();
+        // THE REQUEST PROTOCOL.  Thread 0 alone writes requests; every thread reads this trip's
+        // exactly once, here, behind the barrier that makes thread 0's decision (and everything the
+        // previous trip wrote) visible.  Requests live in TWO slots: a branch below leaves the next
+        // trip's request in the OTHER slot, so nothing a branch does -- at any point, with or without
+        // a barrier of its own -- can change what a slower wave is still about to read; this slot is
+        // written again only after the next trip's barrier, which every thread passes after its read
+        // here.  (Round 2 had one slot and relied on each branch happening to contain a barrier ahead
+        // of its write; REQ_NEXT did not, and a wave that fell behind while another job's kernel held
+        // its CU took the next trip's branch.)
+        const int req = S.req[cur];
         if (req == REQ_DONE)
             break;
 
@@ -1670,10 +1672,10 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                 if (first == 0xFFFFFFFFu) {
                     if (p_start <= last_p)
                         S.st_scan += last_p + 1 - p_start;
-                    S.request = REQ_DONE; // nothing left that the reference could act on (a segment: arrived clean at its end)
+                    S.req[nxt] = REQ_DONE; // nothing left that the reference could act on (a segment: arrived clean at its end)
                 } else if (SEG && seg_open && (uint64_t)first + seg_guard(k) >= seg_end) {
                     S.seg_failed = 2; // an edit this close to the segment's end
-                    S.request = REQ_DONE;
+                    S.req[nxt] = REQ_DONE;
                 } else {
                     S.st_scan += first - p_start + 1;
                     const SiteRec r = a.site_rec[base_bit + first];
@@ -1687,7 +1689,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                         // work the site out on the spot
                         S.need_hash = 1;
                         S.confirmed = 1;
-                        S.request = REQ_SITE;
+                        S.req[nxt] = REQ_SITE;
                     } else {
                         const uint8_t raw = c.seq[ti], draft = to_upper(raw);
                         S.st_sites++;
@@ -1707,7 +1709,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                         for (int i = 0; i < 8; i++)
                             b.indel[i] = r.indel[i];
                         make_edit(c, S, draft, b);
-                        S.request = REQ_NEXT;
+                        S.req[nxt] = REQ_NEXT;
                     }
                 }
             }
@@ -1740,7 +1742,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                 S.cwn = nw;
                 S.cp0 = p0;
                 S.cpn = nb;
-                S.request = REQ_NEXT;
+                S.req[nxt] = REQ_NEXT;
             }
             __syncthreads();
             continue;
@@ -1768,7 +1770,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             if (tid == 0) {
                 if (found == 0xFFFFFFFFu) {
                     S.st_scan += last_p - from + 1;
-                    S.request = REQ_DONE; // nothing absent up to the end of the contig
+                    S.req[nxt] = REQ_DONE; // nothing absent up to the end of the contig
                 } else {
                     // park the head just left of the candidate; thread 0 takes it from there
                     S.st_scan += found - from;
@@ -1781,7 +1783,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                     }
                     S.ti = S.hi + k - 1;
                     S.min_tested_ti = 0;
-                    S.request = REQ_NEXT;
+                    S.req[nxt] = REQ_NEXT;
                 }
             }
             __syncthreads();
@@ -1836,14 +1838,17 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                 S.rh = S.scan_rh[dest - j0];
                 S.char_in = S.Z[dest + k - 1];
                 S.cur_tested = 1;
-                S.request = first != 0xFFFFFFFFu ? REQ_SITE : REQ_NEXT;
+                S.req[nxt] = first != 0xFFFFFFFFu ? REQ_SITE : REQ_NEXT;
             }
             __syncthreads();
             continue;
         }
 
-        if (req == REQ_NEXT)
-            continue; // thread 0 takes it from the top of the loop (the barrier after the read above covers this trip)
+        if (req == REQ_NEXT) {
+            if (tid == 0)
+                S.req[nxt] = REQ_NEXT; // thread 0 takes it from the top of the loop
+            continue;
+        }
 
         // ------------------------------------------------------------ REQ_SITE
         if (tid == 0) {
@@ -1942,7 +1947,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
         }
         if (!f_confirmed && (S.confirm_bad || S.confirm_missing < a.need_missing)) {
             if (tid == 0) {
-                S.request = REQ_NEXT;
+                S.req[nxt] = REQ_NEXT;
                 S.need_hash = 0;
             }
             __syncthreads();
@@ -2070,7 +2075,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
         __syncthreads();
         if (tid == 0) {
             make_edit(c, S, (uint8_t)S.draft, best);
-            S.request = REQ_NEXT;
+            S.req[nxt] = REQ_NEXT;
         }
         __syncthreads();
     }
