@@ -199,15 +199,22 @@ struct Shared {
     uint32_t cwn;             // words in the cache
     uint32_t cp0, cpn;        // contig positions [cp0, cp0 + cpn) held in c_seq
     alignas(16) uint8_t c_seq[kCacheBases];
-    uint64_t scan_fh[kWalkThreads], scan_rh[kWalkThreads];
+    // (make_edit's work arrays -- thread 0 only, 1.2 KB of scratch for every lane while they were
+    // private -- share the scan's hash arrays: a scan's hashes are consumed before its branch ends,
+    // make_edit runs at the end of a site's or a sweep's branch)
+    union {
+        struct {
+            uint64_t scan_fh[kWalkThreads], scan_rh[kWalkThreads];
+        };
+        struct {
+            int32_t me_lps[224];
+            uint8_t me_prev[224];
+            uint8_t me_kmer[kMaxK];
+        };
+    };
     uint32_t wave_min[kWalkThreads / 64];
     unsigned long long prof_t[8], prof_n[8], prof_last;
     int32_t prof_req;
-    // make_edit's work arrays (thread 0 only): in private memory they were 1.2 KB of scratch for
-    // every lane of every workgroup
-    int32_t me_lps[224];
-    uint8_t me_prev[224];
-    uint8_t me_kmer[kMaxK];
     uint32_t seg_failed;      // a segment's walk worked on something too close to its end (1, 2) or gave up (3)
     uint32_t seg_busy;        // consecutive decisions of a segment's walker that were not "clean"
 };
@@ -3222,13 +3229,11 @@ int stage_b_pass(gp_job* job, uint32_t ki)
         a.n_prof_contigs = job->n_contigs;
     }
     // waves per SIMD the walk is compiled for: many contigs -> more workgroups per CU at fewer
-    // registers (GP_WALK_WAVES overrides: 1, 4 or 6)
+    // registers (GP_WALK_WAVES overrides: 1 or 4; compiled for 6 the kernel no longer fits 80 registers and was slower: 170 against 149 ms on 4000 x 25 kbp)
     const uint64_t walk_waves = env_u64("GP_WALK_WAVES", job->n_contigs > 3 * 256 ? 4 : 1); // (measured on 1000 x 25 kbp: 6 -> 52 ms, 5 -> 50, 4 -> 45, 1 -> 63)
     auto launch_walk = [&](unsigned grid, bool seg) {
         if (seg)
             hipLaunchKernelGGL((ntedit_walk<1, true>), dim3(grid), dim3(kWalkThreads), 0, s, a);
-        else if (walk_waves >= 6)
-            hipLaunchKernelGGL((ntedit_walk<6, false>), dim3(grid), dim3(kWalkThreads), 0, s, a);
         else if (walk_waves >= 4)
             hipLaunchKernelGGL((ntedit_walk<4, false>), dim3(grid), dim3(kWalkThreads), 0, s, a);
         else
