@@ -75,6 +75,7 @@ struct WalkArgs {
     // long contigs walked as segments (see SegDesc); null: every contig by one workgroup
     const struct SegDesc* segs;
     struct SegOut* seg_out;
+    struct SegState* seg_state;        // [descriptor] where a failed segment leaves its walker
     const uint32_t* contig_mode;       // per contig: 0 = walk it whole, 1 = walked as segments (the whole-contig workgroup leaves),
                                        // 2 = a segment failed, walk it whole now (second launch)
     uint32_t walk_phase;               // 0: first launch (whole contigs with mode 0, segments); 1: the rerun of contigs with mode 2
@@ -102,10 +103,20 @@ struct SegDesc {
     uint32_t p_begin, p_end;   // k-mer starts of the segment; p_end == 0xFFFFFFFF: to the end of the contig
     uint32_t node_first;       // first node slot of the segment inside the contig's node region
     uint32_t node_cap;
+    uint32_t resume_from;      // 0xFFFFFFFF: start clean at p_begin; else: go on from the state descriptor `resume_from` left
+    uint32_t pad;
 };
 struct SegOut {
     uint32_t failed, n_nodes, out_len, pad;
     unsigned long long st[4];  // scan, sites, probes, edits
+};
+// the walker of a segment that failed, as it stood: a failed segment is not walked again, it goes ON
+// through its right neighbours' stretch (whose bases come back from the pass's copy first)
+struct SegState {
+    uint32_t hi, ti, hn, tn, nn, char_in, min_tested_ti, clean_from, need_hash, fast_head, confirmed;
+    int32_t cur_tested;
+    uint64_t fh, rh;
+    unsigned long long st[4];
 };
 // How close to its end a segment's walker may still WORK (anything but sweep over records): the
 // base a k-mer start q owns is q + k - 1, the right neighbour writes bases from seg_end + k - 1 on,
@@ -1275,7 +1286,44 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
         S.seg_failed = 0;
         S.seg_busy = 0;
     }
-    if (SEG && seg_begin != 0) {
+    if (SEG && a.segs[seg_index].resume_from != 0xFFFFFFFFu) {
+        // go on where descriptor resume_from stopped (its node list is this descriptor's, untouched)
+        if (tid == 0) {
+            for (uint32_t code = 0; code < 5; code++) {
+                uint64_t sd0 = code < 4 ? seed_of_code(code) : 0ULL;
+                S.ht.f[code] = sd0;
+                S.ht.r[code] = sd0;
+                S.ht.fk[code] = sroln(sd0, k);
+                S.ht.rk[code] = sroln(sd0, k);
+            }
+            const SegState st = a.seg_state[a.segs[seg_index].resume_from];
+            S.hi = st.hi;
+            S.ti = st.ti;
+            S.hn = st.hn;
+            S.tn = st.tn;
+            S.nn = st.nn;
+            S.char_in = st.char_in;
+            S.min_tested_ti = st.min_tested_ti;
+            S.clean_from = st.clean_from;
+            S.need_hash = st.need_hash;
+            S.fast_head = st.fast_head;
+            S.confirmed = st.confirmed;
+            S.cur_tested = st.cur_tested;
+            S.fh = st.fh;
+            S.rh = st.rh;
+            S.st_scan = st.st[0];
+            S.st_sites = st.st[1];
+            S.st_probes = st.st[2];
+            S.st_edits = st.st[3];
+            S.nc_next = 0;
+            S.cw0 = 0;
+            S.cwn = 0;
+            S.cp0 = 0;
+            S.cpn = 0;
+            nd_cache_drop(S);
+            S.req[0] = REQ_NEXT;
+        }
+    } else if (SEG && seg_begin != 0) {
         // start clean at seg_begin: the head parked just left of it, everything from it on untouched
         if (tid == 0) {
             for (uint32_t code = 0; code < 5; code++) {
@@ -1681,7 +1729,14 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                         S.st_scan += last_p + 1 - p_start;
                     S.req[nxt] = REQ_DONE; // nothing left that the reference could act on (a segment: arrived clean at its end)
                 } else if (SEG && seg_open && (uint64_t)first + seg_guard(k) >= seg_end) {
-                    S.seg_failed = 2; // an edit this close to the segment's end
+                    // an edit this close to the segment's end: park the (clean) walker just left of
+                    // the site, as the bit scan does, so that whoever goes on sweeps into it first thing
+                    S.seg_failed = 2;
+                    S.st_scan += first - p_start;
+                    S.hi = first - 1;
+                    S.ti = S.hi + k - 1;
+                    S.cur_tested = 1;
+                    S.min_tested_ti = 0;
                     S.req[nxt] = REQ_DONE;
                 } else {
                     S.st_scan += first - p_start + 1;
@@ -2096,7 +2151,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
         if (tid == 0) {
             const uint32_t b_lo = seg_begin ? seg_begin + k - 1 : 0u, b_hi = seg_open ? seg_end + k - 1 : len;
             uint32_t o = 0, live = 0;
-            const uint32_t nn = S.nn;
+            const uint32_t nn = S.seg_failed ? 0u : S.nn; // (a failed segment's node list stays as the walker left it: it is gone on from)
             for (uint32_t ni = 0; ni < nn; ni++) {
                 Node n = c.nd[ni];
                 if (n.type == -1)
@@ -2131,6 +2186,28 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             so.st[2] = S.st_probes;
             so.st[3] = S.st_edits;
             a.seg_out[seg_index] = so;
+            if (S.seg_failed) {
+                SegState st;
+                st.hi = S.hi;
+                st.ti = S.ti;
+                st.hn = S.hn;
+                st.tn = S.tn;
+                st.nn = S.nn;
+                st.char_in = S.char_in;
+                st.min_tested_ti = S.min_tested_ti;
+                st.clean_from = S.clean_from;
+                st.need_hash = S.need_hash;
+                st.fast_head = S.fast_head;
+                st.confirmed = S.confirmed;
+                st.cur_tested = S.cur_tested;
+                st.fh = S.fh;
+                st.rh = S.rh;
+                st.st[0] = S.st_scan;
+                st.st[1] = S.st_sites;
+                st.st[2] = S.st_probes;
+                st.st[3] = S.st_edits;
+                a.seg_state[seg_index] = st;
+            }
             if (a.prof && seg_index < 8192u)
                 for (int i = 0; i < 8; i++) {
                     a.prof[((uint64_t)a.n_prof_contigs + seg_index) * 16 + i] = S.prof_t[i];
@@ -3188,6 +3265,8 @@ int stage_b_pass(gp_job* job, uint32_t ki)
                         d.p_end = j < cuts.size() ? cuts[j] : 0xFFFFFFFFu;
                         d.node_first = node_at(d.p_begin);
                         d.node_cap = (j < cuts.size() ? node_at(cuts[j]) : (uint32_t)region) - d.node_first;
+                        d.resume_from = 0xFFFFFFFFu;
+                        d.pad = 0;
                         h_segs.push_back(d);
                     }
                     h_segc.push_back(sc);
@@ -3201,6 +3280,7 @@ int stage_b_pass(gp_job* job, uint32_t ki)
             h_mode[sc.cid] = 1;
         if ((rc = b->seg_desc.ensure(h_segs.size() * sizeof(SegDesc))) != GP_OK ||
             (rc = b->seg_out.ensure(h_segs.size() * sizeof(SegOut))) != GP_OK ||
+            (rc = b->seg_state.ensure(2 * h_segs.size() * sizeof(SegState))) != GP_OK ||
             (rc = b->seg_contigs.ensure(h_segc.size() * sizeof(SegContig))) != GP_OK ||
             (rc = b->contig_mode.ensure(job->n_contigs)) != GP_OK)
             return rc;
@@ -3217,6 +3297,7 @@ int stage_b_pass(gp_job* job, uint32_t ki)
         GP_HIP(hipStreamSynchronize(s)); // the host vectors above are gone when this function returns
         a.segs = reinterpret_cast<const SegDesc*>(b->seg_desc.p);
         a.seg_out = reinterpret_cast<SegOut*>(b->seg_out.p);
+        a.seg_state = reinterpret_cast<SegState*>(b->seg_state.p);
         a.contig_mode = b->contig_mode.p;
         a.walk_phase = 0;
     }
@@ -3258,10 +3339,10 @@ int stage_b_pass(gp_job* job, uint32_t ki)
         a.seg_base = 0;
         launch_walk((unsigned)h_segs.size(), true);
         lap("segments");
-        // A failed segment is walked again together with what follows it, up to and including
-        // the first segment that did not fail (whose end the right neighbours were built on):
-        // its bases come back from the pass's copy first.  A repair that fails again sends the
-        // whole contig to the one-workgroup walk (merge_segments).
+        // A failed segment goes ON, from the state its walker was left in, through what follows it up
+        // to and including the first segment that did not fail (whose end the right neighbours
+        // were built on); the bases of that stretch come back from the pass's copy first.  One that
+        // fails again sends the whole contig to the one-workgroup walk (merge_segments).
         std::vector<SegOut> so(h_segs.size());
         GP_HIP(hipMemcpyAsync(so.data(), b->seg_out.p, so.size() * sizeof(SegOut), hipMemcpyDeviceToHost, s));
         GP_HIP(hipStreamSynchronize(s));
@@ -3287,14 +3368,17 @@ int stage_b_pass(gp_job* job, uint32_t ki)
                 if (m >= n)
                     m = n - 1; // (the last segment cannot fail; kept for safety)
                 SegDesc d = h_segs[first + j];
+                // the bases of the stretch it goes on through come back from the pass's copy: what
+                // segments j + 1 .. m wrote there is void (its own bases stay as its walker left them)
+                const uint32_t b_lo = d.p_end + a.k - 1;
                 d.p_end = h_segs[first + m].p_end;
                 d.node_cap = h_segs[first + m].node_first + h_segs[first + m].node_cap - d.node_first;
-                const uint32_t b_lo = d.p_begin ? d.p_begin + a.k - 1 : 0u;
+                d.resume_from = first + j;
                 if (!len_c) {
                     GP_HIP(hipMemcpy(&len_c, a.len_cur + d.cid, 4, hipMemcpyDeviceToHost));
                 }
                 const uint32_t b_hi = d.p_end != 0xFFFFFFFFu ? std::min<uint32_t>(len_c, d.p_end + a.k - 1) : len_c;
-                restores.push_back({ d.cid, b_lo, b_hi, 0 });
+                restores.push_back({ d.cid, std::min(b_lo, b_hi), b_hi, 0 });
                 order.push_back((uint32_t)h_segs.size());
                 h_segs.push_back(d);
                 j = m + 1;
