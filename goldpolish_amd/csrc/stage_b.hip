@@ -1732,6 +1732,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                     // an edit this close to the segment's end: park the (clean) walker just left of
                     // the site, as the bit scan does, so that whoever goes on sweeps into it first thing
                     S.seg_failed = 2;
+                    S.st_probes -= (k + jump - 1) / jump; // the site's confirm look-ups are counted by the sweep that goes on
                     S.st_scan += first - p_start;
                     S.hi = first - 1;
                     S.ti = S.hi + k - 1;
@@ -3440,6 +3441,15 @@ int stage_b_pass(gp_job* job, uint32_t ki)
             }
             for (uint32_t m : mode)
                 whole += m == 2;
+            {
+                std::vector<SegState> stv(so2.size());
+                GP_HIP(hipMemcpy(stv.data(), b->seg_state.p, stv.size() * sizeof(SegState), hipMemcpyDeviceToHost));
+                for (size_t i = h_segs.size() - n_repairs; i < so2.size(); i++)
+                    if (so2[i].failed)
+                        fprintf(stderr, "WALKSEG k=%u: resume %zu (contig %u, starts %u..%u, from %u whose head stood at %u) failed with %u, head now %u\n",
+                                a.k, i, h_segs[i].cid, h_segs[i].p_begin, h_segs[i].p_end, h_segs[i].resume_from,
+                                stv[h_segs[i].resume_from].hi, so2[i].failed, stv[i].hi);
+            }
             fprintf(stderr, "WALKSEG k=%u: %zu contigs in %zu segments; failed: %u (walker not clean near the end) + %u (edit near "
                             "the end); %u repairs, %u of them failed; contigs walked whole again: %u\n",
                     a.k, h_segc.size(), h_segs.size() - n_repairs, f1, f2, n_repairs, fr, whole);
