@@ -35,7 +35,7 @@ struct StageBC {
     DevBuf<uint32_t> tile_contig, tile_first; // output tiles of materialize_kernel
     uint32_t n_tiles = 0;
     // long contigs walked as segments (stage_b.hip, SegDesc): per-pass descriptors and results
-    DevBuf<uint8_t> seg_desc, seg_out, seg_contigs, seg_req, seg_state; // SegDesc[], SegOut[], SegContig[], BoundaryReq[]
+    DevBuf<uint8_t> seg_desc, seg_out, seg_contigs, seg_req, seg_req2, seg_state; // SegDesc[], SegOut[], SegContig[], BoundaryReq[]
     DevBuf<uint32_t> seg_cut, contig_mode, seg_order;
     std::vector<uint64_t> h_off, h_node_off;
     int cur = 0;

@@ -228,6 +228,7 @@ struct Shared {
     int32_t prof_req;
     uint32_t seg_failed;      // a segment's walk worked on something too close to its end (1, 2) or gave up (3)
     uint32_t seg_busy;        // consecutive decisions of a segment's walker that were not "clean"
+    uint32_t seg_arrived;     // the segment's sweep reached its end
 };
 
 enum { REQ_DONE = 0, REQ_SCAN, REQ_SITE, REQ_NEXT, REQ_BITSCAN, REQ_REFILL, REQ_SWEEP };
@@ -1285,6 +1286,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
     if (tid == 0) {
         S.seg_failed = 0;
         S.seg_busy = 0;
+        S.seg_arrived = 0;
     }
     if (SEG && a.segs[seg_index].resume_from != 0xFFFFFFFFu) {
         // go on where descriptor resume_from stopped (its node list is this descriptor's, untouched)
@@ -1471,7 +1473,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             }
             if (SEG && S.seg_failed) {
                 // (given up just above)
-            } else if (SEG && seg_open &&
+            } else if (SEG && seg_open && S.hi < len &&
                 ((clean && a.site_rec != nullptr) ? S.hi + (S.cur_tested ? 1u : 0u) > seg_end
                                                   : (uint64_t)S.hi + seg_guard(k) >= seg_end)) {
                 // the walker is still among what an edit touched this close to the segment's end (or
@@ -1728,6 +1730,8 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                     if (p_start <= last_p)
                         S.st_scan += last_p + 1 - p_start;
                     S.req[nxt] = REQ_DONE; // nothing left that the reference could act on (a segment: arrived clean at its end)
+                    if (SEG)
+                        S.seg_arrived = 1;
                 } else if (SEG && seg_open && (uint64_t)first + seg_guard(k) >= seg_end) {
                     // an edit this close to the segment's end: park the (clean) walker just left of
                     // the site, as the bit scan does, so that whoever goes on sweeps into it first thing
@@ -2150,9 +2154,17 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
         // a segment's nodes with offsets from the segment's own start; merge_segments puts the
         // segments of a contig behind one another.  Bases [b_lo, b_hi) are this segment's.
         if (tid == 0) {
-            const uint32_t b_lo = seg_begin ? seg_begin + k - 1 : 0u, b_hi = seg_open ? seg_end + k - 1 : len;
+            // The walk of a contig can END inside it: after a refused insertion the reference looks for
+            // the next accepted k-mer along its node list and gives the contig up when it finds none
+            // (findAcceptedKmer returning "", ntedit.cpp:704-760: hi = len).  A segment whose walker
+            // ended like that is valid, everything right of it is not to be touched: code 4, its
+            // last node runs to the end of the contig, the host drops the segments behind it.
+            if (seg_open && !S.seg_failed && !S.seg_arrived)
+                S.seg_failed = 4;
+            const bool ended = S.seg_failed == 4;
+            const uint32_t b_lo = seg_begin ? seg_begin + k - 1 : 0u, b_hi = (seg_open && !ended) ? seg_end + k - 1 : len;
             uint32_t o = 0, live = 0;
-            const uint32_t nn = S.seg_failed ? 0u : S.nn; // (a failed segment's node list stays as the walker left it: it is gone on from)
+            const uint32_t nn = (S.seg_failed && !ended) ? 0u : S.nn; // (a failed segment's node list stays as the walker left it: it is gone on from)
             for (uint32_t ni = 0; ni < nn; ni++) {
                 Node n = c.nd[ni];
                 if (n.type == -1)
@@ -2187,7 +2199,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             so.st[2] = S.st_probes;
             so.st[3] = S.st_edits;
             a.seg_out[seg_index] = so;
-            if (S.seg_failed) {
+            if (S.seg_failed && !ended) {
                 SegState st;
                 st.hi = S.hi;
                 st.ti = S.ti;
@@ -2356,7 +2368,7 @@ __global__ __launch_bounds__(256) void merge_segments(WalkArgs a, const SegConti
         uint32_t f = 0, nn = 0, ol = 0;
         for (uint32_t j = 0; j < sc.n_seg; j++) {
             const SegOut& so = a.seg_out[a.seg_order[sc.seg_first + j]];
-            f |= so.failed;
+            f |= (so.failed != 0 && so.failed != 4) ? 1u : 0u;
             nn += so.n_nodes;
             ol += so.out_len;
         }
@@ -3349,22 +3361,30 @@ int stage_b_pass(gp_job* job, uint32_t ki)
         GP_HIP(hipStreamSynchronize(s));
         std::vector<uint32_t> order;
         std::vector<RestoreReq> restores;
+        std::vector<uint32_t> len_of(job->n_contigs, 0);
+        auto contig_len = [&](uint32_t cid) -> uint32_t {
+            if (!len_of[cid])
+                (void)hipMemcpy(&len_of[cid], a.len_cur + cid, 4, hipMemcpyDeviceToHost);
+            return len_of[cid];
+        };
         const size_t n_first = h_segs.size();
         for (SegContig& sc : h_segc) {
             const uint32_t first = sc.seg_first, n = sc.n_seg;
             sc.seg_first = (uint32_t)order.size();
-            uint32_t len_c = 0;
             bool gave_up = false;
             for (uint32_t j = 0; j < n; j++)
                 gave_up |= so[first + j].failed == 3;
             for (uint32_t j = 0; j < n;) {
-                if (!so[first + j].failed || gave_up) { // (a contig with a segment that gave up is walked whole: merge_segments sees the flag)
+                const uint32_t f = so[first + j].failed;
+                if (f == 0 || f == 4 || gave_up) { // (a contig with a segment that gave up is walked whole: merge_segments sees the flag)
                     order.push_back(first + j);
                     j++;
+                    if (f == 4 && !gave_up)
+                        break; // the contig's walk ended inside this segment: what lies behind it is dropped below
                     continue;
                 }
                 uint32_t m = j + 1;
-                while (m < n && so[first + m].failed)
+                while (m < n && (so[first + m].failed == 1 || so[first + m].failed == 2))
                     m++;
                 if (m >= n)
                     m = n - 1; // (the last segment cannot fail; kept for safety)
@@ -3375,9 +3395,7 @@ int stage_b_pass(gp_job* job, uint32_t ki)
                 d.p_end = h_segs[first + m].p_end;
                 d.node_cap = h_segs[first + m].node_first + h_segs[first + m].node_cap - d.node_first;
                 d.resume_from = first + j;
-                if (!len_c) {
-                    GP_HIP(hipMemcpy(&len_c, a.len_cur + d.cid, 4, hipMemcpyDeviceToHost));
-                }
+                const uint32_t len_c = contig_len(d.cid);
                 const uint32_t b_hi = d.p_end != 0xFFFFFFFFu ? std::min<uint32_t>(len_c, d.p_end + a.k - 1) : len_c;
                 restores.push_back({ d.cid, std::min(b_lo, b_hi), b_hi, 0 });
                 order.push_back((uint32_t)h_segs.size());
@@ -3412,7 +3430,41 @@ int stage_b_pass(gp_job* job, uint32_t ki)
                                reinterpret_cast<const RestoreReq*>(b->seg_req.p));
             a.seg_base = (uint32_t)n_first;
             launch_walk(n_repairs, true);
-            lap("repairs");
+            lap("resumes");
+            so.resize(h_segs.size());
+            GP_HIP(hipMemcpyAsync(so.data(), b->seg_out.p, so.size() * sizeof(SegOut), hipMemcpyDeviceToHost, s));
+            GP_HIP(hipStreamSynchronize(s));
+        }
+        // A walk that ENDED inside a segment (code 4) ended its contig: the descriptors behind it are
+        // dropped and the bases they edited come back from the pass's copy.
+        {
+            std::vector<RestoreReq> tails;
+            std::vector<uint32_t> kept;
+            for (SegContig& sc : h_segc) {
+                const uint32_t o0 = sc.seg_first, n = sc.n_seg;
+                sc.seg_first = (uint32_t)kept.size();
+                for (uint32_t j = 0; j < n; j++) {
+                    const uint32_t di = order[o0 + j];
+                    kept.push_back(di);
+                    if (so[di].failed == 4) {
+                        const uint32_t len_c = contig_len(sc.cid);
+                        if (j + 1 < n && h_segs[di].p_end != 0xFFFFFFFFu)
+                            tails.push_back({ sc.cid, std::min<uint32_t>(len_c, h_segs[di].p_end + a.k - 1), len_c, 0 });
+                        break;
+                    }
+                }
+                sc.n_seg = (uint32_t)kept.size() - sc.seg_first;
+            }
+            order.swap(kept);
+            if (!tails.empty()) {
+                // (seg_req may still be read by the restore of the resumes: a buffer of its own)
+                if ((rc = b->seg_req2.ensure(tails.size() * sizeof(RestoreReq))) != GP_OK)
+                    return rc;
+                GP_HIP(hipMemcpyAsync(b->seg_req2.p, tails.data(), tails.size() * sizeof(RestoreReq), hipMemcpyHostToDevice, s));
+                GP_HIP(hipStreamSynchronize(s));
+                hipLaunchKernelGGL(restore_ranges, dim3(64, (unsigned)tails.size()), dim3(256), 0, s, a,
+                                   reinterpret_cast<const RestoreReq*>(b->seg_req2.p));
+            }
         }
         GP_HIP(hipMemcpyAsync(b->seg_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, s));
         GP_HIP(hipMemcpyAsync(b->seg_contigs.p, h_segc.data(), h_segc.size() * sizeof(SegContig), hipMemcpyHostToDevice, s));
