@@ -3448,7 +3448,7 @@ int stage_b_pass(gp_job* job, uint32_t ki)
                     kept.push_back(di);
                     if (so[di].failed == 4) {
                         const uint32_t len_c = contig_len(sc.cid);
-                        if (j + 1 < n && h_segs[di].p_end != 0xFFFFFFFFu)
+                        if (h_segs[di].p_end != 0xFFFFFFFFu) // (segments lay behind it: they ran, whether they are still listed or not)
                             tails.push_back({ sc.cid, std::min<uint32_t>(len_c, h_segs[di].p_end + a.k - 1), len_c, 0 });
                         break;
                     }
