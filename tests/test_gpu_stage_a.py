@@ -66,11 +66,18 @@ def run_and_compare(core, ctx, oracle, w, params, batch_contig_begin=None):
         job.close()
 
 
-def test_filters_match_oracle_default_sizes(gp, oracle):
+def test_filters_match_oracle_default_sizes(gp, oracle, stage_a_path):
     core, ctx = gp
     w = synth.make_workload([25000, 9000, 14000], 30, seed=11)
     c = run_and_compare(core, ctx, oracle, w, core.default_params())
     assert c["a_ops"] > 0 and c["a_ordered_ops"] > 0
+    # the schedule the fixture asked for is the one that ran (a silent fall-back would still match the oracle)
+    if stage_a_path == "grid":
+        assert c["a_reservations"] > 0 and c["a_replayed"] == 0
+    elif stage_a_path == "local":
+        assert c["a_reservations"] == 0 and c["a_replayed"] == c["a_ops"]
+    else:
+        assert c["a_reservations"] == 0 and 0 < c["a_replayed"] < c["a_ops"] // 2
 
 
 def test_small_filters_heavy_collisions_and_saturation(gp, oracle):
