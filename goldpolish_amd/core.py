@@ -36,7 +36,7 @@ SYMBOLS = [
     "gp_jobs_polish", "gp_filter_save", "gp_filter_save_btllib", "gp_filter_load", "gp_job_write_fasta",
     "gp_sealer_consensus", "gp_device_pool_bytes", "gp_device_pool_trim",
     "gp_pipeline_create", "gp_pipeline_submit", "gp_pipeline_collect", "gp_pipeline_kernel_time",
-    "gp_pipeline_destroy",
+    "gp_pipeline_destroy", "gp_job_reset",
 ]
 
 
@@ -138,7 +138,7 @@ def load_library(path=None):
                                 C.POINTER(C.c_void_p)]
     L.gp_job_destroy.argtypes = [C.c_void_p]
     for name in ("gp_job_polish", "gp_job_build_filters", "gp_job_ntedit_guard", "gp_job_mask",
-                 "gp_job_sealer", "gp_job_upper"):
+                 "gp_job_sealer", "gp_job_upper", "gp_job_reset"):
         getattr(L, name).argtypes = [C.c_void_p, C.c_int]
     L.gp_job_ntedit_pass.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
     L.gp_jobs_polish.argtypes = [C.POINTER(C.c_void_p), C.c_uint32]
@@ -597,6 +597,9 @@ class Job:
 
     def ntedit_pass(self, ki, sync=True):
         _check(lib().gp_job_ntedit_pass(self._h, ki, int(sync)))
+
+    def reset(self, sync=True):
+        _check(lib().gp_job_reset(self._h, int(sync)))
 
     def ntedit_guard(self, sync=True):
         _check(lib().gp_job_ntedit_guard(self._h, int(sync)))

@@ -693,6 +693,16 @@ try {
     return finish(job, rc, sync);
 } GP_CATCH("gp_job_ntedit_pass")
 
+int gp_job_reset(gp_job* job, int sync)
+try {
+    if (!job)
+        return GP_ERR_INVALID_ARG;
+    GP_HIP(hipSetDevice(job->ctx->device));
+    if (int rcb = ensure_work(job, "gp_job_reset"))
+        return rcb;
+    return finish(job, stage_b_reset(job), sync);
+} GP_CATCH("gp_job_reset")
+
 int gp_job_ntedit_guard(gp_job* job, int sync)
 try {
     if (!job)

@@ -191,7 +191,10 @@ int gp_job_polish(gp_job* job, int sync);
  * while the call runs.  Returns the first failing job's status, its message prefixed with the
  * job's index. */
 int gp_jobs_polish(gp_job* const* jobs, uint32_t n_jobs);
-/* Individual stages, in order, for tests and profiling. */
+/* Individual stages, in order: for tests, profiling and the per-tool programs (examples/gp_tools.cpp). */
+/* current sequences := the uploaded contigs (what gp_job_ntedit_pass(job, 0, ..) does before its
+ * pass): lets a later stage run on the inputs as they are, e.g. Sealer alone as `sealer-gr` does */
+int gp_job_reset(gp_job* job, int sync);
 int gp_job_build_filters(gp_job* job, int sync);          /* stage A */
 int gp_job_ntedit_pass(gp_job* job, uint32_t k_index, int sync); /* stage B, one k */
 int gp_job_ntedit_guard(gp_job* job, int sync);           /* 0.75 byte-ratio guard */
