@@ -93,7 +93,7 @@ struct CState {
     DevBuf<uint32_t> fill_len;     // [G] 0 = not closed
     DevBuf<uint32_t> table_left, table_pair; // exact hash sets, value = gap index + 1
     DevBuf<uint32_t> work;         // valid gaps
-    DevBuf<uint32_t> defer, defer2; // gaps the small / the medium lane arenas could not settle
+    DevBuf<uint32_t> defer;        // gaps left for the one-per-wave workers
     DevBuf<uint8_t> small;         // kSimtWaves x kSimtLanes lane arenas (SmallArena)
     DevBuf<uint32_t> queue;        // [0] work count [1] head [2] multi count [3] multi head
     DevBuf<uint8_t> pool;          // fills and connecting sequences
@@ -139,8 +139,7 @@ struct CArgs {
     uint32_t* table_pair;
     uint32_t table_bits;
     uint32_t* work;
-    uint32_t* defer;     // gaps phase 1 (lane per gap, small arenas) left over, count in queue[4]
-    uint32_t* defer2;    // ... and what phase 1b (medium arenas) left for phase 2, count in queue[6]
+    uint32_t* defer;     // gaps phase 1 (lane per gap) left for phase 2, count in queue[4]
     uint32_t* queue;
     uint8_t* pool;
     unsigned long long* pool_head;
@@ -368,7 +367,7 @@ struct Search {
     SeedTab st;
     uint32_t* slots;
     uint32_t epoch;
-    uint32_t slot_mask, tag_shift, vert_cap, edge_cap; // of the arena in use: slots - 1, where an entry's epoch tag starts, room
+    uint32_t slot_bits, vert_cap, edge_cap; // of the arena in use (a worker's big one or a lane's small one)
     bool small;                              // lane-per-gap attempt: no room for path enumeration
     Vert* v;
     Edge* e;
@@ -489,12 +488,12 @@ __device__ inline uint64_t mix_km(uint64_t a, uint64_t b)
 
 __device__ uint32_t vert_get(Search& S, const uint64_t km[2], uint64_t fh, uint64_t rh)
 {
-    const uint32_t id_mask = (1u << S.tag_shift) - 1u;
-    uint32_t slot = (uint32_t)(mix_km(km[0], km[1]) >> 40) & S.slot_mask;
-    const uint32_t tag = S.epoch << S.tag_shift;
+    const uint32_t n_slots = 1u << S.slot_bits;
+    uint32_t slot = (uint32_t)(mix_km(km[0], km[1]) >> 40) & (n_slots - 1);
+    const uint32_t tag = S.epoch << S.slot_bits;
     for (;;) {
         uint32_t sv = S.slots[slot];
-        if ((sv & ~id_mask) != tag || sv == 0) {
+        if ((sv & ~(n_slots - 1)) != tag || sv == 0) {
             // empty for this search
             if (S.nv >= S.vert_cap - 1) {
                 S.overflow = true;
@@ -513,10 +512,10 @@ __device__ uint32_t vert_get(Search& S, const uint64_t km[2], uint64_t fh, uint6
             S.slots[slot] = tag | (id + 1);
             return id;
         }
-        uint32_t id = (sv & id_mask) - 1;
+        uint32_t id = (sv & (n_slots - 1)) - 1;
         if (S.v[id].km[0] == km[0] && S.v[id].km[1] == km[1])
             return id;
-        slot = (slot + 1) & S.slot_mask;
+        slot = (slot + 1) & (n_slots - 1);
     }
 }
 
@@ -861,19 +860,6 @@ __device__ void write_merged(const CArgs& a, uint32_t gi, const uint8_t* r1, uin
     a.fill_len[gi] = lm;
 }
 
-// A lane's arena for a lane-per-gap attempt: a small one of its own (SmallArena below, cleared per
-// gap), or a 32nd of a worker's big arena (medium: 4096 vertices; its slot entries carry the
-// worker's epoch like the big arena's, so nothing is cleared)
-struct LaneArena {
-    Vert* v;
-    Edge* e;
-    uint32_t* slots;
-    uint32_t* q0;
-    uint32_t* q1;
-    uint32_t vert_cap, edge_cap, slot_mask, tag_shift, epoch;
-    bool clear; // the slots are the lane's own and are zeroed before the search
-};
-
 struct SmallArena {
     Vert v[kSmallVerts];
     Edge e[kSmallEdges];
@@ -885,7 +871,7 @@ struct SmallArena {
 // when the gap has to be done again by a worker (arena too small, or paths to enumerate) --
 // nothing of such an attempt is counted or written.
 __device__ bool connect_one(const CArgs& a, Search& S, uint32_t gi, uint32_t wid, uint8_t* r1,
-                            uint8_t* r2, uint8_t* tmp, const LaneArena* sm)
+                            uint8_t* r2, uint8_t* tmp, SmallArena* sm)
 {
     const Gap g = a.gaps[gi];
     // still in `flanks`?  (last gap of its flank pair, left flank not closed at a larger k)
@@ -928,19 +914,17 @@ __device__ bool connect_one(const CArgs& a, Search& S, uint32_t gi, uint32_t wid
     S.small = sm != nullptr;
     if (sm) {
         // ---- lane-private small arena
-        if (sm->clear)
-            for (uint32_t i = 0; i <= sm->slot_mask; i++)
-                sm->slots[i] = 0;
+        for (uint32_t i = 0; i < (1u << kSmallSlotBits); i++)
+            sm->slots[i] = 0;
         S.slots = sm->slots;
-        S.epoch = sm->epoch;
-        S.slot_mask = sm->slot_mask;
-        S.tag_shift = sm->tag_shift;
-        S.vert_cap = sm->vert_cap;
-        S.edge_cap = sm->edge_cap;
+        S.epoch = 1;
+        S.slot_bits = kSmallSlotBits;
+        S.vert_cap = kSmallVerts;
+        S.edge_cap = kSmallEdges;
         S.v = sm->v;
         S.e = sm->e;
-        S.q[0] = sm->q0;
-        S.q[1] = sm->q1;
+        S.q[0] = sm->q[0];
+        S.q[1] = sm->q[1];
         S.dfs_path = S.dfs_it = S.left = S.right = S.found = nullptr;
     } else {
         // ---- this worker's arena
@@ -953,8 +937,7 @@ __device__ bool connect_one(const CArgs& a, Search& S, uint32_t gi, uint32_t wid
         }
         a.epoch[wid] = ep;
         S.epoch = ep;
-        S.slot_mask = kSlots - 1;
-        S.tag_shift = kSlotBits;
+        S.slot_bits = kSlotBits;
         S.vert_cap = kVertCap;
         S.edge_cap = kEdgeCap;
         S.v = a.verts + (uint64_t)wid * kVertCap;
@@ -1063,18 +1046,6 @@ __global__ __launch_bounds__(64) void sealer_connect_lanes(CArgs a, SmallArena* 
     const uint32_t lane = threadIdx.x;
     const uint32_t n_work = a.queue[0];
     SmallArena* mine = arenas + (uint64_t)blockIdx.x * kSimtLanes + (lane % kSimtLanes);
-    LaneArena la;
-    la.v = mine->v;
-    la.e = mine->e;
-    la.slots = mine->slots;
-    la.q0 = mine->q[0];
-    la.q1 = mine->q[1];
-    la.vert_cap = kSmallVerts;
-    la.edge_cap = kSmallEdges;
-    la.slot_mask = (1u << kSmallSlotBits) - 1u;
-    la.tag_shift = kSmallSlotBits;
-    la.epoch = 1;
-    la.clear = true;
     Search S;
     uint8_t r1[64], r2[64];
     for (;;) {
@@ -1087,70 +1058,8 @@ __global__ __launch_bounds__(64) void sealer_connect_lanes(CArgs a, SmallArena* 
         const uint32_t it = base + lane;
         if (lane < kSimtLanes && it < n_work) {
             const uint32_t gi = a.work[it];
-            if (connect_one(a, S, gi, 0, r1, r2, nullptr, &la))
+            if (connect_one(a, S, gi, 0, r1, r2, nullptr, mine))
                 a.defer[atomicAdd(&a.queue[4], 1u)] = gi;
-        }
-    }
-}
-
-// Phase 1b: what outgrew the small arenas, again one gap per LANE, in a 32nd of a worker's big
-// arena each (4096 vertices, 8192 edges, 8192 slots): most of it is searches that end at a limit
-// -- 1000 open branches, the cost cap -- after a few thousand vertices and never have a path to
-// enumerate; they were 2 of the 11.5 s of a step on megabase contigs (34 000 of them per step, one
-// lane of a wave each).  Slot entries carry the worker's epoch like the big arena's (a unique one
-// per search: the counter is the worker's), so nothing is cleared.  What still does not fit, or
-// finds paths, goes on to phase 2.
-constexpr uint32_t kMedVerts = kVertCap / kSimtLanes, kMedEdges = 2 * kMedVerts, kMedSlots = kSlots / kSimtLanes;
-__global__ __launch_bounds__(64) void sealer_connect_lanes_medium(CArgs a)
-{
-    const uint32_t wid = blockIdx.x, lane = threadIdx.x;
-    const uint32_t n_work = a.queue[4];
-    // an epoch counter about to run out of tag bits: the wave clears its slots once, together
-    if (a.epoch[wid] + 8192u >= (1u << (32 - kSlotBits))) {
-        for (uint32_t i = lane; i < kSlots; i += 64)
-            a.slots[(uint64_t)wid * kSlots + i] = 0;
-        __syncthreads();
-        if (lane == 0)
-            a.epoch[wid] = 0;
-        __syncthreads();
-    }
-    LaneArena la;
-    la.v = a.verts + (uint64_t)wid * kVertCap + (uint64_t)(lane % kSimtLanes) * kMedVerts;
-    la.e = a.edges + (uint64_t)wid * kEdgeCap + (uint64_t)(lane % kSimtLanes) * kMedEdges;
-    la.slots = a.slots + (uint64_t)wid * kSlots + (uint64_t)(lane % kSimtLanes) * kMedSlots;
-    uint32_t* sc = a.scratch + (uint64_t)wid * kScratchWords;
-    la.q0 = sc + (uint64_t)(lane % kSimtLanes) * kMedVerts;
-    la.q1 = sc + kVertCap + (uint64_t)(lane % kSimtLanes) * kMedVerts;
-    la.vert_cap = kMedVerts;
-    la.edge_cap = kMedEdges;
-    la.slot_mask = kMedSlots - 1u;
-    la.tag_shift = kSlotBits;
-    la.clear = false;
-    Search S;
-    uint8_t r1[64], r2[64];
-    for (uint32_t round = 0;; round++) {
-        uint32_t base = 0;
-        if (lane == 0)
-            base = atomicAdd(&a.queue[5], kSimtLanes);
-        base = __shfl(base, 0);
-        if (base >= n_work || round >= 240u) // (a wave takes at most 240 x 32 searches: its epochs last for them)
-            break;
-        const uint32_t it = base + lane;
-        if (lane < kSimtLanes && it < n_work) {
-            const uint32_t gi = a.defer[it];
-            la.epoch = atomicAdd(&a.epoch[wid], 1u) + 1u;
-            if (connect_one(a, S, gi, 0, r1, r2, nullptr, &la))
-                a.defer2[atomicAdd(&a.queue[6], 1u)] = gi;
-        }
-    }
-    // a wave that stopped early leaves the rest of the list to phase 2
-    if (lane == 0) {
-        for (;;) {
-            const uint32_t base = atomicAdd(&a.queue[5], kSimtLanes);
-            if (base >= n_work)
-                break;
-            for (uint32_t it = base; it < min(base + kSimtLanes, n_work); it++)
-                a.defer2[atomicAdd(&a.queue[6], 1u)] = a.defer[it];
         }
     }
 }
@@ -1162,10 +1071,10 @@ __global__ __launch_bounds__(64) void sealer_connect(CArgs a)
     __shared__ uint8_t r1[64], r2[64], tmp[kPathCap + 64];
     __shared__ uint32_t item;
     const uint32_t wid = blockIdx.x, lane = threadIdx.x;
-    const uint32_t n_work = a.queue[6];
+    const uint32_t n_work = a.queue[4];
     for (;;) {
         if (lane == 0)
-            item = atomicAdd(&a.queue[7], 1u);
+            item = atomicAdd(&a.queue[5], 1u);
         __syncthreads();
         const uint32_t it = item;
         __syncthreads();
@@ -1173,7 +1082,7 @@ __global__ __launch_bounds__(64) void sealer_connect(CArgs a)
             break; // every wave leaves here once the list has drained
         // one lane walks the graph; the wave reconverges before the next fetch
         if (lane == 0)
-            (void)connect_one(a, S, a.defer2[it], wid, r1, r2, tmp, nullptr);
+            (void)connect_one(a, S, a.defer[it], wid, r1, r2, tmp, nullptr);
     }
 }
 
@@ -1656,7 +1565,7 @@ int stage_c_prepare(gp_job* job)
         (rc = c->closed_at.alloc(g)) != GP_OK || (rc = c->fill_off.alloc(g)) != GP_OK ||
         (rc = c->fill_len.alloc(g)) != GP_OK || (rc = c->table_left.alloc(1ull << tb)) != GP_OK ||
         (rc = c->table_pair.alloc(1ull << tb)) != GP_OK || (rc = c->work.alloc(g)) != GP_OK ||
-        (rc = c->defer.alloc(g)) != GP_OK || (rc = c->defer2.alloc(g)) != GP_OK ||
+        (rc = c->defer.alloc(g)) != GP_OK ||
         (rc = c->small.alloc((uint64_t)kSimtWaves * kSimtLanes * sizeof(SmallArena))) != GP_OK ||
         (rc = c->queue.alloc(8)) != GP_OK || (rc = c->pool.alloc(c->pool_cap)) != GP_OK ||
         (rc = c->pool_head.alloc(1)) != GP_OK || (rc = c->multi.alloc(c->multi_cap)) != GP_OK ||
@@ -1722,7 +1631,6 @@ int stage_c_run(gp_job* job)
     a.table_bits = c->table_bits;
     a.work = c->work.p;
     a.defer = c->defer.p;
-    a.defer2 = c->defer2.p;
     a.queue = c->queue.p;
     a.pool = c->pool.p;
     a.pool_head = c->pool_head.p;
@@ -1757,10 +1665,9 @@ int stage_c_run(gp_job* job)
         // queue heads back to 0, counts stay
         GP_HIP(hipMemsetAsync(c->queue.p + 1, 0, sizeof(uint32_t), s));
         GP_HIP(hipMemsetAsync(c->queue.p + 2, 0, 2 * sizeof(uint32_t), s));
-        GP_HIP(hipMemsetAsync(c->queue.p + 4, 0, 4 * sizeof(uint32_t), s));
+        GP_HIP(hipMemsetAsync(c->queue.p + 4, 0, 2 * sizeof(uint32_t), s));
         hipLaunchKernelGGL(sealer_connect_lanes, dim3(kSimtWaves), dim3(64), 0, s, a,
                            reinterpret_cast<SmallArena*>(c->small.p));
-        hipLaunchKernelGGL(sealer_connect_lanes_medium, dim3(c->n_workers), dim3(64), 0, s, a);
         hipLaunchKernelGGL(sealer_connect, dim3(c->n_workers), dim3(64), 0, s, a);
         hipLaunchKernelGGL(sealer_consensus, dim3(kNwWorkers), dim3(64), 0, s, a);
     }
