@@ -360,6 +360,7 @@ def main():
         pipe = core.Pipeline(device_index, params, depth=2)
         sums, times = [], {"upload_ms": [], "polish_ms": [], "download_ms": []}
         last = {}
+        pinned = {}
 
         def step(tag, timed):
             r = pipe.collect(copy=False)
@@ -379,7 +380,20 @@ def main():
                     payload = torch.from_numpy(data)
                 got = gather_to_rank0(lens_t, payload, rank, world)
                 if rank == 0:
-                    host = [(l.cpu(), b.cpu()) for l, b in got[1:]]
+                    # ... in pinned host buffers kept from step to step (a pageable .cpu() of 7 x 375 MB
+                    # would cost more than the gather itself)
+                    host = []
+                    for i, (l, b) in enumerate(got[1:]):
+                        if on_gpu:
+                            hb = pinned.get(i)
+                            if hb is None or hb.numel() < b.numel():
+                                hb = pinned[i] = torch.empty(int(b.numel() * 1.1) + 4096, dtype=torch.uint8, pin_memory=True)
+                            hb[:b.numel()].copy_(b, non_blocking=True)
+                            host.append((l.cpu(), hb[:b.numel()]))
+                        else:
+                            host.append((l, b))
+                    if on_gpu:
+                        torch.cuda.synchronize()
                     last["gathered"] = (sum(int(l.numel()) for l, _ in host) + r["lengths"].size,
                                         sum(int(b.numel()) for _, b in host) + n)
             sums.append((r["total_bytes"], word_sum(data)))

@@ -57,3 +57,34 @@ def test_jobs_must_have_contexts_of_their_own_and_errors_name_the_job():
         core.polish_jobs([a])
         a.close()
         b.close()
+
+
+def test_a_job_without_reads_among_pipelined_jobs(oracle):
+    """gp_jobs_polish with a legal job that has no reads at all (its filters are empty: nothing to
+    edit, every soft-masked gap stays): the filter build of such a job returns at once, and the back
+    half on the other stream must still find its filters cleared (round 2 left the clearing in flight)"""
+    from goldpolish_amd import core
+    w = synth.make_workload([9000, 5000, 7000], 25, seed=33)
+    p = core.default_params()
+    parts = [core.slice_workload(w, 0, 1), core.slice_workload(w, 1, 2), core.slice_workload(w, 2, 3)]
+    # the middle job loses its reads
+    parts[1]["read_buf"] = np.zeros(0, np.uint8)
+    parts[1]["read_off"] = np.zeros(1, np.uint64)
+    parts[1]["contig_read_begin"] = np.zeros(2, np.uint32)
+    ctxs = [core.Context(0) for _ in parts]
+    jobs = [core.Job(c, p, **kw) for c, kw in zip(ctxs, parts)]
+    try:
+        for _ in range(3):
+            core.polish_jobs(jobs)
+            got = [j.sequences()[0] for j in jobs]
+            for i in (0, 2):
+                outs, _, _ = oracle.polish_batch([w.names[i]], [w.contig(i)], [w.reads_of(i)], [int(w.kmer_threshold[i])])
+                assert got[i] == outs[0], i
+            outs, _, _ = oracle.polish_batch([w.names[1]], [w.contig(1)], [[]], [int(w.kmer_threshold[1])])
+            assert got[1] == outs[0]
+            assert not np.any(jobs[1].get_filter(0, 0))
+    finally:
+        for j in jobs:
+            j.close()
+        for c in ctxs:
+            c.close()
