@@ -611,11 +611,11 @@ def main():
             "workload": desc_main,
             "timed_region": "SURVEY 8d: reads + contigs resident in host memory -> polished bytes in host memory at "
                             "rank 0, steady state: every step holds one upload (H2D, beside the polishing of the step "
-                            "before), the path, the download (D2H)" + (" and the RCCL gather" if world > 1 else ""),
+                            "before), the path, the download (D2H)" + (" and the gather on rank 0" if world > 1 else ""),
             "contigs_per_gpu": main_res["n_contigs"], "bp_per_gpu": main_res["bp_per_rank"], "bp_total": total_bp,
             "read_coverage": round(main_res["coverage"], 2), "k": ",".join(map(str, ks_main)),
             "parallelism": f"batches sharded over {world} GPU(s), one process per GPU; gp_pipeline (upload | polish | "
-                           "collect) per GPU" + (", gather of polished records to rank 0 (RCCL)" if world > 1 else ""),
+                           "collect) per GPU" + ((", gather of polished records to rank 0 (" + ("RCCL" if on_gpu else "gloo rehearsal") + ")") if world > 1 else ""),
             "device_GiB_in_use": round(main_res["device_bytes"] / 2**30, 1),
             **extra_cfg,
         },
