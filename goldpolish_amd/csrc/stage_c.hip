@@ -49,7 +49,14 @@ constexpr uint32_t kSmallSlotBits = 8, kSmallVerts = 96, kSmallEdges = 256;
 constexpr uint32_t kSimtWaves = 3072;   // waves of the lane-per-gap kernel (three per SIMD is what its registers allow) ...
 constexpr uint32_t kSimtLanes = 32;     // ... and the lanes of each that take a gap (divergent walks serialise)
 constexpr uint32_t kNwMax = 1800;            // longest sequence the consensus aligner takes
-constexpr uint32_t kMaxWorkers = 3072;  // one-wave workers of sealer_connect, 13 MB of arena each (CState::n_workers: by job size)
+constexpr uint32_t kMaxWorkers = 3072;  // one-wave workers of sealer_connect (CState::n_workers: by job size)
+// Their arenas come in two sizes.  Nearly every search a worker takes stays below a few thousand
+// vertices (limit 1000 open branches), so the 3072 workers of the first pass hold 8192 vertices each
+// (1 MB with edges, slots, queues and path scratch: 3 GiB), and what outgrows that -- the cost cap of
+// 100 000 allows 131 072 vertices -- is done again by at most 256 workers with full arenas (13 MB
+// each: 3.3 GiB).  Round 2 gave all 3072 workers full arenas: 39 GiB for a stage of 0.15 s.
+constexpr uint32_t kMedSlotBits = 14, kMedVertCap = 1u << 13, kMedEdgeCap = 2u * kMedVertCap + 64;
+constexpr uint32_t kBigWorkers = 256;
 constexpr int kNwWorkers = 16;
 
 enum { FWD = 0, REV = 1 };
@@ -103,7 +110,11 @@ struct CState {
     DevBuf<uint32_t> slots;
     DevBuf<Vert> verts;
     DevBuf<Edge> edges;
-    DevBuf<uint32_t> scratch;      // queues, stacks, paths
+    DevBuf<uint32_t> scratch;      // queues, stacks, paths (the full arenas of kBigWorkers workers)
+    DevBuf<uint32_t> m_slots, m_scratch, m_epoch; // the medium arenas of n_workers workers
+    DevBuf<Vert> m_verts;
+    DevBuf<Edge> m_edges;
+    DevBuf<uint32_t> defer2;       // gaps that outgrew a medium arena
     DevBuf<int32_t> nw;
     DevBuf<uint32_t> epoch;        // per worker
     std::vector<uint32_t> h_gap_off;
@@ -112,9 +123,10 @@ struct CState {
     uint64_t pool_cap = 0;
 };
 
-constexpr uint32_t kScratchWords = 2 * kVertCap            // two BFS queues
-                                   + 4 * kPathCap          // DFS path + iterator stacks
-                                   + 3 * kMaxPathsDev * kPathCap; // left, right, found paths
+constexpr uint32_t kPathScratchWords = 4 * kPathCap                   // DFS path + iterator stacks
+                                       + 3 * kMaxPathsDev * kPathCap; // left, right, found paths
+constexpr uint32_t kScratchWords = 2 * kVertCap + kPathScratchWords;       // two BFS queues + path scratch (full arena)
+constexpr uint32_t kMedScratchWords = 2 * kMedVertCap + kPathScratchWords; // (medium arena)
 
 struct CArgs {
     const uint8_t* seq;      // masked sequences (stage input)
@@ -150,6 +162,13 @@ struct CArgs {
     Vert* verts;
     Edge* edges;
     uint32_t* scratch;
+    uint32_t* m_slots;   // medium arenas (first pass of sealer_connect), see kMedVertCap
+    Vert* m_verts;
+    Edge* m_edges;
+    uint32_t* m_scratch;
+    uint32_t* m_epoch;
+    uint32_t* defer2;    // gaps the medium arenas could not hold, count in queue[6]
+    uint32_t tier;       // sealer_connect: 0 medium arenas (what overflows goes to defer2), 1 full arenas over defer2
     int32_t* nw;
     uint32_t* epoch;
     uint32_t* err;
@@ -369,6 +388,7 @@ struct Search {
     uint32_t epoch;
     uint32_t slot_bits, vert_cap, edge_cap; // of the arena in use (a worker's big one or a lane's small one)
     bool small;                              // lane-per-gap attempt: no room for path enumeration
+    bool retry_on_overflow;                  // a larger arena takes the gap if this one runs out: whatever else was flagged is not final
     Vert* v;
     Edge* e;
     uint32_t nv, ne;
@@ -782,8 +802,8 @@ __device__ int bidi_search(Search& S)
         else if (dir == FWD && S.qh[REV] < S.qt[REV])
             dir = REV;
     }
-    if (S.small && S.overflow)
-        return R_MEM; // the small arena ran out: whatever else was flagged is not final
+    if (S.retry_on_overflow && S.overflow)
+        return R_MEM; // the arena ran out and a larger one follows: whatever else was flagged is not final
     if (S.too_many_paths)
         return R_TOO_MANY_PATHS;
     if (S.too_many_branches)
@@ -912,6 +932,7 @@ __device__ bool connect_one(const CArgs& a, Search& S, uint32_t gi, uint32_t wid
         return false;
     }
     S.small = sm != nullptr;
+    S.retry_on_overflow = sm != nullptr || a.tier == 0;
     if (sm) {
         // ---- lane-private small arena
         for (uint32_t i = 0; i < (1u << kSmallSlotBits); i++)
@@ -927,25 +948,29 @@ __device__ bool connect_one(const CArgs& a, Search& S, uint32_t gi, uint32_t wid
         S.q[1] = sm->q[1];
         S.dfs_path = S.dfs_it = S.left = S.right = S.found = nullptr;
     } else {
-        // ---- this worker's arena
-        uint32_t ep = a.epoch[wid] + 1;
-        S.slots = a.slots + (uint64_t)wid * kSlots;
-        if (ep >= (1u << (32 - kSlotBits))) {
-            for (uint32_t i = 0; i < kSlots; i++)
+        // ---- this worker's arena: a medium one in the first pass, a full one for what outgrew that
+        const bool med = a.tier == 0;
+        const uint32_t sbits = med ? kMedSlotBits : kSlotBits, vcap = med ? kMedVertCap : kVertCap;
+        const uint32_t ecap = med ? kMedEdgeCap : kEdgeCap;
+        uint32_t* const epoch_of = (med ? a.m_epoch : a.epoch) + wid;
+        uint32_t ep = *epoch_of + 1;
+        S.slots = med ? a.m_slots + ((uint64_t)wid << kMedSlotBits) : a.slots + (uint64_t)wid * kSlots;
+        if (ep >= (1u << (32 - sbits))) {
+            for (uint32_t i = 0; i < (1u << sbits); i++)
                 S.slots[i] = 0;
             ep = 1;
         }
-        a.epoch[wid] = ep;
+        *epoch_of = ep;
         S.epoch = ep;
-        S.slot_bits = kSlotBits;
-        S.vert_cap = kVertCap;
-        S.edge_cap = kEdgeCap;
-        S.v = a.verts + (uint64_t)wid * kVertCap;
-        S.e = a.edges + (uint64_t)wid * kEdgeCap;
-        uint32_t* sc = a.scratch + (uint64_t)wid * kScratchWords;
+        S.slot_bits = sbits;
+        S.vert_cap = vcap;
+        S.edge_cap = ecap;
+        S.v = med ? a.m_verts + (uint64_t)wid * kMedVertCap : a.verts + (uint64_t)wid * kVertCap;
+        S.e = med ? a.m_edges + (uint64_t)wid * kMedEdgeCap : a.edges + (uint64_t)wid * kEdgeCap;
+        uint32_t* sc = med ? a.m_scratch + (uint64_t)wid * kMedScratchWords : a.scratch + (uint64_t)wid * kScratchWords;
         S.q[0] = sc;
-        S.q[1] = sc + kVertCap;
-        S.dfs_path = sc + 2 * kVertCap;
+        S.q[1] = sc + vcap;
+        S.dfs_path = sc + 2 * vcap;
         S.dfs_it = S.dfs_path + 2 * kPathCap;
         S.left = S.dfs_it + 2 * kPathCap;
         S.right = S.left + kMaxPathsDev * kPathCap;
@@ -994,6 +1019,8 @@ __device__ bool connect_one(const CArgs& a, Search& S, uint32_t gi, uint32_t wid
     const int rc = bidi_search(S);
     if (sm && (rc == R_DEFER || rc == R_MEM))
         return true;
+    if (!sm && a.tier == 0 && rc == R_MEM)
+        return true; // outgrew the medium arena: a worker with a full one does it again (nothing counted, nothing written)
     atomicAdd(&a.stats[6], S.tests);
     if (S.overflow)
         atomicOr(a.err, 64u);
@@ -1064,25 +1091,29 @@ __global__ __launch_bounds__(64) void sealer_connect_lanes(CArgs a, SmallArena* 
     }
 }
 
-// Phase 2: one gap per wave, lane 0 walking, with the worker's big arena: whatever phase 1 left
+// Phase 2: one gap per wave, lane 0 walking: whatever phase 1 left.  Launched twice: tier 0, every
+// worker with a medium arena over phase 1's list (what outgrows it goes to a second list); tier 1,
+// a few workers with full arenas over that list.
 __global__ __launch_bounds__(64) void sealer_connect(CArgs a)
 {
     __shared__ Search S;
     __shared__ uint8_t r1[64], r2[64], tmp[kPathCap + 64];
     __shared__ uint32_t item;
     const uint32_t wid = blockIdx.x, lane = threadIdx.x;
-    const uint32_t n_work = a.queue[4];
+    const uint32_t* const list = a.tier == 0 ? a.defer : a.defer2;
+    uint32_t* const head = a.queue + (a.tier == 0 ? 5 : 7);
+    const uint32_t n_work = a.queue[a.tier == 0 ? 4 : 6];
     for (;;) {
         if (lane == 0)
-            item = atomicAdd(&a.queue[5], 1u);
+            item = atomicAdd(head, 1u);
         __syncthreads();
         const uint32_t it = item;
         __syncthreads();
         if (it >= n_work)
             break; // every wave leaves here once the list has drained
         // one lane walks the graph; the wave reconverges before the next fetch
-        if (lane == 0)
-            (void)connect_one(a, S, a.defer[it], wid, r1, r2, tmp, nullptr);
+        if (lane == 0 && connect_one(a, S, list[it], wid, r1, r2, tmp, nullptr))
+            a.defer2[atomicAdd(&a.queue[6], 1u)] = list[it];
     }
 }
 
@@ -1555,10 +1586,10 @@ int stage_c_prepare(gp_job* job)
     c->table_bits = tb;
     c->multi_cap = (uint32_t)std::min<uint64_t>(g, 1u << 20);
     c->pool_cap = 2 * total_len + (16ull << 20);
-    // a worker per 4 kbp of contigs, 256 at least (3 GiB of arenas), kMaxWorkers (39 GiB) from 12 Mbp on
+    // a worker per 4 kbp of contigs, 256 at least, kMaxWorkers from 12 Mbp on (3 GiB of medium arenas + 3.3 GiB of full ones)
     c->n_workers = (uint32_t)std::min<uint64_t>(
         kMaxWorkers, std::max<uint64_t>(256, env_u64("GP_SEALER_WORKERS", total_len / 4096)));
-    const uint64_t n_workers = c->n_workers;
+    const uint64_t n_workers = c->n_workers, n_big = std::min<uint64_t>(n_workers, kBigWorkers);
     int rc;
     if ((rc = c->gaps.alloc(g)) != GP_OK || (rc = c->gap_off.alloc((size_t)n + 1)) != GP_OK ||
         (rc = c->n_gaps.alloc(n)) != GP_OK || (rc = c->pair_last.alloc(g)) != GP_OK ||
@@ -1569,18 +1600,22 @@ int stage_c_prepare(gp_job* job)
         (rc = c->small.alloc((uint64_t)kSimtWaves * kSimtLanes * sizeof(SmallArena))) != GP_OK ||
         (rc = c->queue.alloc(8)) != GP_OK || (rc = c->pool.alloc(c->pool_cap)) != GP_OK ||
         (rc = c->pool_head.alloc(1)) != GP_OK || (rc = c->multi.alloc(c->multi_cap)) != GP_OK ||
-        (rc = c->slots.alloc(n_workers * kSlots)) != GP_OK ||
-        (rc = c->verts.alloc(n_workers * kVertCap)) != GP_OK ||
-        (rc = c->edges.alloc(n_workers * kEdgeCap)) != GP_OK ||
-        (rc = c->scratch.alloc(n_workers * kScratchWords)) != GP_OK ||
+        (rc = c->slots.alloc(n_big * kSlots)) != GP_OK || (rc = c->verts.alloc(n_big * kVertCap)) != GP_OK ||
+        (rc = c->edges.alloc(n_big * kEdgeCap)) != GP_OK || (rc = c->scratch.alloc(n_big * kScratchWords)) != GP_OK ||
+        (rc = c->m_slots.alloc(n_workers << kMedSlotBits)) != GP_OK || (rc = c->m_verts.alloc(n_workers * kMedVertCap)) != GP_OK ||
+        (rc = c->m_edges.alloc(n_workers * kMedEdgeCap)) != GP_OK ||
+        (rc = c->m_scratch.alloc(n_workers * kMedScratchWords)) != GP_OK || (rc = c->m_epoch.alloc(n_workers)) != GP_OK ||
+        (rc = c->defer2.alloc(g)) != GP_OK ||
         (rc = c->nw.alloc((uint64_t)kNwWorkers *
                           (3ull * (kNwMax + 1) * (kNwMax + 1) + 2 * (2 * kNwMax + 64) / 4 + 64))) != GP_OK ||
-        (rc = c->epoch.alloc(n_workers)) != GP_OK)
+        (rc = c->epoch.alloc(n_big)) != GP_OK)
         return rc;
     GP_HIP(hipMemcpy(c->gap_off.p, c->h_gap_off.data(), (n + 1) * sizeof(uint32_t),
                      hipMemcpyHostToDevice));
-    GP_HIP(hipMemset(c->slots.p, 0, n_workers * kSlots * sizeof(uint32_t)));
-    GP_HIP(hipMemset(c->epoch.p, 0, n_workers * sizeof(uint32_t)));
+    GP_HIP(hipMemset(c->slots.p, 0, n_big * kSlots * sizeof(uint32_t)));
+    GP_HIP(hipMemset(c->epoch.p, 0, n_big * sizeof(uint32_t)));
+    GP_HIP(hipMemset(c->m_slots.p, 0, (n_workers << kMedSlotBits) * sizeof(uint32_t)));
+    GP_HIP(hipMemset(c->m_epoch.p, 0, n_workers * sizeof(uint32_t)));
     return GP_OK;
 }
 
@@ -1631,6 +1666,12 @@ int stage_c_run(gp_job* job)
     a.table_bits = c->table_bits;
     a.work = c->work.p;
     a.defer = c->defer.p;
+    a.defer2 = c->defer2.p;
+    a.m_slots = c->m_slots.p;
+    a.m_verts = c->m_verts.p;
+    a.m_edges = c->m_edges.p;
+    a.m_scratch = c->m_scratch.p;
+    a.m_epoch = c->m_epoch.p;
     a.queue = c->queue.p;
     a.pool = c->pool.p;
     a.pool_head = c->pool_head.p;
@@ -1665,10 +1706,14 @@ int stage_c_run(gp_job* job)
         // queue heads back to 0, counts stay
         GP_HIP(hipMemsetAsync(c->queue.p + 1, 0, sizeof(uint32_t), s));
         GP_HIP(hipMemsetAsync(c->queue.p + 2, 0, 2 * sizeof(uint32_t), s));
-        GP_HIP(hipMemsetAsync(c->queue.p + 4, 0, 2 * sizeof(uint32_t), s));
+        GP_HIP(hipMemsetAsync(c->queue.p + 4, 0, 4 * sizeof(uint32_t), s));
         hipLaunchKernelGGL(sealer_connect_lanes, dim3(kSimtWaves), dim3(64), 0, s, a,
                            reinterpret_cast<SmallArena*>(c->small.p));
+        a.tier = 0;
         hipLaunchKernelGGL(sealer_connect, dim3(c->n_workers), dim3(64), 0, s, a);
+        a.tier = 1;
+        hipLaunchKernelGGL(sealer_connect, dim3(std::min<uint32_t>(c->n_workers, kBigWorkers)), dim3(64), 0, s, a);
+        a.tier = 0;
         hipLaunchKernelGGL(sealer_consensus, dim3(kNwWorkers), dim3(64), 0, s, a);
     }
     hipLaunchKernelGGL(apply_fills, dim3(job->n_contigs), dim3(kApplyThreads), 0, s, a);
