@@ -119,6 +119,7 @@ struct CState {
     DevBuf<uint32_t> epoch;        // per worker
     std::vector<uint32_t> h_gap_off;
     uint32_t gap_cap = 0, table_bits = 0, multi_cap = 0;
+    uint32_t n_big = 0;            // workers with full arenas (all of them where long contigs are polished, else kBigWorkers)
     uint32_t n_workers = 0;        // sealer_connect's grid: 1024 took 0.15 s per configs[2] step, 2048 0.10 s, 3072 (three waves per SIMD: what its registers allow) 0.08 s
     uint64_t pool_cap = 0;
 };
@@ -168,7 +169,7 @@ struct CArgs {
     uint32_t* m_scratch;
     uint32_t* m_epoch;
     uint32_t* defer2;    // gaps the medium arenas could not hold, count in queue[6]
-    uint32_t tier;       // sealer_connect: 0 medium arenas (what overflows goes to defer2), 1 full arenas over defer2
+    uint32_t tier;       // sealer_connect: 0 medium arenas (what overflows goes to defer2), 1 full arenas over defer2, 2 full arenas over defer (no medium pass)
     int32_t* nw;
     uint32_t* epoch;
     uint32_t* err;
@@ -949,7 +950,7 @@ __device__ bool connect_one(const CArgs& a, Search& S, uint32_t gi, uint32_t wid
         S.dfs_path = S.dfs_it = S.left = S.right = S.found = nullptr;
     } else {
         // ---- this worker's arena: a medium one in the first pass, a full one for what outgrew that
-        const bool med = a.tier == 0;
+        const bool med = a.tier == 0;  // (tiers 1 and 2: a full arena)
         const uint32_t sbits = med ? kMedSlotBits : kSlotBits, vcap = med ? kMedVertCap : kVertCap;
         const uint32_t ecap = med ? kMedEdgeCap : kEdgeCap;
         uint32_t* const epoch_of = (med ? a.m_epoch : a.epoch) + wid;
@@ -1100,9 +1101,9 @@ __global__ __launch_bounds__(64) void sealer_connect(CArgs a)
     __shared__ uint8_t r1[64], r2[64], tmp[kPathCap + 64];
     __shared__ uint32_t item;
     const uint32_t wid = blockIdx.x, lane = threadIdx.x;
-    const uint32_t* const list = a.tier == 0 ? a.defer : a.defer2;
-    uint32_t* const head = a.queue + (a.tier == 0 ? 5 : 7);
-    const uint32_t n_work = a.queue[a.tier == 0 ? 4 : 6];
+    const uint32_t* const list = a.tier == 1 ? a.defer2 : a.defer; // (tier 2: full arenas straight over phase 1's list)
+    uint32_t* const head = a.queue + (a.tier == 1 ? 7 : 5);
+    const uint32_t n_work = a.queue[a.tier == 1 ? 6 : 4];
     for (;;) {
         if (lane == 0)
             item = atomicAdd(head, 1u);
@@ -1589,7 +1590,18 @@ int stage_c_prepare(gp_job* job)
     // a worker per 4 kbp of contigs, 256 at least, kMaxWorkers from 12 Mbp on (3 GiB of medium arenas + 3.3 GiB of full ones)
     c->n_workers = (uint32_t)std::min<uint64_t>(
         kMaxWorkers, std::max<uint64_t>(256, env_u64("GP_SEALER_WORKERS", total_len / 4096)));
-    const uint64_t n_workers = c->n_workers, n_big = std::min<uint64_t>(n_workers, kBigWorkers);
+    // Full arenas for every worker where long contigs are polished: their near-saturated filters make
+    // searches that neither find a path nor hit the branch limit explore tens of thousands of
+    // vertices (160 000 such searches per step on SURVEY 8d's 100 Mbp of megabase contigs; with 256
+    // full arenas behind the medium ones Sealer took 6.4 s there instead of 2.0).  Read-length contigs
+    // get the two tiers: 6.3 GiB instead of 39.
+    uint64_t longest = 0;
+    for (uint32_t i = 0; i < n; i++)
+        longest = std::max<uint64_t>(longest, job->h_contig_off[i + 1] - job->h_contig_off[i]);
+    const uint64_t n_workers = c->n_workers;
+    const uint64_t n_big = longest >= env_u64("GP_SEALER_LONG", 200000) ? n_workers : std::min<uint64_t>(n_workers, kBigWorkers);
+    c->n_big = (uint32_t)n_big;
+    const uint64_t n_med = n_big < n_workers ? n_workers : 1; // (no medium pass when every worker has a full arena)
     int rc;
     if ((rc = c->gaps.alloc(g)) != GP_OK || (rc = c->gap_off.alloc((size_t)n + 1)) != GP_OK ||
         (rc = c->n_gaps.alloc(n)) != GP_OK || (rc = c->pair_last.alloc(g)) != GP_OK ||
@@ -1602,9 +1614,9 @@ int stage_c_prepare(gp_job* job)
         (rc = c->pool_head.alloc(1)) != GP_OK || (rc = c->multi.alloc(c->multi_cap)) != GP_OK ||
         (rc = c->slots.alloc(n_big * kSlots)) != GP_OK || (rc = c->verts.alloc(n_big * kVertCap)) != GP_OK ||
         (rc = c->edges.alloc(n_big * kEdgeCap)) != GP_OK || (rc = c->scratch.alloc(n_big * kScratchWords)) != GP_OK ||
-        (rc = c->m_slots.alloc(n_workers << kMedSlotBits)) != GP_OK || (rc = c->m_verts.alloc(n_workers * kMedVertCap)) != GP_OK ||
-        (rc = c->m_edges.alloc(n_workers * kMedEdgeCap)) != GP_OK ||
-        (rc = c->m_scratch.alloc(n_workers * kMedScratchWords)) != GP_OK || (rc = c->m_epoch.alloc(n_workers)) != GP_OK ||
+        (rc = c->m_slots.alloc(n_med << kMedSlotBits)) != GP_OK || (rc = c->m_verts.alloc(n_med * kMedVertCap)) != GP_OK ||
+        (rc = c->m_edges.alloc(n_med * kMedEdgeCap)) != GP_OK ||
+        (rc = c->m_scratch.alloc(n_med * kMedScratchWords)) != GP_OK || (rc = c->m_epoch.alloc(n_med)) != GP_OK ||
         (rc = c->defer2.alloc(g)) != GP_OK ||
         (rc = c->nw.alloc((uint64_t)kNwWorkers *
                           (3ull * (kNwMax + 1) * (kNwMax + 1) + 2 * (2 * kNwMax + 64) / 4 + 64))) != GP_OK ||
@@ -1614,8 +1626,8 @@ int stage_c_prepare(gp_job* job)
                      hipMemcpyHostToDevice));
     GP_HIP(hipMemset(c->slots.p, 0, n_big * kSlots * sizeof(uint32_t)));
     GP_HIP(hipMemset(c->epoch.p, 0, n_big * sizeof(uint32_t)));
-    GP_HIP(hipMemset(c->m_slots.p, 0, (n_workers << kMedSlotBits) * sizeof(uint32_t)));
-    GP_HIP(hipMemset(c->m_epoch.p, 0, n_workers * sizeof(uint32_t)));
+    GP_HIP(hipMemset(c->m_slots.p, 0, (n_med << kMedSlotBits) * sizeof(uint32_t)));
+    GP_HIP(hipMemset(c->m_epoch.p, 0, n_med * sizeof(uint32_t)));
     return GP_OK;
 }
 
@@ -1709,10 +1721,15 @@ int stage_c_run(gp_job* job)
         GP_HIP(hipMemsetAsync(c->queue.p + 4, 0, 4 * sizeof(uint32_t), s));
         hipLaunchKernelGGL(sealer_connect_lanes, dim3(kSimtWaves), dim3(64), 0, s, a,
                            reinterpret_cast<SmallArena*>(c->small.p));
-        a.tier = 0;
-        hipLaunchKernelGGL(sealer_connect, dim3(c->n_workers), dim3(64), 0, s, a);
-        a.tier = 1;
-        hipLaunchKernelGGL(sealer_connect, dim3(std::min<uint32_t>(c->n_workers, kBigWorkers)), dim3(64), 0, s, a);
+        if (c->n_big < c->n_workers) {
+            a.tier = 0;
+            hipLaunchKernelGGL(sealer_connect, dim3(c->n_workers), dim3(64), 0, s, a);
+            a.tier = 1;
+            hipLaunchKernelGGL(sealer_connect, dim3(c->n_big), dim3(64), 0, s, a);
+        } else {
+            a.tier = 2;
+            hipLaunchKernelGGL(sealer_connect, dim3(c->n_big), dim3(64), 0, s, a);
+        }
         a.tier = 0;
         hipLaunchKernelGGL(sealer_consensus, dim3(kNwWorkers), dim3(64), 0, s, a);
     }
