@@ -132,7 +132,7 @@ const char* gp_last_error(void);
 int gp_version(void);
 /* Device memory (bytes, all devices) this library holds right now: lets a caller size its jobs.
  * A job needs about n_batches * n_k * (cbf_bytes + bf_bytes) for the filters, 30 bytes per contig
- * base and 1 byte per read base, plus 13 GiB of Sealer search arenas per job with run_sealer. */
+ * base and 1 byte per read base, plus 3 to 6 GiB of Sealer search arenas per job with run_sealer (39 GiB where contigs of 200 kbp and more are polished). */
 uint64_t gp_device_bytes_in_use(void);
 /* Device memory the library keeps for re-use: blocks of destroyed jobs go to a pool, so that the
  * next job of a like shape costs no hipMalloc / hipFree (a stream of jobs: gp_pipeline_*).  The
