@@ -283,13 +283,17 @@ def test_cpp_host_program_over_the_c_abi(tmp_path):
         with core.Job.from_files(ctx, p, ti, ri, m, batches, 40.0) as job:
             job.polish()
             job.write_fasta(tmp_path / "py.fa")
-    for extra in ([], ["-j", "0"]):   # -j 0: every batch its own job, appended
+    # -j 0: every batch its own job, appended; -d 0,0 / 0,0,0: the several-devices path (a host thread
+    # and a context each, batches dealt by gp_partition_batches, part files merged back into input
+    # order) with every "device" being GPU 0
+    for extra in ([], ["-j", "0"], ["-d", "0,0"], ["-d", "0,0,0", "-j", "0"]):
         out = tmp_path / "cpp.fa"
         r = subprocess.run([str(exe), "-k", "32", "-k", "24", "-b", "2", *extra, str(fa), str(fq), str(paf), str(out)],
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
-        assert out.read_bytes() == (tmp_path / "py.fa").read_bytes()
+        assert out.read_bytes() == (tmp_path / "py.fa").read_bytes(), extra
         assert "Gaps closed = " in r.stderr and "No start/goal kmer: " in r.stderr
+        assert not list(tmp_path.glob("cpp.fa.part*"))
     r = subprocess.run([str(exe), str(fa), str(fq), str(tmp_path / "missing.paf"), str(tmp_path / "x.fa")],
                        capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "loading the mappings failed" in r.stderr
