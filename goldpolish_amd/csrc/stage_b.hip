@@ -229,6 +229,7 @@ struct Shared {
     uint32_t seg_failed;      // a segment's walk worked on something too close to its end (1, 2) or gave up (3)
     uint32_t seg_busy;        // consecutive decisions of a segment's walker that were not "clean"
     uint32_t seg_arrived;     // the segment's sweep reached its end
+    uint32_t seg_refused;     // make_edit refused a repeat insertion (and dropped nodes of the list)
 };
 
 enum { REQ_DONE = 0, REQ_SCAN, REQ_SITE, REQ_NEXT, REQ_BITSCAN, REQ_REFILL, REQ_SWEEP };
@@ -700,6 +701,8 @@ __device__ void make_edit(const Ctx& c, Shared& S, uint8_t draft, Best& b)
                 }
             }
         }
+        if (skipped)
+            S.seg_refused = 1; // (see the segment walk: a refused insertion sends the contig to the one-workgroup walk)
         if (!skipped) {
             make_insertion(c, S, S.tn, (int)S.ti, b.indel, b.indel_len);
             changelast(ht, S.fh, S.rh, draft, b.indel[0]);
@@ -1287,6 +1290,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
         S.seg_failed = 0;
         S.seg_busy = 0;
         S.seg_arrived = 0;
+        S.seg_refused = 0;
     }
     if (SEG && a.segs[seg_index].resume_from != 0xFFFFFFFFu) {
         // go on where descriptor resume_from stopped (its node list is this descriptor's, untouched)
@@ -1467,6 +1471,18 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                 // repair, then whole would cost it three times -- give the contig up at once
                 S.seg_busy = (clean && a.site_rec != nullptr) ? 0u : S.seg_busy + 1u;
                 if (seg_open && S.seg_busy > 3000u) {
+                    S.seg_failed = 3;
+                    S.req[cur] = REQ_DONE;
+                }
+                // A REFUSED INSERTION (make_edit: it would have repeated what was inserted just
+                // before) rearranges the node list -- drop_repeat_nodes moves later nodes over
+                // earlier ones and leaves dead ones behind, at which the reference's writer ENDS
+                // the contig (ntedit.cpp: the output loop stops at the first node of type -1) -- and
+                // may end the walk (findAcceptedKmer finding nothing).  What the output of such a
+                // contig is depends on the whole list, not on a segment's part of it (found by
+                // tools/fuzz_parity.py with segments of 2048 starts, k = 11 on an 8 KiB filter):
+                // the contig goes to the one-workgroup walk.  Any segment, the last one included.
+                if (S.seg_refused) {
                     S.seg_failed = 3;
                     S.req[cur] = REQ_DONE;
                 }
