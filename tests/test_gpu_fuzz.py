@@ -25,3 +25,23 @@ def test_random_jobs_match_the_oracle(oracle, monkeypatch):
         for seed in [1086, 20621, 20645, 300029] + list(range(7000, 7009)) + list(range(400000, 400012)):
             for mode in ("0", "1", "2"):   # grid-wide, cbf_local plain, cbf_local behind the census
                 assert fuzz_parity.run_case(core, ctx, oracle, seed, mode) is None, (seed, mode)
+
+
+def test_random_jobs_with_contigs_walked_as_segments(oracle, monkeypatch):
+    """the same with every contig of 4 kbp and more cut into segments of 2048 k-mer starts (and, for
+    some seeds, at the nominal positions whatever the records say): tiny k on tiny filters makes
+    ntEdit refuse insertions, drop nodes and end contigs early -- what the segment walk has to hand
+    back to the one-workgroup walk.  910080: a refused insertion's dead nodes end the contig's OUTPUT
+    (the reference's writer stops at the first one); segments that did not know gave 18 994 bases
+    for the oracle's 11 816."""
+    import fuzz_parity
+    from goldpolish_amd import core
+    for name in ("GP_STAGE_A_LOCAL", "GP_STAGE_A_CENSUS", "GP_STAGE_A_CENSUS_MIN"):
+        monkeypatch.setenv(name, "0")
+    monkeypatch.setenv("GP_WALK_SEG", "2048")
+    with core.Context(0) as ctx:
+        for seed in [910080, 20621, 20645, 300029] + list(range(910000, 910012)):
+            assert fuzz_parity.run_case(core, ctx, oracle, seed, "2") is None, seed
+        monkeypatch.setenv("GP_WALK_SEG_FORCE", "1")
+        for seed in [910080] + list(range(920000, 920008)):
+            assert fuzz_parity.run_case(core, ctx, oracle, seed, "2") is None, ("forced", seed)
