@@ -3225,9 +3225,13 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     std::vector<SegDesc> h_segs;
     std::vector<SegContig> h_segc;
     {
+        // only contigs of GP_WALK_SEG_MIN starts and more (default 131072; two segment lengths at least)
+        // are cut: a job of thousands of 30-100 kbp contigs fills the chip with one workgroup per
+        // contig, and cutting them would only add descriptors, copies and host round trips
+        const uint64_t seg_min = std::max<uint64_t>(2 * seg_len, env_u64("GP_WALK_SEG_MIN", 131072));
         bool any_long = false;
         for (uint32_t c = 0; seg_len && a.site_rec && c < job->n_contigs && !any_long; c++)
-            any_long = job->h_contig_off[c + 1] - job->h_contig_off[c] >= 2 * seg_len;
+            any_long = job->h_contig_off[c + 1] - job->h_contig_off[c] >= seg_min;
         if (any_long) {
             // the contigs' current lengths (edits of the earlier passes have changed them)
             std::vector<uint32_t> h_len(job->n_contigs);
@@ -3240,7 +3244,7 @@ int stage_b_pass(gp_job* job, uint32_t ki)
             std::vector<uint32_t> req_first(job->n_contigs + 1, 0);
             for (uint32_t c = 0; c < job->n_contigs; c++) {
                 req_first[c] = (uint32_t)h_req.size();
-                if (h_drop[c] || h_len[c] < 2 * seg_len)
+                if (h_drop[c] || h_len[c] < seg_min)
                     continue;
                 for (uint64_t p = seg_len; p + seg_len <= h_len[c]; p += seg_len)
                     h_req.push_back({ c, (uint32_t)p, half_window, 0 });

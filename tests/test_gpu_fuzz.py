@@ -39,6 +39,7 @@ def test_random_jobs_with_contigs_walked_as_segments(oracle, monkeypatch):
     for name in ("GP_STAGE_A_LOCAL", "GP_STAGE_A_CENSUS", "GP_STAGE_A_CENSUS_MIN"):
         monkeypatch.setenv(name, "0")
     monkeypatch.setenv("GP_WALK_SEG", "2048")
+    monkeypatch.setenv("GP_WALK_SEG_MIN", "0")
     with core.Context(0) as ctx:
         for seed in [910080, 20621, 20645, 300029] + list(range(910000, 910012)):
             assert fuzz_parity.run_case(core, ctx, oracle, seed, "2") is None, seed

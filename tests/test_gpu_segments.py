@@ -23,6 +23,7 @@ def test_segmented_walk_equals_the_whole_contig_walk(monkeypatch, oracle):
     from goldpolish_amd import core
     w = synth.make_workload_chunked([420_000, 160_000, 70_000, 9_000], 40, seed=23, chunk=1)
     p = core.default_params()
+    monkeypatch.setenv("GP_WALK_SEG_MIN", "0")     # cut everything of two segment lengths and more
     monkeypatch.setenv("GP_WALK_SEG", "0")
     want = run(core, p, w)
     assert want[1][2] > 1000     # real edits
