@@ -703,6 +703,16 @@ constexpr uint32_t kCStretch = kCSuper * kTile;
 constexpr uint32_t kCBuckets = 2048;      // most counter ranges per pair (a range is a power of two wide: 1280 of 8192 for 10 MiB)
 constexpr uint32_t kCRun = 64;            // records a stretch may leave in one bucket (26 expected at four hashes and 10 MiB)
 constexpr uint32_t kCMaxShift = 14;       // counters per range: 14 bits of a record, 64 KB of LDS in census_mark
+// Two geometries of the same record layout (the kernels are templates over them): RUN record slots per
+// (range, stretch), a ring of RING slots per range in LDS, groups of RING / 2 records per store.
+//   narrow: <= 2048 ranges, RUN 64, RING 8: 16-byte groups (half a 32-byte sector: PMC showed 0.59 TB
+//           written per configs[2] step for 0.26 TB of records);
+//   wide:   <= 1024 ranges (16384 counters each at 10 MiB), RUN 128, RING 16: 32-byte groups, whole
+//           sectors, by two neighbouring lanes; census_mark's table is 64 KB, two 1024-thread
+//           workgroups per CU.
+// Both need RUN x ranges = the same record slots per stretch.
+constexpr uint32_t kCBucketsWide = 1024, kCRunWide = 128, kCRingWide = 16;
+static_assert(kCBuckets * kCRun == kCBucketsWide * kCRunWide, "the record buffers are sized alike");
 
 struct CensusArgs {
     const uint32_t* wg_pair;       // [workgroups] pair (cohort-local) of a stretch
@@ -771,8 +781,10 @@ __device__ inline LaneOps lane_hashes(const uint64_t* seed_t, const uint8_t* cod
 // 43 ms like this; 63-68 ms with the records sorted by bucket in LDS first and every run written
 // in one go, which costs a second hashing pass and most of the occupancy; 67 ms with 2048-position
 // stretches, whose runs of six records reach memory as partial sectors.)
+template <uint32_t RUN, uint32_t RING>
 __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
 {
+    constexpr uint32_t G = RING / 2, Q = G / 4; // records per group; 16-byte pieces of a group, a lane each
     // Records do not go to memory one by one (a 4-byte store is an L2 request of its own and, with
     // hundreds of MB of half-written runs in flight, leaves L2 as a 32-byte sector of its own: PMC
     // showed 1.35 TB written per configs[2] step for 0.26 TB of records, and the kernel bound by
@@ -784,11 +796,11 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
     // (ring, counters and group bases are sized by the pair's ranges, not by the most a pair may
     // have: 1280 ranges at GoldPolish's 10 MiB make 51 KB with the rest, three workgroups per CU
     // where the static 2048-range arrays left room for two)
-    extern __shared__ uint32_t ring[]; // [ranges][8], then hist[ranges], then gbase[ranges] (bytes)
+    extern __shared__ uint32_t ring[]; // [ranges][RING], then hist[ranges], then gbase[ranges] (bytes)
     __shared__ uint8_t codes[kTile + kHalo];
     __shared__ uint64_t seed_t[kSeedTableWords];
-    uint32_t* const hist = ring + (size_t)c.n_buckets * 8;
-    uint8_t* const gbase = reinterpret_cast<uint8_t*>(hist + c.n_buckets); // groups of four of the run that are not the ring's any more (base / 4)
+    uint32_t* const hist = ring + (size_t)c.n_buckets * RING;
+    uint8_t* const gbase = reinterpret_cast<uint8_t*>(hist + c.n_buckets); // groups of the run that are not the ring's any more (base / G)
     const uint32_t pair = c.wg_pair[blockIdx.x];
     const uint32_t b = c.pair_batch[pair], ki = c.pair_ki[pair];
     const KConsts& kc = a.kc[ki];
@@ -833,41 +845,44 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
                 const uint32_t bucket = ix >> shift;
                 const uint32_t rank = atomicAdd(&hist[bucket], 1u);
                 const uint32_t r = (off << 16) | ((ix & lmask) << 2) | h;
-                if (rank >= kCRun)
+                if (rank >= RUN)
                     over = true;
-                else if (rank - 4u * gbase[bucket] < 8u)
-                    ring[bucket * 8u + (rank & 7u)] = r;
+                else if (rank - G * gbase[bucket] < RING)
+                    ring[bucket * RING + (rank & (RING - 1u))] = r;
                 else
-                    rec[((uint64_t)bucket * nst + stretch) * kCRun + rank] = r;
+                    rec[((uint64_t)bucket * nst + stretch) * RUN + rank] = r;
             }
         }
         __syncthreads();
-        // the groups of four this tile completed
-        for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock) {
-            const uint32_t cnt = min(hist[i], kCRun), g0 = gbase[i];
+        // the groups this tile completed: Q neighbouring lanes per range, 16 bytes of a group each
+        // (they are lanes of one wave: all of them have read gbase before the first of them writes it)
+        for (uint32_t idx = threadIdx.x; idx < c.n_buckets * Q; idx += kBlock) {
+            const uint32_t i = idx / Q, part = idx % Q;
+            const uint32_t cnt = min(hist[i], RUN), g0 = gbase[i];
             uint32_t ng, g_next;
-            if (cnt > 4u * g0 + 8u) { // more than the ring holds: its two groups are full, the rest is in memory
+            if (cnt > G * g0 + RING) { // more than the ring holds: its two groups are full, the rest is in memory
                 ng = 2;
-                g_next = (cnt + 3u) / 4u;
+                g_next = (cnt + G - 1u) / G;
             } else {
-                ng = cnt > 4u * g0 ? (cnt - 4u * g0) / 4u : 0u; // (after such a tile the window starts past the records)
+                ng = cnt > G * g0 ? (cnt - G * g0) / G : 0u; // (after such a tile the window starts past the records)
                 g_next = g0 + ng;
             }
-            uint4* const dst = reinterpret_cast<uint4*>(rec + ((uint64_t)i * nst + stretch) * kCRun);
-            const uint4* const src = reinterpret_cast<const uint4*>(ring + i * 8u);
+            uint4* const dst = reinterpret_cast<uint4*>(rec + ((uint64_t)i * nst + stretch) * RUN);
+            const uint4* const src = reinterpret_cast<const uint4*>(ring + i * RING);
             for (uint32_t g = g0; g < g0 + ng; g++)
-                dst[g] = src[g & 1u];
-            gbase[i] = (uint8_t)g_next;
+                dst[g * Q + part] = src[(g & 1u) * Q + part];
+            if (part == 0)
+                gbase[i] = (uint8_t)g_next;
         }
     }
     __syncthreads();
     uint8_t* const cnt = c.cnt + c.pair_cnt_off[pair];
     for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock) {
-        const uint32_t n = min(hist[i], kCRun);
+        const uint32_t n = min(hist[i], RUN);
         cnt[(uint64_t)i * nst + stretch] = (uint8_t)n;
-        // what is left in the ring: fewer than four records
-        for (uint32_t r = 4u * gbase[i]; r < n; r++)
-            rec[((uint64_t)i * nst + stretch) * kCRun + r] = ring[i * 8u + (r & 7u)];
+        // what is left in the ring: less than a group
+        for (uint32_t r = G * gbase[i]; r < n; r++)
+            rec[((uint64_t)i * nst + stretch) * RUN + r] = ring[i * RING + (r & (RING - 1u))];
     }
     if (over)
         c.overflow[pair] = 1u; // many copies of one k-mer within the stretch: this pair is replayed whole
@@ -886,41 +901,52 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
 // A wave takes a stretch's run at a time (256 bytes of record slots, as many lanes as it
 // holds); the runs' lengths are fetched once, the records once (kept in registers between the
 // two passes when the bucket has no more than kKeep runs per wave).
-constexpr int kMarkBlock = 512, kMarkWaves = kMarkBlock / 64; // eight waves share a range's table: 32 waves per CU at 10 MiB
-__global__ __launch_bounds__(kMarkBlock, 8) void census_mark(CensusArgs c)
+constexpr int kMarkBlock = 512;       // eight waves share a range's table: 32 waves per CU at 10 MiB (narrow ranges)
+constexpr int kMarkBlockWide = 1024;  // wide ranges: a 64 KB table, two workgroups per CU, sixteen waves each
+template <uint32_t RUN, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 8) void census_mark(CensusArgs c)
 {
-    extern __shared__ uint32_t first_t[]; // a word per counter of the range (32 KB at GoldPolish's 10 MiB), then the run lengths
+    constexpr int kMarkWaves = BLOCK / 64;
+    constexpr int PER = RUN / 64;         // records of a run per lane
+    extern __shared__ uint32_t first_t[]; // a word per counter of the range (32 KB at GoldPolish's 10 MiB; 64 KB for wide ranges), then the run lengths
     const uint32_t pair = blockIdx.x / c.n_buckets, bucket = blockIdx.x % c.n_buckets;
     const uint32_t bucket_w = 1u << c.bucket_shift;
     if (c.overflow[pair])
         return;
     const uint32_t nst = c.pair_nst[pair];
-    uint32_t* const rec = c.rec + c.pair_rec_off[pair] + (uint64_t)bucket * nst * kCRun;
+    uint32_t* const rec = c.rec + c.pair_rec_off[pair] + (uint64_t)bucket * nst * RUN;
     const uint8_t* cnt = c.cnt + c.pair_cnt_off[pair] + (uint64_t)bucket * nst;
     uint8_t* const s_cnt = reinterpret_cast<uint8_t*>(first_t + bucket_w);
-    for (uint32_t i = threadIdx.x; i < bucket_w; i += kMarkBlock)
+    for (uint32_t i = threadIdx.x; i < bucket_w; i += BLOCK)
         first_t[i] = 0xFFFFFFFFu;
-    for (uint32_t i = threadIdx.x; i < nst; i += kMarkBlock)
+    for (uint32_t i = threadIdx.x; i < nst; i += BLOCK)
         s_cnt[i] = cnt[i];
     __syncthreads();
     constexpr int kKeep = 128 / kMarkWaves; // 128 runs: a pair of a million positions
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t keep[kKeep];
+    uint32_t keep[kKeep][PER];
 #pragma unroll
     for (int q = 0; q < kKeep; q++) {
         const uint32_t st = wave + (uint32_t)kMarkWaves * (uint32_t)q;
-        keep[q] = (st < nst && lane < s_cnt[st]) ? rec[(uint64_t)st * kCRun + lane] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int e = 0; e < PER; e++)
+            keep[q][e] = (st < nst && lane + 64u * e < s_cnt[st]) ? rec[(uint64_t)st * RUN + lane + 64u * e] : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int q = 0; q < kKeep; q++)
-        if (keep[q] != 0xFFFFFFFFu)
-            atomicMin(&first_t[(keep[q] >> 2) & 0x3FFFu], (wave + (uint32_t)kMarkWaves * (uint32_t)q) * kCStretch + (keep[q] >> 16));
+#pragma unroll
+        for (int e = 0; e < PER; e++)
+            if (keep[q][e] != 0xFFFFFFFFu)
+                atomicMin(&first_t[(keep[q][e] >> 2) & 0x3FFFu],
+                          (wave + (uint32_t)kMarkWaves * (uint32_t)q) * kCStretch + (keep[q][e] >> 16));
 #pragma unroll 4
     for (uint32_t st = wave + (uint32_t)kMarkWaves * kKeep; st < nst; st += kMarkWaves)
-        if (lane < s_cnt[st]) {
-            const uint32_t r = rec[(uint64_t)st * kCRun + lane];
-            atomicMin(&first_t[(r >> 2) & 0x3FFFu], st * kCStretch + (r >> 16));
-        }
+#pragma unroll
+        for (int e = 0; e < PER; e++)
+            if (lane + 64u * e < s_cnt[st]) {
+                const uint32_t r = rec[(uint64_t)st * RUN + lane + 64u * e];
+                atomicMin(&first_t[(r >> 2) & 0x3FFFu], st * kCStretch + (r >> 16));
+            }
     __syncthreads();
     // The touches that are not their counter's first go back into the head of their own run, bit 31
     // set, packed (the records are in registers, the run is this wave's alone): a sector or two per
@@ -928,32 +954,40 @@ __global__ __launch_bounds__(kMarkBlock, 8) void census_mark(CensusArgs c)
     // (19 G bytes per configs[2] step that left L2 as 0.64 TB of partial sectors).  census_pack reads
     // a run up to the first record without the bit; a run whose touches are all marked gets a zero
     // behind them (what lies past a run's records is left over from an earlier cohort).
-    auto mark = [&](uint32_t r, bool valid, uint32_t st) { // every lane of the wave
-        const uint32_t t = st * kCStretch + (r >> 16);
-        const bool later = valid && first_t[(r >> 2) & 0x3FFFu] != t; // (a counter hit twice by one operation: both touches are its first)
-        const unsigned long long m = __ballot(later);
-        uint32_t* const run = rec + (uint64_t)st * kCRun;
-        if (later)
-            run[__popcll(m & ((1ull << lane) - 1ull))] = r | 0x80000000u;
-        const uint32_t n = (uint32_t)__popcll(m);
-        if (lane == 0 && n == s_cnt[st] && n < kCRun)
+    auto mark = [&](const uint32_t (&r)[PER], uint32_t st) { // every lane of the wave; r[e] == 0xFFFFFFFF: no record
+        uint32_t* const run = rec + (uint64_t)st * RUN;
+        uint32_t n = 0;
+#pragma unroll
+        for (int e = 0; e < PER; e++) {
+            const uint32_t t = st * kCStretch + ((r[e] >> 16) & (kCStretch - 1u));
+            const bool later = r[e] != 0xFFFFFFFFu && first_t[(r[e] >> 2) & 0x3FFFu] != t; // (a counter hit twice by one operation: both touches are its first)
+            const unsigned long long m = __ballot(later);
+            if (later)
+                run[n + __popcll(m & ((1ull << lane) - 1ull))] = r[e] | 0x80000000u;
+            n += (uint32_t)__popcll(m);
+        }
+        if (lane == 0 && n == s_cnt[st] && n < RUN)
             run[n] = 0;
     };
 #pragma unroll
     for (int q = 0; q < kKeep; q++) {
         const uint32_t st = wave + (uint32_t)kMarkWaves * (uint32_t)q;
         if (st < nst)
-            mark(keep[q], keep[q] != 0xFFFFFFFFu, st);
+            mark(keep[q], st);
     }
     for (uint32_t st = wave + (uint32_t)kMarkWaves * kKeep; st < nst; st += kMarkWaves) {
-        const bool valid = lane < s_cnt[st];
-        mark(valid ? rec[(uint64_t)st * kCRun + lane] : 0u, valid, st);
+        uint32_t r[PER];
+#pragma unroll
+        for (int e = 0; e < PER; e++)
+            r[e] = lane + 64u * e < s_cnt[st] ? rec[(uint64_t)st * RUN + lane + 64u * e] : 0xFFFFFFFFu;
+        mark(r, st);
     }
 }
 
 // ---- census 3: operations with every touch marked -> one bit each.  A workgroup per stretch: a lane
 // per range reads the marked records at the head of the stretch's run there and counts them per
 // position in LDS (a byte each).
+template <uint32_t RUN>
 __global__ __launch_bounds__(256) void census_pack(AArgs a, CensusArgs c)
 {
     __shared__ uint32_t s_touch[kCStretch / 4];
@@ -973,8 +1007,8 @@ __global__ __launch_bounds__(256) void census_pack(AArgs a, CensusArgs c)
     __syncthreads();
     const uint32_t* const rec = c.rec + c.pair_rec_off[pair];
     for (uint32_t bu = threadIdx.x; bu < c.n_buckets; bu += 256) {
-        const uint4* run = reinterpret_cast<const uint4*>(rec + ((uint64_t)bu * nst + stretch) * kCRun);
-        for (uint32_t q = 0; q < kCRun / 4; q++) {
+        const uint4* run = reinterpret_cast<const uint4*>(rec + ((uint64_t)bu * nst + stretch) * RUN);
+        for (uint32_t q = 0; q < RUN / 4; q++) {
             const uint4 v = run[q];
             const uint32_t w[4] = { v.x, v.y, v.z, v.w };
             bool more = true;
@@ -1879,8 +1913,9 @@ int stage_a_run(gp_job* job)
         a.pair_bit_off = nullptr;
         a.cand = nullptr;
         // counter ranges: a power of two wide, at most kCBuckets of them
+        const bool wide = env_u64("GP_STAGE_A_CENSUS_WIDE", 1) != 0; // 32-byte groups of records (see kCBucketsWide)
         uint32_t bucket_shift = 2;
-        while (((p.cbf_bytes + (1ull << bucket_shift) - 1) >> bucket_shift) > kCBuckets)
+        while (((p.cbf_bytes + (1ull << bucket_shift) - 1) >> bucket_shift) > (wide ? kCBucketsWide : kCBuckets))
             bucket_shift++;
         const uint32_t n_buckets = (uint32_t)((p.cbf_bytes + (1ull << bucket_shift) - 1) >> bucket_shift);
         if (env_u64("GP_STAGE_A_CENSUS", 1) && p.hash_num <= 4 && bucket_shift <= kCMaxShift) {
@@ -1915,7 +1950,7 @@ int stage_a_run(gp_job* job)
                 if (pos < min_pos || pos >= (1ull << 32) || pos * p.hash_num > 2 * p.cbf_bytes)
                     continue;
                 const uint32_t nst = (uint32_t)((pos + kCStretch - 1) / kCStretch);
-                const uint64_t recs = (uint64_t)n_buckets * nst * kCRun; // a run of slots per bucket and stretch
+                const uint64_t recs = (uint64_t)n_buckets * nst * (wide ? kCRunWide : kCRun); // a run of slots per bucket and stretch
                 if (recs * p.n_k > rec_budget)
                     continue; // a batch that would not fit a cohort by itself
                 if (cur_rec + recs * p.n_k > rec_budget)
@@ -1961,7 +1996,11 @@ int stage_a_run(gp_job* job)
                 // census_scatter: a ring of eight record slots per range in LDS (40 KB at 1280 ranges:
                 // two workgroups per CU, which is also what it likes best -- with eight per CU and
                 // records stored one by one it had 670 MB of half-written runs in flight)
-                const size_t scatter_lds = (size_t)n_buckets * (8 + 1) * sizeof(uint32_t) + ((size_t)n_buckets + 3) / 4 * 4;
+                const size_t scatter_lds =
+                    (size_t)n_buckets * ((wide ? kCRingWide : 8u) + 1) * sizeof(uint32_t) + ((size_t)n_buckets + 3) / 4 * 4;
+                if (wide) // a 64 KB table and the run lengths: more than a workgroup gets without asking (per device)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&census_mark<kCRunWide, kMarkBlockWide>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
                 hipStream_t sm = n_sets > 1 ? job->a_stream2 : s; // mark and pack
                 for (size_t ci = 0; ci < cohorts.size(); ci++) {
                     Cohort& co = cohorts[ci];
@@ -2008,7 +2047,10 @@ int stage_a_run(gp_job* job)
                     c.cand = job->d_cand.p;
                     c.bucket_shift = bucket_shift;
                     c.n_buckets = n_buckets;
-                    hipLaunchKernelGGL(census_scatter, dim3((unsigned)nw), dim3(kBlock), scatter_lds, s, a, c);
+                    if (wide)
+                        hipLaunchKernelGGL((census_scatter<kCRunWide, kCRingWide>), dim3((unsigned)nw), dim3(kBlock), scatter_lds, s, a, c);
+                    else
+                        hipLaunchKernelGGL((census_scatter<kCRun, 8u>), dim3((unsigned)nw), dim3(kBlock), scatter_lds, s, a, c);
                     if (n_sets > 1) {
                         GP_HIP(hipEventRecord(ev_scattered, s));
                         GP_HIP(hipStreamWaitEvent(sm, ev_scattered, 0));
@@ -2018,9 +2060,16 @@ int stage_a_run(gp_job* job)
                         for (uint32_t x : co.pair_nst)
                             max_nst = std::max(max_nst, x);
                         const size_t lds = ((size_t)sizeof(uint32_t) << bucket_shift) + (max_nst + 3) / 4 * 4;
-                        hipLaunchKernelGGL(census_mark, dim3((unsigned)(np * n_buckets)), dim3(kMarkBlock), lds, sm, c);
+                        if (wide)
+                            hipLaunchKernelGGL((census_mark<kCRunWide, kMarkBlockWide>), dim3((unsigned)(np * n_buckets)),
+                                               dim3(kMarkBlockWide), lds, sm, c);
+                        else
+                            hipLaunchKernelGGL((census_mark<kCRun, kMarkBlock>), dim3((unsigned)(np * n_buckets)), dim3(kMarkBlock), lds, sm, c);
                     }
-                    hipLaunchKernelGGL(census_pack, dim3((unsigned)nw), dim3(256), 0, sm, a, c);
+                    if (wide)
+                        hipLaunchKernelGGL((census_pack<kCRunWide>), dim3((unsigned)nw), dim3(256), 0, sm, a, c);
+                    else
+                        hipLaunchKernelGGL((census_pack<kCRun>), dim3((unsigned)nw), dim3(256), 0, sm, a, c);
                     GP_HIP(hipGetLastError());
                     if (n_sets > 1)
                         GP_HIP(hipEventRecord(ev_marked, sm));

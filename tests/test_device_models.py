@@ -7,8 +7,8 @@ agree on random inputs -- the argument the kernel's comment makes, executed.
    (tests/golden/nthash_kat.json, made with /root/reference's nthash.hpp).
 2. `gather_plan` / `advance` (stage_b.hip): the walker's window and head a node at a time, against
    the char-by-char get_char / increment loop (ntedit.cpp's node list semantics).
-3. `census_scatter`'s ring (stage_a.hip): records staged in eight LDS slots per range and written in
-   groups of four, against storing every record at its slot.
+3. `census_scatter`'s ring (stage_a.hip): records staged in eight (sixteen) LDS slots per range and
+   written in groups of four (eight), against storing every record at its slot.
 4. `census_mark` / `census_pack`: marked records packed into the head of their run and read back up
    to the first record without the mark, against a flag per touch."""
 import json
@@ -187,59 +187,64 @@ def test_walker_window_and_head_a_node_at_a_time():
 
 # ---------------------------------------------------------------------------------- scatter ring
 K_RUN = 64
+GEOMETRIES = [(64, 8), (128, 16)]       # (RUN, RING) of census_scatter: narrow and wide ranges
 
 
-def scatter_with_ring(tiles):
-    """tiles: records a range gets in each tile of a stretch.  Returns the run as memory holds it."""
-    mem = [None] * K_RUN
-    ring = [None] * 8
+def scatter_with_ring(tiles, run=64, ring_n=8):
+    """tiles: records a range gets in each tile of a stretch.  Returns the run as memory holds it.
+    Groups of ring_n / 2 records leave the ring together (16 or 32 bytes)."""
+    G = ring_n // 2
+    mem = [None] * run
+    ring = [None] * ring_n
     hist, gbase = 0, 0
     for recs in tiles:
         for r in recs:
             rank = hist
             hist += 1
-            if rank >= K_RUN:
+            if rank >= run:
                 continue                                 # the pair falls back (overflow)
-            if 0 <= rank - 4 * gbase < 8:
-                ring[rank & 7] = r
+            if 0 <= rank - G * gbase < ring_n:
+                ring[rank & (ring_n - 1)] = r
             else:
                 assert mem[rank] is None
                 mem[rank] = r
-        cnt = min(hist, K_RUN)
-        if cnt > 4 * gbase + 8:
-            ng, g_next = 2, (cnt + 3) // 4
+        cnt = min(hist, run)
+        if cnt > G * gbase + ring_n:
+            ng, g_next = 2, (cnt + G - 1) // G
         else:
-            ng = (cnt - 4 * gbase) // 4 if cnt > 4 * gbase else 0
+            ng = (cnt - G * gbase) // G if cnt > G * gbase else 0
             g_next = gbase + ng
         for g in range(gbase, gbase + ng):
-            for i in range(4):
-                assert mem[4 * g + i] is None            # a group is written one way only
-                mem[4 * g + i] = ring[4 * (g & 1) + i]
+            for i in range(G):
+                assert mem[G * g + i] is None            # a group is written one way only
+                mem[G * g + i] = ring[G * (g & 1) + i]
         gbase = g_next
-    n = min(hist, K_RUN)
-    for r in range(4 * gbase, n):
+    n = min(hist, run)
+    for r in range(G * gbase, n):
         assert mem[r] is None
-        mem[r] = ring[r & 7]
+        mem[r] = ring[r & (ring_n - 1)]
     return mem[:n]
 
 
 def test_scatter_ring_leaves_every_record_at_its_slot():
     rng = np.random.default_rng(11)
-    for _ in range(4000):
-        lam = float(rng.choice([0.5, 3.2, 6.0, 12.0]))
-        tiles, nxt = [], 0
-        for _t in range(8):
-            n = int(rng.poisson(lam))
-            tiles.append(list(range(nxt, nxt + n)))
-            nxt += n
-        want = list(range(min(nxt, K_RUN)))
-        assert scatter_with_ring(tiles) == want
+    for run, ring_n in GEOMETRIES:
+        for _ in range(4000):
+            lam = float(rng.choice([0.5, 3.2, 6.4, 12.0, 20.0]))
+            tiles, nxt = [], 0
+            for _t in range(8):
+                n = int(rng.poisson(lam))
+                tiles.append(list(range(nxt, nxt + n)))
+                nxt += n
+            want = list(range(min(nxt, run)))
+            assert scatter_with_ring(tiles, run, ring_n) == want
 
 
 # ---------------------------------------------------------------------------------- mark and pack
 def test_marked_records_packed_into_the_run_head():
     rng = np.random.default_rng(13)
-    for _ in range(3000):
+    for it in range(3000):
+        K_RUN = GEOMETRIES[it & 1][0]
         cnt = int(rng.integers(0, K_RUN + 1))
         stale = [int(x) for x in rng.integers(0, 1 << 32, size=K_RUN)]   # an earlier cohort's leftovers
         recs = [int(x) for x in rng.integers(0, 1 << 29, size=cnt)]      # bit 31 clear: this cohort's records

@@ -37,6 +37,8 @@ for name in ("config3", "config2", "probe"):
                 if r["Counter_Name"] != counter:
                     continue
                 k = r["Kernel_Name"].split("(")[0]
+                if k.startswith("void gp::census_"):      # templates over the record geometry: one name per kernel
+                    k = k[len("void "):].split("<")[0]
                 agg[k][0] += 1
                 agg[k][1] += float(r["Counter_Value"])
             for k, (n, v) in agg.items():
