@@ -734,46 +734,6 @@ struct CensusArgs {
     uint32_t n_buckets;            // ranges per pair
 };
 
-// hashes of the lane's kPerThread consecutive positions of a staged tile (as cbf_first_pass does it)
-struct LaneOps {
-    uint64_t base[kPerThread];
-    uint32_t valid; // bit j: position j of the lane holds a k-mer
-};
-
-__device__ inline LaneOps lane_hashes(const uint64_t* seed_t, const uint8_t* codes, int t0, const KConsts& kc, uint64_t pos0,
-                                      uint64_t tile_end, uint64_t n_pos)
-{
-    LaneOps o;
-    o.valid = 0;
-    const uint32_t k = kc.k;
-    if (pos0 >= tile_end)
-        return o;
-    uint64_t fh = 0, rh = 0;
-    int last_bad = -1;
-    kmer_hash_from_table(seed_t, codes + t0, k, fh, rh, last_bad);
-#pragma unroll
-    for (int j = 0; j < kPerThread; j++) {
-        const uint64_t pos = pos0 + j;
-        if (pos >= tile_end)
-            break;
-        if (j > 0) {
-            uint32_t out = codes[t0 + j - 1], in = codes[t0 + j + k - 1];
-            uint64_t s_in = in < 4 ? seed_of_code(in) : 0ULL;
-            uint64_t s_outk = out < 4 ? kc.out_fwd[out] : 0ULL;
-            uint64_t r_ink = in < 4 ? kc.in_rev[in] : 0ULL;
-            uint64_t r_out = out < 4 ? seed_of_code(out ^ 2) : 0ULL;
-            fh = srol1(fh) ^ s_in ^ s_outk;
-            rh = sror1(rh ^ r_ink ^ r_out);
-            if (in >= 4)
-                last_bad = j + (int)k - 1;
-        }
-        o.base[j] = fh + rh;
-        if (last_bad < j && pos + k <= n_pos)
-            o.valid |= 1u << j;
-    }
-    return o;
-}
-
 // ---- census 1: every counter touch of an 8192-position stretch into the bucket of its counter
 // range.  A stretch has a run of kCRun record slots of its own in every bucket (the stretch and
 // the bucket are in the address: 4-byte records, no shared cursor, one hashing pass).  Ranges are
@@ -781,26 +741,38 @@ __device__ inline LaneOps lane_hashes(const uint64_t* seed_t, const uint8_t* cod
 // 43 ms like this; 63-68 ms with the records sorted by bucket in LDS first and every run written
 // in one go, which costs a second hashing pass and most of the occupancy; 67 ms with 2048-position
 // stretches, whose runs of six records reach memory as partial sectors.)
-template <uint32_t RUN, uint32_t RING>
+template <uint32_t RUN, uint32_t RING, int ROUNDS>
 __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
 {
+    // A lane hashes ROUNDS x kPerThread consecutive positions of a staged tile: the k-step start of
+    // its run of positions (2k table look-ups) once, a roll per position after that; the ring is
+    // emptied after every round (1024 positions, whichever they are: a record carries its position).
+    // Device clocks per phase (1000 x 25 kbp, cycles per workgroup = per stretch): staging 12 k
+    // (45 k before the words came a tile ahead), starts 32 k / 13 k / 7 k at 1 / 2 / 4 rounds, hashing +
+    // slotting 110-120 k -- about 65 instructions per touch, which is what four SIMDs issue in the time:
+    // the kernel is bound by instruction issue, not by LDS or memory -- and 27 k for the flushes.
+    // Four rounds make the workgroup 15 % shorter and the launch no faster (57.9 against 60.0 ms: fewer
+    // workgroups are resident with the larger staged tile), so one round is the default.
+    constexpr int PER = kPerThread, SPAN = PER * ROUNDS, TILE = kBlock * SPAN;
+    static_assert(kCStretch % TILE == 0, "whole tiles per stretch");
     constexpr uint32_t G = RING / 2, Q = G / 4; // records per group; 16-byte pieces of a group, a lane each
     // Records do not go to memory one by one (a 4-byte store is an L2 request of its own and, with
     // hundreds of MB of half-written runs in flight, leaves L2 as a 32-byte sector of its own: PMC
     // showed 1.35 TB written per configs[2] step for 0.26 TB of records, and the kernel bound by
-    // that).  Every range has a ring of eight record slots in LDS; after each tile the complete
-    // groups of four records are written as 16 bytes.  The window of a range is [base, base + 8)
-    // record slots of its run, base a multiple of four: a record whose slot lies in it goes to the
-    // ring, any other (a tile that brings a range more than the ring holds) straight to memory, so
-    // a group of four is always written by one of the two ways only.
+    // that).  Every range has a ring of RING record slots in LDS; after each round the complete
+    // groups of G records are written as 16 bytes per lane.  The window of a range is
+    // [base, base + RING) record slots of its run, base a multiple of G: a record whose slot lies in
+    // it goes to the ring, any other (a round that brings a range more than the ring holds)
+    // straight to memory, so a group is always written by one of the two ways only.
     // (ring, counters and group bases are sized by the pair's ranges, not by the most a pair may
-    // have: 1280 ranges at GoldPolish's 10 MiB make 51 KB with the rest, three workgroups per CU
-    // where the static 2048-range arrays left room for two)
-    extern __shared__ uint32_t ring[]; // [ranges][RING], then hist[ranges], then gbase[ranges] (bytes)
-    __shared__ uint8_t codes[kTile + kHalo];
+    // have: three workgroups per CU where the static 2048-range arrays left room for two)
+    extern __shared__ uint32_t ring[]; // [ranges][RING], then hist[ranges]
+    __shared__ uint8_t codes[TILE + kHalo];
     __shared__ uint64_t seed_t[kSeedTableWords];
+    // per range, one word: records so far (low half; at most 4 x 8192) and, in the high half, the groups
+    // of the run that are not the ring's any more (base / G) -- the atomic that hands out a record's
+    // rank brings the window along (a look-up less per touch)
     uint32_t* const hist = ring + (size_t)c.n_buckets * RING;
-    uint8_t* const gbase = reinterpret_cast<uint8_t*>(hist + c.n_buckets); // groups of the run that are not the ring's any more (base / G)
     const uint32_t pair = c.wg_pair[blockIdx.x];
     const uint32_t b = c.pair_batch[pair], ki = c.pair_ki[pair];
     const KConsts& kc = a.kc[ki];
@@ -810,78 +782,134 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
     const uint64_t stretch_end = min(b_end, pos0 + (uint64_t)kCStretch);
     const uint32_t nst = c.pair_nst[pair], stretch = (uint32_t)((pos0 - b_start) / kCStretch);
     uint32_t* const rec = c.rec + c.pair_rec_off[pair];
-    const int t0 = threadIdx.x * kPerThread;
+    const int t0 = threadIdx.x * SPAN;
     const uint32_t shift = c.bucket_shift, lmask = (1u << shift) - 1u;
     uint32_t n_positions = 0, n_ops = 0;
     bool over = false;
-    for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock) {
+    for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock)
         hist[i] = 0;
-        gbase[i] = 0;
-    }
     fill_seed_table(seed_t);
-    for (int st = 0; st < kCSuper; st++) {
-        const uint64_t tile0 = pos0 + (uint64_t)st * kTile;
+    // A tile's bases come as aligned 32-bit words, all of a lane's in flight together, a tile ahead.
+    constexpr int NW = (TILE + kHalo) / 4 + 1, WPT = (NW + kBlock - 1) / kBlock;
+    uint32_t pre[WPT];
+    auto fetch = [&](uint64_t tile0) {
+        const uint64_t a0 = tile0 & ~3ull;
+#pragma unroll
+        for (int q = 0; q < WPT; q++) {
+            const int w = (int)threadIdx.x + q * kBlock;
+            const uint64_t p = a0 + 4ull * (uint64_t)w;
+            uint32_t v = 0x0A0A0A0Au; // '\n' past the end of the reads
+            if (w < NW) {
+                if (p + 4 <= a.n_pos) {
+                    v = *reinterpret_cast<const uint32_t*>(a.reads + p);
+                } else {
+                    for (int bb = 0; bb < 4; bb++)
+                        if (p + bb < a.n_pos)
+                            v = (v & ~(0xFFu << (8 * bb))) | ((uint32_t)a.reads[p + bb] << (8 * bb));
+                }
+            }
+            pre[q] = v;
+        }
+    };
+    if (pos0 < stretch_end)
+        fetch(pos0);
+    for (int st = 0; st < (int)(kCStretch / TILE); st++) {
+        const uint64_t tile0 = pos0 + (uint64_t)st * TILE;
         if (tile0 >= stretch_end)
             break; // uniform
-        const uint64_t tile_end = min(stretch_end, tile0 + (uint64_t)kTile);
+        const uint64_t tile_end = min(stretch_end, tile0 + (uint64_t)TILE);
         __syncthreads(); // codes and ring free (and the counters cleared before the first use)
-        for (int i = threadIdx.x; i < kTile + kHalo; i += kBlock) {
-            const uint64_t p = tile0 + i;
-            codes[i] = base_code(p < a.n_pos ? a.reads[p] : (uint8_t)'\n');
+        {
+            const int sh = (int)(tile0 & 3ull);
+#pragma unroll
+            for (int q = 0; q < WPT; q++) {
+                const int i0 = 4 * ((int)threadIdx.x + q * kBlock) - sh;
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++)
+                    if (i0 + bb >= 0 && i0 + bb < TILE + kHalo)
+                        codes[i0 + bb] = base_code((uint8_t)(pre[q] >> (8 * bb)));
+            }
         }
+        if (tile0 + (uint64_t)TILE < stretch_end)
+            fetch(tile0 + (uint64_t)TILE); // the next tile's bases are on their way while this one is hashed
         __syncthreads();
-        const LaneOps o = lane_hashes(seed_t, codes, t0, kc, tile0 + t0, tile_end, a.n_pos);
+        const uint64_t lane_pos0 = tile0 + t0;
+        const bool lane_on = lane_pos0 < tile_end;
+        uint64_t fh = 0, rh = 0;
+        int last_bad = -1;
+        if (lane_on)
+            kmer_hash_from_table(seed_t, codes + t0, k, fh, rh, last_bad);
         // cbf_local only visits the candidates of a census pair: the counters of positions
         // streamed and of operations (valid k-mers) are kept here
-        n_positions += tile0 + t0 < tile_end ? (uint32_t)min((uint64_t)kPerThread, tile_end - (tile0 + t0)) : 0u;
-        n_ops += (uint32_t)__popc(o.valid);
+        n_positions += lane_on ? (uint32_t)min((uint64_t)SPAN, tile_end - lane_pos0) : 0u;
+        for (int rd = 0; rd < ROUNDS; rd++) {
+            if (rd > 0)
+                __syncthreads(); // the round before has been flushed
 #pragma unroll
-        for (int j = 0; j < kPerThread; j++) {
-            if (!((o.valid >> j) & 1u))
-                continue;
-            const uint32_t off = (uint32_t)(st * kTile + t0 + j); // position in the stretch
-            for (uint32_t h = 0; h < a.hash_num; h++) {
-                const uint32_t ix = (uint32_t)fastmod(h ? ext_hash(o.base[j], k, h) : o.base[j], a.cbf_mod);
-                const uint32_t bucket = ix >> shift;
-                const uint32_t rank = atomicAdd(&hist[bucket], 1u);
-                const uint32_t r = (off << 16) | ((ix & lmask) << 2) | h;
-                if (rank >= RUN)
-                    over = true;
-                else if (rank - G * gbase[bucket] < RING)
-                    ring[bucket * RING + (rank & (RING - 1u))] = r;
-                else
-                    rec[((uint64_t)bucket * nst + stretch) * RUN + rank] = r;
+            for (int j = 0; j < PER; j++) {
+                const int jj = rd * PER + j;
+                const uint64_t pos = lane_pos0 + jj;
+                if (!lane_on || pos >= tile_end)
+                    break;
+                if (jj > 0) {
+                    const uint32_t out = codes[t0 + jj - 1], in = codes[t0 + jj + k - 1];
+                    const uint64_t s_in = in < 4 ? seed_of_code(in) : 0ULL;
+                    const uint64_t s_outk = out < 4 ? kc.out_fwd[out] : 0ULL;
+                    const uint64_t r_ink = in < 4 ? kc.in_rev[in] : 0ULL;
+                    const uint64_t r_out = out < 4 ? seed_of_code(out ^ 2) : 0ULL;
+                    fh = srol1(fh) ^ s_in ^ s_outk;
+                    rh = sror1(rh ^ r_ink ^ r_out);
+                    if (in >= 4)
+                        last_bad = jj + (int)k - 1;
+                }
+                if (!(last_bad < jj && pos + k <= a.n_pos))
+                    continue;
+                n_ops++;
+                const uint64_t base = fh + rh;
+                const uint32_t off = (uint32_t)(st * TILE + t0 + jj); // position in the stretch
+                for (uint32_t h = 0; h < a.hash_num; h++) {
+                    const uint32_t ix = (uint32_t)fastmod(h ? ext_hash(base, k, h) : base, a.cbf_mod);
+                    const uint32_t bucket = ix >> shift;
+                    const uint32_t word = atomicAdd(&hist[bucket], 1u), rank = word & 0xFFFFu;
+                    const uint32_t r = (off << 16) | ((ix & lmask) << 2) | h;
+                    if (rank >= RUN)
+                        over = true;
+                    else if (rank - G * (word >> 16) < RING)
+                        ring[bucket * RING + (rank & (RING - 1u))] = r;
+                    else
+                        rec[((uint64_t)bucket * nst + stretch) * RUN + rank] = r;
+                }
             }
-        }
-        __syncthreads();
-        // the groups this tile completed: Q neighbouring lanes per range, 16 bytes of a group each
-        // (they are lanes of one wave: all of them have read gbase before the first of them writes it)
-        for (uint32_t idx = threadIdx.x; idx < c.n_buckets * Q; idx += kBlock) {
-            const uint32_t i = idx / Q, part = idx % Q;
-            const uint32_t cnt = min(hist[i], RUN), g0 = gbase[i];
-            uint32_t ng, g_next;
-            if (cnt > G * g0 + RING) { // more than the ring holds: its two groups are full, the rest is in memory
-                ng = 2;
-                g_next = (cnt + G - 1u) / G;
-            } else {
-                ng = cnt > G * g0 ? (cnt - G * g0) / G : 0u; // (after such a tile the window starts past the records)
-                g_next = g0 + ng;
+            __syncthreads();
+            // the groups this round completed: Q neighbouring lanes per range, 16 bytes of a group each
+            // (they are lanes of one wave: all of them have read the range's word before the first of them writes it)
+            for (uint32_t idx = threadIdx.x; idx < c.n_buckets * Q; idx += kBlock) {
+                const uint32_t i = idx / Q, part = idx % Q;
+                const uint32_t word = hist[i], cnt = min(word & 0xFFFFu, RUN), g0 = word >> 16;
+                uint32_t ng, g_next;
+                if (cnt > G * g0 + RING) { // more than the ring holds: its two groups are full, the rest is in memory
+                    ng = 2;
+                    g_next = (cnt + G - 1u) / G;
+                } else {
+                    ng = cnt > G * g0 ? (cnt - G * g0) / G : 0u; // (after such a round the window starts past the records)
+                    g_next = g0 + ng;
+                }
+                uint4* const dst = reinterpret_cast<uint4*>(rec + ((uint64_t)i * nst + stretch) * RUN);
+                const uint4* const src = reinterpret_cast<const uint4*>(ring + i * RING);
+                for (uint32_t g = g0; g < g0 + ng; g++)
+                    dst[g * Q + part] = src[(g & 1u) * Q + part];
+                if (part == 0)
+                    hist[i] = (word & 0xFFFFu) | (g_next << 16);
             }
-            uint4* const dst = reinterpret_cast<uint4*>(rec + ((uint64_t)i * nst + stretch) * RUN);
-            const uint4* const src = reinterpret_cast<const uint4*>(ring + i * RING);
-            for (uint32_t g = g0; g < g0 + ng; g++)
-                dst[g * Q + part] = src[(g & 1u) * Q + part];
-            if (part == 0)
-                gbase[i] = (uint8_t)g_next;
         }
     }
     __syncthreads();
     uint8_t* const cnt = c.cnt + c.pair_cnt_off[pair];
     for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock) {
-        const uint32_t n = min(hist[i], RUN);
+        const uint32_t n = min(hist[i] & 0xFFFFu, RUN);
         cnt[(uint64_t)i * nst + stretch] = (uint8_t)n;
         // what is left in the ring: less than a group
-        for (uint32_t r = G * gbase[i]; r < n; r++)
+        for (uint32_t r = G * (hist[i] >> 16); r < n; r++)
             rec[((uint64_t)i * nst + stretch) * RUN + r] = ring[i * RING + (r & (RING - 1u))];
     }
     if (over)
@@ -917,20 +945,30 @@ __global__ __launch_bounds__(BLOCK, 8) void census_mark(CensusArgs c)
     uint32_t* const rec = c.rec + c.pair_rec_off[pair] + (uint64_t)bucket * nst * RUN;
     const uint8_t* cnt = c.cnt + c.pair_cnt_off[pair] + (uint64_t)bucket * nst;
     uint8_t* const s_cnt = reinterpret_cast<uint8_t*>(first_t + bucket_w);
-    for (uint32_t i = threadIdx.x; i < bucket_w; i += BLOCK)
-        first_t[i] = 0xFFFFFFFFu;
-    for (uint32_t i = threadIdx.x; i < nst; i += BLOCK)
-        s_cnt[i] = cnt[i];
-    __syncthreads();
     constexpr int kKeep = 128 / kMarkWaves; // 128 runs: a pair of a million positions
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t keep[kKeep][PER];
+    // The first 64 slots of a run are fetched beside the run lengths, not behind them (a run of
+    // 51 records on average spans those four lines anyway); what a length rules out is dropped below.
 #pragma unroll
     for (int q = 0; q < kKeep; q++) {
         const uint32_t st = wave + (uint32_t)kMarkWaves * (uint32_t)q;
+        keep[q][0] = st < nst ? rec[(uint64_t)st * RUN + lane] : 0xFFFFFFFFu;
+    }
+    for (uint32_t i = threadIdx.x; i < nst; i += BLOCK)
+        s_cnt[i] = cnt[i];
+    for (uint32_t i = threadIdx.x; i < bucket_w; i += BLOCK)
+        first_t[i] = 0xFFFFFFFFu;
+    __syncthreads();
 #pragma unroll
-        for (int e = 0; e < PER; e++)
-            keep[q][e] = (st < nst && lane + 64u * e < s_cnt[st]) ? rec[(uint64_t)st * RUN + lane + 64u * e] : 0xFFFFFFFFu;
+    for (int q = 0; q < kKeep; q++) {
+        const uint32_t st = wave + (uint32_t)kMarkWaves * (uint32_t)q;
+        const uint32_t n = st < nst ? s_cnt[st] : 0u;
+        if (lane >= n)
+            keep[q][0] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int e = 1; e < PER; e++)
+            keep[q][e] = lane + 64u * e < n ? rec[(uint64_t)st * RUN + lane + 64u * e] : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int q = 0; q < kKeep; q++)
@@ -1007,13 +1045,15 @@ __global__ __launch_bounds__(256) void census_pack(AArgs a, CensusArgs c)
     __syncthreads();
     const uint32_t* const rec = c.rec + c.pair_rec_off[pair];
     for (uint32_t bu = threadIdx.x; bu < c.n_buckets; bu += 256) {
+        // a 64-byte line of the run at a time (four loads in flight instead of one behind the other)
         const uint4* run = reinterpret_cast<const uint4*>(rec + ((uint64_t)bu * nst + stretch) * RUN);
-        for (uint32_t q = 0; q < RUN / 4; q++) {
-            const uint4 v = run[q];
-            const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+        for (uint32_t q = 0; q < RUN / 16; q++) {
+            const uint4 v0 = run[4 * q], v1 = run[4 * q + 1], v2 = run[4 * q + 2], v3 = run[4 * q + 3];
+            const uint32_t w[16] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w,
+                                     v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w };
             bool more = true;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < 16; i++) {
                 if (more && (w[i] >> 31)) {
                     const uint32_t off = (w[i] >> 16) & (kCStretch - 1u);
                     atomicAdd(&s_touch[off >> 2], 1u << (8u * (off & 3u)));
@@ -1914,6 +1954,7 @@ int stage_a_run(gp_job* job)
         a.cand = nullptr;
         // counter ranges: a power of two wide, at most kCBuckets of them
         const bool wide = env_u64("GP_STAGE_A_CENSUS_WIDE", 1) != 0; // 32-byte groups of records (see kCBucketsWide)
+        const uint64_t scatter_rounds = env_u64("GP_STAGE_A_SCATTER_ROUNDS", 1); // rounds of four positions per lane and staged tile in census_scatter
         uint32_t bucket_shift = 2;
         while (((p.cbf_bytes + (1ull << bucket_shift) - 1) >> bucket_shift) > (wide ? kCBucketsWide : kCBuckets))
             bucket_shift++;
@@ -1996,8 +2037,7 @@ int stage_a_run(gp_job* job)
                 // census_scatter: a ring of eight record slots per range in LDS (40 KB at 1280 ranges:
                 // two workgroups per CU, which is also what it likes best -- with eight per CU and
                 // records stored one by one it had 670 MB of half-written runs in flight)
-                const size_t scatter_lds =
-                    (size_t)n_buckets * ((wide ? kCRingWide : 8u) + 1) * sizeof(uint32_t) + ((size_t)n_buckets + 3) / 4 * 4;
+                const size_t scatter_lds = (size_t)n_buckets * ((wide ? kCRingWide : 8u) + 1) * sizeof(uint32_t);
                 if (wide) // a 64 KB table and the run lengths: more than a workgroup gets without asking (per device)
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&census_mark<kCRunWide, kMarkBlockWide>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -2047,10 +2087,14 @@ int stage_a_run(gp_job* job)
                     c.cand = job->d_cand.p;
                     c.bucket_shift = bucket_shift;
                     c.n_buckets = n_buckets;
-                    if (wide)
-                        hipLaunchKernelGGL((census_scatter<kCRunWide, kCRingWide>), dim3((unsigned)nw), dim3(kBlock), scatter_lds, s, a, c);
+                    if (wide && scatter_rounds == 4)
+                        hipLaunchKernelGGL((census_scatter<kCRunWide, kCRingWide, 4>), dim3((unsigned)nw), dim3(kBlock), scatter_lds, s, a, c);
+                    else if (wide && scatter_rounds == 2)
+                        hipLaunchKernelGGL((census_scatter<kCRunWide, kCRingWide, 2>), dim3((unsigned)nw), dim3(kBlock), scatter_lds, s, a, c);
+                    else if (wide)
+                        hipLaunchKernelGGL((census_scatter<kCRunWide, kCRingWide, 1>), dim3((unsigned)nw), dim3(kBlock), scatter_lds, s, a, c);
                     else
-                        hipLaunchKernelGGL((census_scatter<kCRun, 8u>), dim3((unsigned)nw), dim3(kBlock), scatter_lds, s, a, c);
+                        hipLaunchKernelGGL((census_scatter<kCRun, 8u, 1>), dim3((unsigned)nw), dim3(kBlock), scatter_lds, s, a, c);
                     if (n_sets > 1) {
                         GP_HIP(hipEventRecord(ev_scattered, s));
                         GP_HIP(hipStreamWaitEvent(sm, ev_scattered, 0));
