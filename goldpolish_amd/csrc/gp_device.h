@@ -118,8 +118,29 @@ __device__ inline void kmer_hash_from_table(const uint64_t* T, const uint8_t* co
 {
     uint64_t f = 0, r = 0;
     int lb = -1;
-#pragma unroll 4
-    for (uint32_t i = 0; i < k; i++) {
+    // four bases at a time: their codes in one LDS round trip, their eight table entries in another
+    // (one base after the other the loop was a chain of 3 k dependent LDS look-ups)
+    uint32_t i = 0;
+    for (; i + 4 <= k; i += 4) {
+        uint32_t c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            c[u] = codes[i + u];
+        uint64_t tf[4], tr[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            tf[u] = T[(k - 1 - i - u) * 8 + c[u]];
+            tr[u] = T[(i + u) * 8 + (c[u] ^ 2u)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            f ^= tf[u];
+            r ^= tr[u];
+            if (c[u] >= 4)
+                lb = (int)(i + u);
+        }
+    }
+    for (; i < k; i++) {
         const uint32_t c = codes[i];
         f ^= T[(k - 1 - i) * 8 + c];
         r ^= T[i * 8 + (c ^ 2u)];
@@ -174,6 +195,40 @@ __device__ inline uint32_t mod32(uint32_t a, const FastMod& m)
 {
     uint64_t low = m.magic * (uint64_t)a;
     return (uint32_t)__umul64hi(low, (uint64_t)m.c);
+}
+
+// x % (5 * 2^s): GoldPolish's counting filter is 10 MiB = 5 * 2^21.  2^32, 2^16 and 2^8 are all 1 modulo 5,
+// so x >> s folds to a number below 1024 with adds and shifts, and t / 5 == (t * 205) >> 10 there.
+__device__ inline uint32_t mod_5_pow2(uint64_t x, uint32_t s)
+{
+    const uint64_t q = x >> s;
+    const uint32_t lo = (uint32_t)q, hi = (uint32_t)(q >> 32);
+    const uint32_t t2 = (lo & 0xFFFFu) + (lo >> 16) + (hi & 0xFFFFu) + (hi >> 16);   // < 2^18: 32-bit adds of 16-bit halves
+    const uint32_t t3 = (t2 & 0xFFu) + ((t2 >> 8) & 0xFFu) + (t2 >> 16);            // < 768
+    const uint32_t r5 = t3 - 5u * ((t3 * 205u) >> 10);
+    return (r5 << s) | ((uint32_t)x & ((1u << s) - 1u));
+}
+
+// The extension hashes 1..3 of one k-mer from ONE 64-bit multiply: their multipliers i ^ (k * seed)
+// differ from M = k * seed in the two lowest bits only, i.e. by a small signed d_i, and
+// base * (M + d_i) = base * M + d_i * base.  d[i] = ((M & 3) ^ i) - (M & 3), uniform per launch.
+struct ExtHash3 {
+    int d[4];
+};
+__host__ __device__ inline ExtHash3 make_ext_hash3(uint32_t k)
+{
+    ExtHash3 e{};
+    const int m2 = (int)(((uint64_t)k * kMultiSeed) & 3u);
+    for (int i = 0; i < 4; i++)
+        e.d[i] = (m2 ^ i) - m2;
+    return e;
+}
+// d * base for d in [-3, 3] (uniform): what the multiplier of extension hash i adds to base * M
+__device__ inline uint64_t ext_addend(uint64_t base, int d)
+{
+    const uint64_t m = d < 0 ? (uint64_t)(-d) : (uint64_t)d;
+    const uint64_t v = (m & 1 ? base : 0) + (m & 2 ? base << 1 : 0);
+    return d < 0 ? 0 - v : v;
 }
 
 __device__ inline uint64_t fastmod(uint64_t x, const FastMod& m)

@@ -741,9 +741,11 @@ struct CensusArgs {
 // 43 ms like this; 63-68 ms with the records sorted by bucket in LDS first and every run written
 // in one go, which costs a second hashing pass and most of the occupancy; 67 ms with 2048-position
 // stretches, whose runs of six records reach memory as partial sectors.)
-template <uint32_t RUN, uint32_t RING, int ROUNDS>
+template <uint32_t RUN, uint32_t RING, int ROUNDS, bool MOD5>
 __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
 {
+    // MOD5: the filter holds 5 * 2^s counters (GoldPolish's 10 MiB, s < 32) and an operation has four
+    // touches: the index arithmetic without the general reduction's code and branches
     // A lane hashes ROUNDS x kPerThread consecutive positions of a staged tile: the k-step start of
     // its run of positions (2k table look-ups) once, a roll per position after that; the ring is
     // emptied after every round (1024 positions, whichever they are: a record carries its position).
@@ -769,26 +771,45 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
     extern __shared__ uint32_t ring[]; // [ranges][RING], then hist[ranges]
     __shared__ uint8_t codes[TILE + kHalo];
     __shared__ uint64_t seed_t[kSeedTableWords];
+    // what a base brings to the two hashes when it enters a k-mer and when it leaves one, by code
+    // (codes >= 4: nothing): two 16-byte LDS reads per position instead of four select chains
+    __shared__ ulonglong2 roll_in[8], roll_out[8]; // {forward, reverse}
     // per range, one word: records so far (low half; at most 4 x 8192) and, in the high half, the groups
     // of the run that are not the ring's any more (base / G) -- the atomic that hands out a record's
     // rank brings the window along (a look-up less per touch)
     uint32_t* const hist = ring + (size_t)c.n_buckets * RING;
-    const uint32_t pair = c.wg_pair[blockIdx.x];
+    const uint32_t spare = c.n_buckets * (RING + 1u); // a word nobody reads
+    uint32_t n_positions = 0, n_ops = 0;
+    fill_seed_table(seed_t);
+    // A workgroup takes several stretches, one after the other (c.n_wg stretches over the grid): the
+    // stores a stretch leaves behind -- its last groups, the run lengths, what was left in the rings --
+    // drain while the next one is hashed.  With a workgroup per stretch the CU's LDS stayed taken until
+    // they had: the launch went no faster when the workgroup itself was made a fifth shorter.
+#pragma nounroll
+    for (uint32_t wg = blockIdx.x; wg < c.n_wg; wg += gridDim.x) {
+    __syncthreads(); // the stretch before is done with the rings and counters
+    const uint32_t pair = c.wg_pair[wg];
     const uint32_t b = c.pair_batch[pair], ki = c.pair_ki[pair];
     const KConsts& kc = a.kc[ki];
     const uint32_t k = kc.k;
     const uint64_t b_start = a.batch_pos[b], b_end = a.batch_pos[b + 1];
-    const uint64_t pos0 = c.wg_pos0[blockIdx.x];
+    const uint64_t pos0 = c.wg_pos0[wg];
     const uint64_t stretch_end = min(b_end, pos0 + (uint64_t)kCStretch);
     const uint32_t nst = c.pair_nst[pair], stretch = (uint32_t)((pos0 - b_start) / kCStretch);
     uint32_t* const rec = c.rec + c.pair_rec_off[pair];
     const int t0 = threadIdx.x * SPAN;
-    const uint32_t shift = c.bucket_shift, lmask = (1u << shift) - 1u;
-    uint32_t n_positions = 0, n_ops = 0;
+    const uint32_t shift = c.bucket_shift, lmask = (1u << shift) - 1u, mod5_s = a.cbf_mod.s;
     bool over = false;
     for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock)
         hist[i] = 0;
-    fill_seed_table(seed_t);
+    if (threadIdx.x < 8) {
+        const uint32_t cd = threadIdx.x;
+        roll_in[cd] = cd < 4 ? make_ulonglong2(seed_of_code(cd), kc.in_rev[cd]) : make_ulonglong2(0, 0);
+        roll_out[cd] = cd < 4 ? make_ulonglong2(kc.out_fwd[cd], seed_of_code(cd ^ 2)) : make_ulonglong2(0, 0);
+    }
+    const ExtHash3 eh = make_ext_hash3(k);
+    const uint64_t ext_m = (uint64_t)k * kMultiSeed;
+    const bool ext_plain = eh.d[1] == 1 && eh.d[2] == 2 && eh.d[3] == 3;
     // A tile's bases come as aligned 32-bit words, all of a lane's in flight together, a tile ahead.
     constexpr int NW = (TILE + kHalo) / 4 + 1, WPT = (NW + kBlock - 1) / kBlock;
     uint32_t pre[WPT];
@@ -853,12 +874,9 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
                     break;
                 if (jj > 0) {
                     const uint32_t out = codes[t0 + jj - 1], in = codes[t0 + jj + k - 1];
-                    const uint64_t s_in = in < 4 ? seed_of_code(in) : 0ULL;
-                    const uint64_t s_outk = out < 4 ? kc.out_fwd[out] : 0ULL;
-                    const uint64_t r_ink = in < 4 ? kc.in_rev[in] : 0ULL;
-                    const uint64_t r_out = out < 4 ? seed_of_code(out ^ 2) : 0ULL;
-                    fh = srol1(fh) ^ s_in ^ s_outk;
-                    rh = sror1(rh ^ r_ink ^ r_out);
+                    const ulonglong2 ri = roll_in[in], ro = roll_out[out];
+                    fh = srol1(fh) ^ ri.x ^ ro.x;
+                    rh = sror1(rh ^ ri.y ^ ro.y);
                     if (in >= 4)
                         last_bad = jj + (int)k - 1;
                 }
@@ -867,17 +885,49 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
                 n_ops++;
                 const uint64_t base = fh + rh;
                 const uint32_t off = (uint32_t)(st * TILE + t0 + jj); // position in the stretch
-                for (uint32_t h = 0; h < a.hash_num; h++) {
-                    const uint32_t ix = (uint32_t)fastmod(h ? ext_hash(base, k, h) : base, a.cbf_mod);
-                    const uint32_t bucket = ix >> shift;
-                    const uint32_t word = atomicAdd(&hist[bucket], 1u), rank = word & 0xFFFFu;
-                    const uint32_t r = (off << 16) | ((ix & lmask) << 2) | h;
-                    if (rank >= RUN)
-                        over = true;
-                    else if (rank - G * (word >> 16) < RING)
-                        ring[bucket * RING + (rank & (RING - 1u))] = r;
-                    else
-                        rec[((uint64_t)bucket * nst + stretch) * RUN + rank] = r;
+                // the operation's touches side by side: their indices, then their LDS atomics in flight
+                // together, then their records (one touch after the other the loop was a chain of
+                // multiply, reduction, atomic, wait and store per touch, at three waves per SIMD)
+                const uint32_t hn = MOD5 ? 4u : a.hash_num; // (MOD5 is launched for four hashes only)
+                uint32_t ix[4], word[4];
+                const uint64_t base_m = base * ext_m; // the one 64-bit multiply of the operation (see ExtHash3)
+                uint64_t hv[4];
+                hv[0] = base;
+                if (ext_plain) { // even k: the multipliers are M + 1, M + 2, M + 3
+                    hv[1] = base_m + base;
+                    hv[2] = hv[1] + base;
+                    hv[3] = hv[2] + base;
+                } else {
+#pragma unroll
+                    for (int h = 1; h < 4; h++)
+                        hv[h] = base_m + ext_addend(base, eh.d[h]);
+                }
+#pragma unroll
+                for (uint32_t h = 0; h < 4; h++) {
+                    if (h < hn) {
+                        const uint64_t v = h ? hv[h] ^ (hv[h] >> kMultiShift) : base;
+                        ix[h] = MOD5 ? mod_5_pow2(v, mod5_s) : (uint32_t)fastmod(v, a.cbf_mod);
+                    }
+                }
+#pragma unroll
+                for (uint32_t h = 0; h < 4; h++)
+                    if (h < hn)
+                        word[h] = atomicAdd(&hist[ix[h] >> shift], 1u);
+#pragma unroll
+                for (uint32_t h = 0; h < 4; h++) {
+                    if (h < hn) {
+                        const uint32_t bucket = ix[h] >> shift, rank = word[h] & 0xFFFFu;
+                        const uint32_t r = (off << 16) | ((ix[h] & lmask) << 2) | h;
+                        // (a rank past the run that still lies in the window lands in a ring slot of a
+                        // group the flush never writes; the pair is given up anyway)
+                        over |= rank >= RUN;
+                        const bool in_win = rank - G * (word[h] >> 16) < RING;
+                        // (a lane outside the window writes the spare word behind the counters)
+                        ring[in_win ? bucket * RING + (rank & (RING - 1u)) : spare] = r;
+                        if (__builtin_expect(__ballot(!in_win && rank < RUN) != 0ull, 0))
+                            if (!in_win && rank < RUN)
+                                rec[((uint64_t)bucket * nst + stretch) * RUN + rank] = r;
+                    }
                 }
             }
             __syncthreads();
@@ -914,6 +964,7 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
     }
     if (over)
         c.overflow[pair] = 1u; // many copies of one k-mer within the stretch: this pair is replayed whole
+    }
     // per-wave sums, one atomic each
     for (int o = 32; o > 0; o >>= 1) {
         n_positions += (uint32_t)__shfl_down((int)n_positions, o);
@@ -1954,6 +2005,7 @@ int stage_a_run(gp_job* job)
         a.cand = nullptr;
         // counter ranges: a power of two wide, at most kCBuckets of them
         const bool wide = env_u64("GP_STAGE_A_CENSUS_WIDE", 1) != 0; // 32-byte groups of records (see kCBucketsWide)
+        const uint64_t scatter_span = std::max<uint64_t>(1, env_u64("GP_STAGE_A_SCATTER_SPAN", 4)); // stretches per census_scatter workgroup
         const uint64_t scatter_rounds = env_u64("GP_STAGE_A_SCATTER_ROUNDS", 1); // rounds of four positions per lane and staged tile in census_scatter
         uint32_t bucket_shift = 2;
         while (((p.cbf_bytes + (1ull << bucket_shift) - 1) >> bucket_shift) > (wide ? kCBucketsWide : kCBuckets))
@@ -2037,7 +2089,7 @@ int stage_a_run(gp_job* job)
                 // census_scatter: a ring of eight record slots per range in LDS (40 KB at 1280 ranges:
                 // two workgroups per CU, which is also what it likes best -- with eight per CU and
                 // records stored one by one it had 670 MB of half-written runs in flight)
-                const size_t scatter_lds = (size_t)n_buckets * ((wide ? kCRingWide : 8u) + 1) * sizeof(uint32_t);
+                const size_t scatter_lds = ((size_t)n_buckets * ((wide ? kCRingWide : 8u) + 1) + 1) * sizeof(uint32_t);
                 if (wide) // a 64 KB table and the run lengths: more than a workgroup gets without asking (per device)
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&census_mark<kCRunWide, kMarkBlockWide>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -2087,14 +2139,20 @@ int stage_a_run(gp_job* job)
                     c.cand = job->d_cand.p;
                     c.bucket_shift = bucket_shift;
                     c.n_buckets = n_buckets;
-                    if (wide && scatter_rounds == 4)
-                        hipLaunchKernelGGL((census_scatter<kCRunWide, kCRingWide, 4>), dim3((unsigned)nw), dim3(kBlock), scatter_lds, s, a, c);
-                    else if (wide && scatter_rounds == 2)
-                        hipLaunchKernelGGL((census_scatter<kCRunWide, kCRingWide, 2>), dim3((unsigned)nw), dim3(kBlock), scatter_lds, s, a, c);
-                    else if (wide)
-                        hipLaunchKernelGGL((census_scatter<kCRunWide, kCRingWide, 1>), dim3((unsigned)nw), dim3(kBlock), scatter_lds, s, a, c);
-                    else
-                        hipLaunchKernelGGL((census_scatter<kCRun, 8u, 1>), dim3((unsigned)nw), dim3(kBlock), scatter_lds, s, a, c);
+                    {
+                        const bool mod5 = a.cbf_mod.fast && a.cbf_mod.c == 5 && a.cbf_mod.s < 32 && a.hash_num == 4;
+                        const dim3 g((unsigned)((nw + scatter_span - 1) / scatter_span)), bl(kBlock);
+                        if (wide && scatter_rounds == 4 && mod5)
+                            hipLaunchKernelGGL((census_scatter<kCRunWide, kCRingWide, 4, true>), g, bl, scatter_lds, s, a, c);
+                        else if (wide && scatter_rounds == 4)
+                            hipLaunchKernelGGL((census_scatter<kCRunWide, kCRingWide, 4, false>), g, bl, scatter_lds, s, a, c);
+                        else if (wide && mod5)
+                            hipLaunchKernelGGL((census_scatter<kCRunWide, kCRingWide, 1, true>), g, bl, scatter_lds, s, a, c);
+                        else if (wide)
+                            hipLaunchKernelGGL((census_scatter<kCRunWide, kCRingWide, 1, false>), g, bl, scatter_lds, s, a, c);
+                        else
+                            hipLaunchKernelGGL((census_scatter<kCRun, 8u, 1, false>), g, bl, scatter_lds, s, a, c);
+                    }
                     if (n_sets > 1) {
                         GP_HIP(hipEventRecord(ev_scattered, s));
                         GP_HIP(hipStreamWaitEvent(sm, ev_scattered, 0));
