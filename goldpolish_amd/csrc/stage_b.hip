@@ -3568,6 +3568,20 @@ int stage_b_pass(gp_job* job, uint32_t ki)
         }
         std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return tot[x] > tot[y]; });
         static const char* names[8] = { "done", "scan", "site", "next", "bitscan", "refill", "sweep", "-" };
+        {
+            double sum_t[8] = {}, all = 0;
+            unsigned long long sum_n[8] = {};
+            for (uint32_t c = 0; c < job->n_contigs; c++)
+                for (int i = 0; i < 8; i++) {
+                    sum_t[i] += (double)h[(size_t)c * 16 + i] / 1e5;
+                    sum_n[i] += h[(size_t)c * 16 + 8 + i];
+                    all += (double)h[(size_t)c * 16 + i] / 1e5;
+                }
+            fprintf(stderr, "WALKPROF k=%u all %u contigs: %.1f ms of workgroup time =", a.k, job->n_contigs, all);
+            for (int i = 1; i < 7; i++)
+                fprintf(stderr, " %s %.1f ms / %llu (%.1f us each)", names[i], sum_t[i], sum_n[i], sum_n[i] ? sum_t[i] * 1e3 / sum_n[i] : 0.0);
+            fprintf(stderr, "\n");
+        }
         for (uint32_t r = 0; r < std::min<uint32_t>(6, job->n_contigs); r++) {
             const uint32_t c = order[r];
             fprintf(stderr, "WALKPROF k=%u contig %u len %llu: %.1f ms =", a.k, c,
