@@ -732,6 +732,7 @@ struct CensusArgs {
     unsigned long long* cand;
     uint32_t bucket_shift;         // a range holds 1 << bucket_shift counters
     uint32_t n_buckets;            // ranges per pair
+    uint32_t seed_rows;            // census_scatter: rows of its table of rotated seeds (the largest k)
 };
 
 // ---- census 1: every counter touch of an 8192-position stretch into the bucket of its counter
@@ -768,9 +769,8 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
     // straight to memory, so a group is always written by one of the two ways only.
     // (ring, counters and group bases are sized by the pair's ranges, not by the most a pair may
     // have: three workgroups per CU where the static 2048-range arrays left room for two)
-    extern __shared__ uint32_t ring[]; // [ranges][RING], then hist[ranges]
+    extern __shared__ uint32_t ring[]; // [ranges][RING], then hist[ranges], a spare word, then the table of rotated seeds (c.seed_rows x 8)
     __shared__ uint8_t codes[TILE + kHalo];
-    __shared__ uint64_t seed_t[kSeedTableWords];
     // what a base brings to the two hashes when it enters a k-mer and when it leaves one, by code
     // (codes >= 4: nothing): two 16-byte LDS reads per position instead of four select chains
     __shared__ ulonglong2 roll_in[8], roll_out[8]; // {forward, reverse}
@@ -779,8 +779,14 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
     // rank brings the window along (a look-up less per touch)
     uint32_t* const hist = ring + (size_t)c.n_buckets * RING;
     const uint32_t spare = c.n_buckets * (RING + 1u); // a word nobody reads
+    // the seeds rotated by 0 .. (largest k) - 1 only: 2 KB at k = 32 instead of the 4 KB of 64 rows, which
+    // is what lets two of these workgroups and one of census_mark's (64 KB) share a CU's 160 KB
+    uint64_t* const seed_t = reinterpret_cast<uint64_t*>(ring + ((spare + 2u) & ~1u));
+    for (uint32_t i = threadIdx.x; i < c.seed_rows * 8u; i += kBlock) {
+        const uint32_t code = i & 7u;
+        seed_t[i] = code < 4 ? sroln(seed_of_code(code), i >> 3) : 0ULL;
+    }
     uint32_t n_positions = 0, n_ops = 0;
-    fill_seed_table(seed_t);
     // A workgroup takes several stretches, one after the other (c.n_wg stretches over the grid): the
     // stores a stretch leaves behind -- its last groups, the run lengths, what was left in the rings --
     // drain while the next one is hashed.  With a workgroup per stretch the CU's LDS stayed taken until
@@ -2018,6 +2024,7 @@ int stage_a_run(gp_job* job)
             // the census: both kernels are held by LDS -- 2 x 56 KB and 4 x 33 KB per CU -- so beside a
             // full scatter the mark gets one workgroup per CU.)
             const uint32_t n_sets = env_u64("GP_STAGE_A_CENSUS_OVERLAP", 1) ? 2u : 1u;
+            const uint64_t scatter_per_cu = env_u64("GP_STAGE_A_SCATTER_PER_CU", n_sets > 1 ? 2 : 0); // census_scatter workgroups per CU (0: no cap on its grid)
             const uint64_t rec_budget = (env_u64("GP_STAGE_A_CENSUS_MB", 16384) << 20) / 4 / n_sets; // (4-byte) record slots of a cohort
             h_pair_mode.assign(n_pairs, 0);
             h_pair_bit_off.assign(n_pairs, 0);
@@ -2089,7 +2096,11 @@ int stage_a_run(gp_job* job)
                 // census_scatter: a ring of eight record slots per range in LDS (40 KB at 1280 ranges:
                 // two workgroups per CU, which is also what it likes best -- with eight per CU and
                 // records stored one by one it had 670 MB of half-written runs in flight)
-                const size_t scatter_lds = ((size_t)n_buckets * ((wide ? kCRingWide : 8u) + 1) + 1) * sizeof(uint32_t);
+                uint32_t k_max = 1;
+                for (uint32_t ki = 0; ki < p.n_k; ki++)
+                    k_max = std::max(k_max, p.k[ki]);
+                const size_t scatter_lds =
+                    (((size_t)n_buckets * ((wide ? kCRingWide : 8u) + 1) + 2) & ~(size_t)1) * sizeof(uint32_t) + (size_t)k_max * 8 * sizeof(uint64_t);
                 if (wide) // a 64 KB table and the run lengths: more than a workgroup gets without asking (per device)
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&census_mark<kCRunWide, kMarkBlockWide>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -2139,9 +2150,15 @@ int stage_a_run(gp_job* job)
                     c.cand = job->d_cand.p;
                     c.bucket_shift = bucket_shift;
                     c.n_buckets = n_buckets;
+                    c.seed_rows = k_max;
                     {
                         const bool mod5 = a.cbf_mod.fast && a.cbf_mod.c == 5 && a.cbf_mod.s < 32 && a.hash_num == 4;
-                        const dim3 g((unsigned)((nw + scatter_span - 1) / scatter_span)), bl(kBlock);
+                        // (beside census_mark -- two buffer sets -- the grid is two workgroups per CU, each
+                        // taking its share of the stretches: with the mark's workgroup that is what a CU holds)
+                        uint64_t n_g = (nw + scatter_span - 1) / scatter_span;
+                        if (scatter_per_cu)
+                            n_g = std::min<uint64_t>(n_g, scatter_per_cu * (uint64_t)job->ctx->prop.multiProcessorCount);
+                        const dim3 g((unsigned)n_g), bl(kBlock);
                         if (wide && scatter_rounds == 4 && mod5)
                             hipLaunchKernelGGL((census_scatter<kCRunWide, kCRingWide, 4, true>), g, bl, scatter_lds, s, a, c);
                         else if (wide && scatter_rounds == 4)
