@@ -168,8 +168,8 @@ struct gp_job {
     uint32_t* h_count_pinned = nullptr;
     hipEvent_t a_ev[16] = {}, a_ev_b[16] = {}; // per-step joins of the two stage-A streams
     hipEvent_t a_ev_init = nullptr;
-    hipEvent_t a_ev_census[4] = {}; // scattered[2], marked[2]: the census's two buffer sets (stage_a_run)
-    hipStream_t a_stream2 = nullptr;
+    hipEvent_t a_ev_census[9] = {}; // scattered[3], marked[3], packed[3]: the census's buffer sets (stage_a_run)
+    hipStream_t a_stream2 = nullptr, a_stream3 = nullptr;
 
     // ---- stage B/C state (see stage_b.hip / stage_c.hip)
     gp::StageBC* bc = nullptr;

@@ -1791,6 +1791,7 @@ int stage_a_prepare(gp_job* job)
     }
     GP_HIP(hipEventCreateWithFlags(&job->a_ev_init, hipEventDisableTiming));
     GP_HIP(hipStreamCreateWithFlags(&job->a_stream2, hipStreamNonBlocking));
+    GP_HIP(hipStreamCreateWithFlags(&job->a_stream3, hipStreamNonBlocking));
     for (hipEvent_t& e : job->a_ev_census)
         GP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return GP_OK;
@@ -1811,6 +1812,9 @@ void stage_a_release(gp_job* job)
         (void)hipEventDestroy(job->a_ev_init);
     if (job->a_stream2)
         (void)hipStreamDestroy(job->a_stream2);
+    if (job->a_stream3)
+        (void)hipStreamDestroy(job->a_stream3);
+    job->a_stream2 = job->a_stream3 = nullptr;
     for (hipEvent_t& e : job->a_ev_census)
         if (e) {
             (void)hipEventDestroy(e);
@@ -1827,14 +1831,16 @@ int stage_a_run(gp_job* job)
     // the back half on another stream) may take "returned" as "the filters are there", and the
     // copies enqueued below read from tables that live on this stack frame.
     struct Drain {
-        hipStream_t a, b;
+        hipStream_t a, b, c;
         ~Drain()
         {
             (void)hipStreamSynchronize(a);
             if (b)
                 (void)hipStreamSynchronize(b);
+            if (c)
+                (void)hipStreamSynchronize(c);
         }
-    } drain{ s, job->a_stream2 };
+    } drain{ s, job->a_stream2, job->a_stream3 };
     AArgs a{};
     a.reads = job->d_reads.p;
     a.n_pos = job->read_positions;
@@ -2023,7 +2029,12 @@ int stage_a_run(gp_job* job)
             // census_mark / census_pack of the one before it (latency), on two streams.  (Worth 4 % of
             // the census: both kernels are held by LDS -- 2 x 56 KB and 4 x 33 KB per CU -- so beside a
             // full scatter the mark gets one workgroup per CU.)
-            const uint32_t n_sets = env_u64("GP_STAGE_A_CENSUS_OVERLAP", 1) ? 2u : 1u;
+            // (OVERLAP=3: three sets and census_pack on a stream of its own, so that no cohort waits for the
+            // pack of the one before -- in the trace the chip idles for it, a tenth of a cohort's time;
+            // measured: 91.7 against 91.8 ms per 1000 contigs, the pack beside the next mark costs what it
+            // saves.  =0: one set, one stream)
+            const uint64_t overlap = env_u64("GP_STAGE_A_CENSUS_OVERLAP", 1);
+            const uint32_t n_sets = overlap == 0 ? 1u : overlap == 3 ? 3u : 2u;
             const uint64_t scatter_per_cu = env_u64("GP_STAGE_A_SCATTER_PER_CU", n_sets > 1 ? 2 : 0); // census_scatter workgroups per CU (0: no cap on its grid)
             const uint64_t rec_budget = (env_u64("GP_STAGE_A_CENSUS_MB", 16384) << 20) / 4 / n_sets; // (4-byte) record slots of a cohort
             h_pair_mode.assign(n_pairs, 0);
@@ -2104,13 +2115,15 @@ int stage_a_run(gp_job* job)
                 if (wide) // a 64 KB table and the run lengths: more than a workgroup gets without asking (per device)
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&census_mark<kCRunWide, kMarkBlockWide>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                hipStream_t sm = n_sets > 1 ? job->a_stream2 : s; // mark and pack
+                hipStream_t sm = n_sets > 1 ? job->a_stream2 : s;  // mark
+                hipStream_t sp = n_sets > 2 ? job->a_stream3 : sm; // pack
                 for (size_t ci = 0; ci < cohorts.size(); ci++) {
                     Cohort& co = cohorts[ci];
                     const uint32_t set = (uint32_t)(ci % n_sets);
-                    hipEvent_t ev_scattered = job->a_ev_census[set], ev_marked = job->a_ev_census[2 + set];
+                    hipEvent_t ev_scattered = job->a_ev_census[set], ev_marked = job->a_ev_census[3 + set],
+                               ev_packed = job->a_ev_census[6 + set];
                     if (n_sets > 1 && ci >= n_sets)
-                        GP_HIP(hipStreamWaitEvent(s, ev_marked, 0)); // the set's previous cohort has been packed
+                        GP_HIP(hipStreamWaitEvent(s, ev_packed, 0)); // the set's previous cohort has been packed
                     uint32_t* const d_tab32 = job->d_census_tab32.p + (uint64_t)set * tab32_n;
                     uint64_t* const d_tab64 = job->d_census_tab64.p + (uint64_t)set * tab64_n;
                     uint32_t* const d_over = job->d_census_over.p + (uint64_t)set * max_pairs;
@@ -2185,17 +2198,21 @@ int stage_a_run(gp_job* job)
                         else
                             hipLaunchKernelGGL((census_mark<kCRun, kMarkBlock>), dim3((unsigned)(np * n_buckets)), dim3(kMarkBlock), lds, sm, c);
                     }
+                    if (sp != sm) {
+                        GP_HIP(hipEventRecord(ev_marked, sm));
+                        GP_HIP(hipStreamWaitEvent(sp, ev_marked, 0));
+                    }
                     if (wide)
-                        hipLaunchKernelGGL((census_pack<kCRunWide>), dim3((unsigned)nw), dim3(256), 0, sm, a, c);
+                        hipLaunchKernelGGL((census_pack<kCRunWide>), dim3((unsigned)nw), dim3(256), 0, sp, a, c);
                     else
-                        hipLaunchKernelGGL((census_pack<kCRun>), dim3((unsigned)nw), dim3(256), 0, sm, a, c);
+                        hipLaunchKernelGGL((census_pack<kCRun>), dim3((unsigned)nw), dim3(256), 0, sp, a, c);
                     GP_HIP(hipGetLastError());
                     if (n_sets > 1)
-                        GP_HIP(hipEventRecord(ev_marked, sm));
+                        GP_HIP(hipEventRecord(ev_packed, sp));
                 }
                 if (n_sets > 1) // everything has been packed before the replay starts
                     for (uint32_t set = 0; set < n_sets && set < cohorts.size(); set++)
-                        GP_HIP(hipStreamWaitEvent(s, job->a_ev_census[2 + set], 0));
+                        GP_HIP(hipStreamWaitEvent(s, job->a_ev_census[6 + set], 0));
                 if ((rcc = job->t_census.end(s)) != GP_OK)
                     return rcc;
                 a.pair_mode = job->d_pair_mode.p;
