@@ -3344,7 +3344,7 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     }
     // waves per SIMD the walk is compiled for: many contigs -> more workgroups per CU at fewer
     // registers (GP_WALK_WAVES overrides: 1 or 4; compiled for 6 the kernel no longer fits 80 registers and was slower: 170 against 149 ms on 4000 x 25 kbp)
-    const uint64_t walk_waves = env_u64("GP_WALK_WAVES", job->n_contigs > 3 * 256 ? 4 : 1); // (measured on 1000 x 25 kbp: 6 -> 52 ms, 5 -> 50, 4 -> 45, 1 -> 63)
+    const uint64_t walk_waves = env_u64("GP_WALK_WAVES", job->n_contigs > 3 * 256 ? 4 : 1); // (measured on 1000 x 25 kbp: 6 -> 52 ms, 5 -> 50, 4 -> 45, 1 -> 63; on 4000 x 25 kbp: 4 -> 150, 3 (168 registers, 14 spilled) -> 174, 1 -> 216)
     auto launch_walk = [&](unsigned grid, bool seg) {
         if (seg)
             hipLaunchKernelGGL((ntedit_walk<1, true>), dim3(grid), dim3(kWalkThreads), 0, s, a);
