@@ -66,6 +66,28 @@ def run_and_compare(core, ctx, oracle, w, params, batch_contig_begin=None):
         job.close()
 
 
+@pytest.mark.parametrize("knobs", [
+    {"GP_STAGE_A_CENSUS_WIDE": "0"},                                   # ranges of 8192 counters, 16-byte record groups
+    {"GP_STAGE_A_SCATTER_ROUNDS": "4"},                                # four rounds per staged tile
+    {"GP_STAGE_A_CENSUS_OVERLAP": "3"},                                # three buffer sets, the pack on its own stream
+    {"GP_STAGE_A_CENSUS_OVERLAP": "0"},                                # one set, one stream, no cap on the scatter's grid
+    {"GP_STAGE_A_SCATTER_PER_CU": "0", "GP_STAGE_A_SCATTER_SPAN": "1"},  # a workgroup per stretch
+    {"GP_STAGE_A_CENSUS_MB": "64"},                                    # many small cohorts
+])
+def test_census_geometries_and_schedules_give_the_same_filters(gp, oracle, stage_a_path, knobs, monkeypatch):
+    """the census kernels' compile-time geometries and the host's ways of scheduling them (default:
+    wide ranges, one round, two sets, two scatter workgroups per CU) against the serial oracle, at
+    GoldPolish's filter sizes (the 5 * 2^21 index arithmetic) and at a size that takes the general one"""
+    if stage_a_path != "census":
+        pytest.skip("census knobs")
+    core, ctx = gp
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    w = synth.make_workload([30000, 12000, 21000, 800], 30, seed=23)
+    run_and_compare(core, ctx, oracle, w, core.default_params())
+    run_and_compare(core, ctx, oracle, w, core.default_params(cbf_bytes=3000017, bf_bytes=262144))
+
+
 def test_filters_match_oracle_default_sizes(gp, oracle, stage_a_path):
     core, ctx = gp
     w = synth.make_workload([25000, 9000, 14000], 30, seed=11)
