@@ -797,7 +797,7 @@ __device__ inline void gather_fill(const Ctx& c, Shared& S, uint8_t* z)
     const uint32_t ns = S.n_gseg;
     for (uint32_t g = 0; g < ns; g++) {
         const uint32_t z0 = S.gseg[g].z0, pos = S.gseg[g].pos, cnt = S.gseg[g].cnt;
-        for (uint32_t i = threadIdx.x; i < cnt; i += kWalkThreads)
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x)
             z[z0 + i] = c.seq[pos + i];
     }
 }
@@ -843,7 +843,7 @@ __device__ inline uint32_t block_min(Shared& S, uint32_t v)
         S.wave_min[wave] = first;
     __syncthreads();
     uint32_t r = 0xFFFFFFFFu;
-    for (int w = 0; w < kWalkThreads / 64; w++)
+    for (int w = 0; w < (int)(blockDim.x / 64); w++)
         r = min(r, S.wave_min[w]);
     __syncthreads();
     return r;
@@ -858,7 +858,7 @@ __device__ inline uint32_t block_sum(Shared& S, uint32_t v)
         S.wave_min[wave] = v;
     __syncthreads();
     uint32_t r = 0;
-    for (int w = 0; w < kWalkThreads / 64; w++)
+    for (int w = 0; w < (int)(blockDim.x / 64); w++)
         r += S.wave_min[w];
     __syncthreads();
     return r;
@@ -879,7 +879,7 @@ __device__ void indel_sweep(const Ctx& c, Shared& S, uint8_t index_char, uint32_
                                : 0u;
     uint32_t probes = 0;
     uint32_t my_best = 0;
-    for (uint32_t cand = threadIdx.x; cand < n_ins + n_del; cand += kWalkThreads) {
+    for (uint32_t cand = threadIdx.x; cand < n_ins + n_del; cand += blockDim.x) {
         uint64_t fh = S.fh, rh = S.rh;
         uint32_t present = 0, order;
         bool pass;
@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(kWalkThreads, 6) void ntedit_site_eval(WalkArgs a, 
             S.st_probes = 0;
         }
         __syncthreads();
-        for (uint32_t i = tid; i < S.nz; i += kWalkThreads)
+        for (uint32_t i = tid; i < S.nz; i += blockDim.x)
             S.Z[i] = c.seq[cand + i];
         __syncthreads();
         {
@@ -1590,7 +1590,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                 } else {
                     uint32_t ahead = len - 1 - S.ti;
                     uint32_t j0 = S.cur_tested ? 1u : 0u;
-                    uint32_t n = min((uint32_t)kWalkThreads, ahead + 1 - j0);
+                    uint32_t n = min((uint32_t)blockDim.x, ahead + 1 - j0);
                     // head and tail in the final run: k-mer j starts at contig position hi + j, and
                     // from clean_from on the records answer -- hash only what an edit has touched
                     if (S.hn == S.tn && S.clean_from > S.hi + j0 && a.site_rec != nullptr)
@@ -1669,7 +1669,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                     // nothing absent and testable in this chunk's words (every lane reads the same
                     // few words, so this is uniform)?  Then fast-forward: one word per lane,
                     // 16 k positions per step, to the next word that holds a bit.
-                    const uint64_t w_lo = (base_bit + p) >> 6, w_hi = (base_bit + min(p + kWalkThreads - 1, last_p)) >> 6;
+                    const uint64_t w_lo = (base_bit + p) >> 6, w_hi = (base_bit + min(p + (uint32_t)blockDim.x - 1, last_p)) >> 6;
                     unsigned long long any = 0;
                     for (uint64_t w = w_lo; w <= w_hi; w++)
                         any |= a.bm_site[w] & a.bm_ok[w];
@@ -1683,7 +1683,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                             if (w <= w_last && (a.bm_site[w] & a.bm_ok[w]))
                                 hit = (uint32_t)(w - w_lo);
                             found = block_min(S, hit);
-                            w0 += kWalkThreads;
+                            w0 += blockDim.x;
                         }
                         if (found == 0xFFFFFFFFu) {
                             p = last_p + 1; // ran off the end
@@ -1734,7 +1734,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                 }
                 if (first != 0xFFFFFFFFu)
                     break;
-                p += kWalkThreads;
+                p += blockDim.x;
             }
             if (my_sites)
                 atomicAdd(&S.st_sites, (unsigned long long)my_sites);
@@ -1807,16 +1807,16 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             const uint32_t nw = (uint32_t)min((uint64_t)kCacheWords, w_last - w0 + 1);
             const uint32_t p0 = (uint32_t)((w0 << 6) - base_bit); // slots start on 1024-byte boundaries
             const uint32_t nb = min((uint32_t)kCacheBases, len - p0);
-            for (uint32_t i = tid; i < nw; i += kWalkThreads) {
+            for (uint32_t i = tid; i < nw; i += blockDim.x) {
                 S.c_site[i] = a.bm_site[w0 + i];
                 S.c_ok[i] = a.bm_ok[w0 + i];
             }
             {
                 const uint4* src4 = reinterpret_cast<const uint4*>(c.seq + p0); // p0 is a multiple of 64
                 uint4* dst4 = reinterpret_cast<uint4*>(S.c_seq);
-                for (uint32_t i = tid; i < nb / 16; i += kWalkThreads)
+                for (uint32_t i = tid; i < nb / 16; i += blockDim.x)
                     dst4[i] = src4[i];
-                for (uint32_t i = (nb / 16) * 16 + tid; i < nb; i += kWalkThreads)
+                for (uint32_t i = (nb / 16) * 16 + tid; i < nb; i += blockDim.x)
                     S.c_seq[i] = c.seq[p0 + i];
             }
             __syncthreads();
@@ -1836,7 +1836,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             const uint64_t base_bit = a.off[cid];
             const uint64_t w_first = (base_bit + from) >> 6, w_last = (base_bit + last_p) >> 6;
             uint32_t found = 0xFFFFFFFFu;
-            for (uint64_t w0 = w_first; w0 <= w_last && found == 0xFFFFFFFFu; w0 += kWalkThreads) {
+            for (uint64_t w0 = w_first; w0 <= w_last && found == 0xFFFFFFFFu; w0 += blockDim.x) {
                 const uint64_t w = w0 + tid;
                 uint32_t hit = 0xFFFFFFFFu;
                 if (w <= w_last) {
@@ -1877,11 +1877,11 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             // lookahead chars Z[k..nz) come straight from the (untouched) contig
             const uint32_t j0 = S.scan_j0, n = S.scan_n, ti0 = S.ti;
             if (S.fast_head)
-                for (uint32_t i = tid; i < k; i += kWalkThreads)
+                for (uint32_t i = tid; i < k; i += blockDim.x)
                     S.Z[i] = c.seq[S.hi + i];
             else
                 gather_fill(c, S, S.Z); // the runs gather_plan left
-            for (uint32_t i = k + tid; i < S.nz; i += kWalkThreads)
+            for (uint32_t i = k + tid; i < S.nz; i += blockDim.x)
                 S.Z[i] = c.seq[ti0 + 1 + (i - k)];
             __syncthreads();
             uint32_t hit = 0xFFFFFFFFu;
@@ -1953,7 +1953,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
         // flags are read once, here, by everybody; thread 0 only rewrites them behind barriers
         const uint32_t f_fast = S.fast_head, f_hash = S.need_hash, f_confirmed = S.confirmed;
         if (f_fast) {
-            for (uint32_t i = tid; i < S.nz; i += kWalkThreads) {
+            for (uint32_t i = tid; i < S.nz; i += blockDim.x) {
                 const uint32_t pos = S.hi + i;
                 S.Z[i] = pos - S.cp0 < S.cpn ? S.c_seq[pos - S.cp0] : c.seq[pos];
             }
@@ -2072,8 +2072,8 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
         {
             // thread (si*64 + q): q == 63 probes the changed k-mer itself,
             // q < k probes the k-mer after q+1 rolls when q % jump == 0
-            const uint32_t si = tid >> 6, q = tid & 63;
-            if (si < S.n_sub) {
+            const uint32_t q = tid & 63;
+            for (uint32_t si = tid >> 6; si < S.n_sub; si += blockDim.x / 64) { // (128-thread workgroups: two waves for up to three substitutes)
                 const uint8_t sb = S.subs[si];
                 if (q == 63) {
                     uint64_t fh = S.fh, rh = S.rh;
@@ -3345,11 +3345,17 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     // waves per SIMD the walk is compiled for: many contigs -> more workgroups per CU at fewer
     // registers (GP_WALK_WAVES overrides: 1 or 4; compiled for 6 the kernel no longer fits 80 registers and was slower: 170 against 149 ms on 4000 x 25 kbp)
     const uint64_t walk_waves = env_u64("GP_WALK_WAVES", job->n_contigs > 3 * 256 ? 4 : 1); // (measured on 1000 x 25 kbp: 6 -> 52 ms, 5 -> 50, 4 -> 45, 1 -> 63; on 4000 x 25 kbp: 4 -> 150, 3 (168 registers, 14 spilled) -> 174, 1 -> 216)
+    // Threads per walking workgroup: the walk is thread 0's chain of decisions with all lanes helping in
+    // bursts (a scan after an edit covers k positions, a site's window 2k + 12 characters), and what
+    // bounds a launch of thousands of contigs is how many of them a CU holds -- at 128 threads twice as
+    // many for the same registers.  (A site's window must fit the workgroup: k <= 56.)
+    const unsigned walk_threads =
+        (unsigned)env_u64("GP_WALK_THREADS", (walk_waves >= 4 && a.k <= 56) ? 128 : kWalkThreads) == 128 && a.k <= 56 ? 128u : (unsigned)kWalkThreads;
     auto launch_walk = [&](unsigned grid, bool seg) {
         if (seg)
             hipLaunchKernelGGL((ntedit_walk<1, true>), dim3(grid), dim3(kWalkThreads), 0, s, a);
         else if (walk_waves >= 4)
-            hipLaunchKernelGGL((ntedit_walk<4, false>), dim3(grid), dim3(kWalkThreads), 0, s, a);
+            hipLaunchKernelGGL((ntedit_walk<4, false>), dim3(grid), dim3(walk_threads), 0, s, a);
         else
             hipLaunchKernelGGL((ntedit_walk<1, false>), dim3(grid), dim3(kWalkThreads), 0, s, a);
     };
