@@ -46,3 +46,17 @@ def test_random_jobs_with_contigs_walked_as_segments(oracle, monkeypatch):
         monkeypatch.setenv("GP_WALK_SEG_FORCE", "1")
         for seed in [910080] + list(range(920000, 920008)):
             assert fuzz_parity.run_case(core, ctx, oracle, seed, "2") is None, ("forced", seed)
+
+
+def test_random_jobs_with_128_thread_walkers(oracle, monkeypatch):
+    """the walk as jobs of many contigs run it: four waves per SIMD, 128-thread workgroups (a wave
+    per substitute takes two turns, every loop strides by the workgroup's real size)"""
+    import fuzz_parity
+    from goldpolish_amd import core
+    for name in ("GP_STAGE_A_LOCAL", "GP_STAGE_A_CENSUS", "GP_STAGE_A_CENSUS_MIN"):
+        monkeypatch.setenv(name, "0")
+    monkeypatch.setenv("GP_WALK_WAVES", "4")
+    monkeypatch.setenv("GP_WALK_THREADS", "128")
+    with core.Context(0) as ctx:
+        for seed in [1086, 20621, 20645, 300029] + list(range(7000, 7009)) + list(range(930000, 930020)):
+            assert fuzz_parity.run_case(core, ctx, oracle, seed, "2") is None, seed

@@ -11,12 +11,18 @@ from test_gpu_stage_a import _custom_workload, oracle_filters
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["sites ahead of the walk", "every site on the spot"], autouse=True)
+@pytest.fixture(params=["sites ahead of the walk", "every site on the spot", "128-thread workgroups",
+                        "128-thread workgroups, every site on the spot"], autouse=True)
 def walk_mode(request, monkeypatch):
     """both ways the walk gets a site's decision: from ntedit_site_eval's records (default) and
-    worked out on the spot at every site (GP_NTEDIT_SPECULATE=0)"""
-    if request.param == "every site on the spot":
+    worked out on the spot at every site (GP_NTEDIT_SPECULATE=0); and both workgroup shapes: the
+    256-thread build of small jobs and the four-waves-per-SIMD build with 128-thread workgroups that
+    jobs of many contigs get (forced here: GP_WALK_WAVES=4)"""
+    if "every site on the spot" in request.param:
         monkeypatch.setenv("GP_NTEDIT_SPECULATE", "0")
+    if "128-thread" in request.param:
+        monkeypatch.setenv("GP_WALK_WAVES", "4")
+        monkeypatch.setenv("GP_WALK_THREADS", "128")
     return request.param
 
 
