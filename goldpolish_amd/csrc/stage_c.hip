@@ -46,12 +46,12 @@ constexpr uint32_t kPathCap = 1024;          // vertices per stored path
 // lane-per-gap first attempt: a small private arena per lane; what outgrows it, or finds paths
 // to enumerate, is done again by the one-gap-per-wave workers with their big arenas
 constexpr uint32_t kSmallSlotBits = 8, kSmallVerts = 96, kSmallEdges = 256;
-constexpr uint32_t kSimtWaves = 3072;   // waves of the lane-per-gap kernel (three per SIMD is what its registers allow) ...
+constexpr uint32_t kSimtWaves = 4096;   // waves of the lane-per-gap kernel (four per SIMD: compiled for 128 registers it spills 13 and is still faster than three) ...
 constexpr uint32_t kSimtLanes = 32;     // ... and the lanes of each that take a gap (divergent walks serialise)
 constexpr uint32_t kNwMax = 1800;            // longest sequence the consensus aligner takes
-constexpr uint32_t kMaxWorkers = 3072;  // one-wave workers of sealer_connect (CState::n_workers: by job size)
+constexpr uint32_t kMaxWorkers = 4096;  // one-wave workers of sealer_connect (CState::n_workers: by job size)
 // Their arenas come in two sizes.  Nearly every search a worker takes stays below a few thousand
-// vertices (limit 1000 open branches), so the 3072 workers of the first pass hold 8192 vertices each
+// vertices (limit 1000 open branches), so the 4096 workers of the first pass hold 8192 vertices each
 // (1 MB with edges, slots, queues and path scratch: 3 GiB), and what outgrows that -- the cost cap of
 // 100 000 allows 131 072 vertices -- is done again by at most 256 workers with full arenas (13 MB
 // each: 3.3 GiB).  Round 2 gave all 3072 workers full arenas: 39 GiB for a stage of 0.15 s.
@@ -120,7 +120,7 @@ struct CState {
     std::vector<uint32_t> h_gap_off;
     uint32_t gap_cap = 0, table_bits = 0, multi_cap = 0;
     uint32_t n_big = 0;            // workers with full arenas (all of them where long contigs are polished, else kBigWorkers)
-    uint32_t n_workers = 0;        // sealer_connect's grid: 1024 took 0.15 s per configs[2] step, 2048 0.10 s, 3072 (three waves per SIMD: what its registers allow) 0.08 s
+    uint32_t n_workers = 0;        // sealer_connect's grid: 1024 took 0.15 s per configs[2] step, 2048 0.10 s, 3072 (three waves per SIMD) 0.08 s, 4096 (four: the kernel fits 128 registers without a spill) 12 ms less
     uint64_t pool_cap = 0;
 };
 
@@ -1069,7 +1069,7 @@ __device__ bool connect_one(const CArgs& a, Search& S, uint32_t gi, uint32_t wid
 // sixty-four walks of a wave diverge freely (each is a handful of dependent look-ups, so there
 // is little to lose and a factor of tens in gaps in flight to gain).  What does not fit, or
 // finds paths to enumerate, goes on the list for phase 2.
-__global__ __launch_bounds__(64) void sealer_connect_lanes(CArgs a, SmallArena* arenas)
+__global__ __launch_bounds__(64, 4) void sealer_connect_lanes(CArgs a, SmallArena* arenas)
 {
     const uint32_t lane = threadIdx.x;
     const uint32_t n_work = a.queue[0];
@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(64) void sealer_connect_lanes(CArgs a, SmallArena* 
 // Phase 2: one gap per wave, lane 0 walking: whatever phase 1 left.  Launched twice: tier 0, every
 // worker with a medium arena over phase 1's list (what outgrows it goes to a second list); tier 1,
 // a few workers with full arenas over that list.
-__global__ __launch_bounds__(64) void sealer_connect(CArgs a)
+__global__ __launch_bounds__(64, 4) void sealer_connect(CArgs a)
 {
     __shared__ Search S;
     __shared__ uint8_t r1[64], r2[64], tmp[kPathCap + 64];
