@@ -965,7 +965,8 @@ __global__ __launch_bounds__(kWalkThreads, 6) void ntedit_site_eval(WalkArgs a, 
     const uint32_t tid = threadIdx.x;
     // the tile tables are per 4096-position tile (kMatTile); this kernel cuts them in 16
     const uint32_t unit = xcd_contiguous(blockIdx.x, gridDim.x); // a contig's tiles probe one filter: one XCD, one L2
-    const uint32_t big = unit / (kMatTile / kEvalTile), sub = unit % (kMatTile / kEvalTile);
+    const uint32_t eval_tile = blockDim.x; // positions per workgroup = its threads (256, or 128: see stage_b_pass)
+    const uint32_t big = unit / (kMatTile / eval_tile), sub = unit % (kMatTile / eval_tile);
     const uint32_t cid = tile_contig[big];
     if (a.dropped[cid])
         return;
@@ -973,7 +974,7 @@ __global__ __launch_bounds__(kWalkThreads, 6) void ntedit_site_eval(WalkArgs a, 
     const uint32_t k = a.k, jump = a.jump;
     if (len < a.min_contig_len || len < 2 * k)
         return;
-    const uint32_t p0 = (big - tile_first[cid]) * kMatTile + sub * kEvalTile;
+    const uint32_t p0 = (big - tile_first[cid]) * kMatTile + sub * eval_tile;
     if (p0 + k > len)
         return;
     const uint64_t base_bit = a.off[cid];
@@ -1148,8 +1149,8 @@ __global__ __launch_bounds__(kWalkThreads, 6) void ntedit_site_eval(WalkArgs a, 
             __syncthreads();
         }
         {
-            const uint32_t si = tid >> 6, q = tid & 63;
-            if (si < S.n_sub) {
+            const uint32_t q = tid & 63;
+            for (uint32_t si = tid >> 6; si < S.n_sub; si += blockDim.x / 64) { // (a wave per substitute; two waves take two turns)
                 const uint8_t sb = S.subs[si];
                 if (q == 63) {
                     uint64_t fh = S.fh, rh = S.rh;
@@ -3210,7 +3211,11 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     if (a.site_rec) {
         // 1b. what the trials decide at every confirmed site of the untouched contigs
         GP_HIP(hipMemsetAsync(b->site_rec.p, 0, b->site_rec.n * sizeof(uint4), s));
-        hipLaunchKernelGGL(ntedit_site_eval, dim3(b->n_tiles * (kMatTile / kEvalTile)), dim3(kWalkThreads), 0, s,
+        // (128-thread workgroups: a site's full trials take the whole workgroup, one site after the
+        // other, so more and smaller workgroups wait less -- 82.6 -> 77.0 ms of scan + evaluation per
+        // configs[2] step; k <= 56 so that a site's window fits; GP_EVAL_THREADS=256 for the old shape)
+        const unsigned eval_threads = env_u64("GP_EVAL_THREADS", 128) == 128 && a.k <= 56 ? 128u : (unsigned)kEvalTile;
+        hipLaunchKernelGGL(ntedit_site_eval, dim3(b->n_tiles * (kMatTile / eval_threads)), dim3(eval_threads), 0, s,
                            a, (const uint32_t*)b->tile_contig.p, (const uint32_t*)b->tile_first.p);
         GP_HIP(hipGetLastError());
     }

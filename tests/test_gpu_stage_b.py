@@ -23,6 +23,8 @@ def walk_mode(request, monkeypatch):
     if "128-thread" in request.param:
         monkeypatch.setenv("GP_WALK_WAVES", "4")
         monkeypatch.setenv("GP_WALK_THREADS", "128")
+    else:
+        monkeypatch.setenv("GP_EVAL_THREADS", "256")   # (ntedit_site_eval: 128-thread workgroups are its default)
     return request.param
 
 
