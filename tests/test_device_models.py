@@ -10,7 +10,12 @@ agree on random inputs -- the argument the kernel's comment makes, executed.
 3. `census_scatter`'s ring (stage_a.hip): records staged in eight (sixteen) LDS slots per range and
    written in groups of four (eight), against storing every record at its slot.
 4. `census_mark` / `census_pack`: marked records packed into the head of their run and read back up
-   to the first record without the mark, against a flag per touch."""
+   to the first record without the mark, against a flag per touch.
+5. `mod_5_pow2` (gp_device.h): x mod (5 * 2^s) by folding 16- and 8-bit pieces (2^16 and 2^8 are 1
+   modulo 5) and t / 5 = (t * 205) >> 10, against Python's %; and the extension hashes 1..3 from ONE
+   multiply (census_scatter): base * (i ^ M) = base * M + d_i * base with d_i = ((M & 3) ^ i) - (M & 3).
+6. `census_scatter`'s range word: a record's rank (low half) and the range's window base (high half)
+   from one atomic add, against a counter and a base kept apart."""
 import json
 import pathlib
 
@@ -263,3 +268,74 @@ def test_marked_records_packed_into_the_run_head():
                 break
             got.append(r & ~(1 << 31))
         assert got == [r for r, m in zip(recs, later) if m]
+
+
+# ---------------------------------------------------------------------------------- index arithmetic
+MULTISEED, MULTISHIFT = 0x90b45d39fb6da1fa, 27
+
+
+def mod_5_pow2(x, s):
+    q = x >> s
+    lo, hi = q & 0xFFFFFFFF, q >> 32
+    t2 = (lo & 0xFFFF) + (lo >> 16) + (hi & 0xFFFF) + (hi >> 16)
+    assert t2 < 1 << 18
+    t3 = (t2 & 0xFF) + ((t2 >> 8) & 0xFF) + (t2 >> 16)
+    assert t3 < 1024                                  # where (t * 205) >> 10 is exact
+    r5 = t3 - 5 * ((t3 * 205) >> 10)
+    return (r5 << s) | (x & ((1 << s) - 1))
+
+
+def test_fold_modulo_five_times_a_power_of_two():
+    rng = np.random.default_rng(17)
+    for t in range(1024):
+        assert (t * 205) >> 10 == t // 5
+    for s in list(range(0, 32)):
+        xs = [0, 1, 4, 5, M64, M64 - 1, (1 << 63), (5 << s) - 1, 5 << s] + [int(v) for v in rng.integers(0, 1 << 63, size=400)]
+        xs += [int(v) | (1 << 63) for v in rng.integers(0, 1 << 63, size=100)]
+        for x in xs:
+            assert mod_5_pow2(x & M64, s) == (x & M64) % (5 << s), (x, s)
+
+
+def test_extension_hashes_from_one_multiply():
+    rng = np.random.default_rng(19)
+    for k in range(1, 64):
+        m = (k * MULTISEED) & M64
+        m2 = m & 3
+        for base in [0, 1, M64] + [int(v) for v in rng.integers(0, 1 << 63, size=40)]:
+            bm = (base * m) & M64
+            for i in (1, 2, 3):
+                d = (m2 ^ i) - m2
+                want = (base * (i ^ m)) & M64                     # btllib's multi-hash: base * (i ^ k * seed)
+                got = (bm + d * base) & M64
+                assert got == want, (k, i, base)
+                want_h = want ^ (want >> MULTISHIFT)
+                assert (got ^ (got >> MULTISHIFT)) == want_h
+        if k % 2 == 0:                                            # even k: the seed is even, so M & 3 == 0 and d = 1, 2, 3
+            assert m2 == 0
+
+
+def test_rank_and_window_base_share_a_word():
+    """hist word = records so far | (groups flushed << 16): what the scatter's atomicAdd returns tells a
+    record its rank AND whether its slot is in the ring's window, as two separate variables would"""
+    rng = np.random.default_rng(23)
+    for run, ring_n in GEOMETRIES:
+        G = ring_n // 2
+        for _ in range(500):
+            word, cnt, gbase = 0, 0, 0
+            for _round in range(8):
+                for _ in range(int(rng.poisson(6.4))):
+                    old = word
+                    word += 1                                     # the atomic add
+                    rank, g = old & 0xFFFF, old >> 16
+                    assert (rank, g) == (cnt, gbase)
+                    cnt += 1
+                # the flush: only the high half changes, the count stays
+                c = min(word & 0xFFFF, run)
+                g0 = word >> 16
+                if c > G * g0 + ring_n:
+                    g_next = (c + G - 1) // G
+                else:
+                    g_next = g0 + ((c - G * g0) // G if c > G * g0 else 0)
+                word = (word & 0xFFFF) | (g_next << 16)
+                gbase = g_next
+                assert word & 0xFFFF == cnt and g_next <= (run + G - 1) // G + 1
