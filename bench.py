@@ -156,7 +156,9 @@ def pmc_traffic(workload, kernel):
 
 
 def pmc_traffic_census(workload):
-    """the same for the three census kernels in front of a cbf_local launch, summed per cbf_local launch"""
+    """the same for the three census kernels in front of a cbf_local launch, summed per cbf_local launch.
+    census_mark and census_pack read wide, streaming: their FETCH_SIZE is the guide's x2 case, which
+    tools/collect_profiles.py writes as FETCH_SIZE_corrected; that is what is summed where it is there."""
     for f in sorted((ROOT / "profiles").glob(f"r*_{workload}_pmc_traffic.json"), reverse=True):
         t = json.loads(f.read_text())
         loc = t.get("gp::cbf_local")
@@ -164,8 +166,9 @@ def pmc_traffic_census(workload):
             continue
         kb = 0.0
         for name in ("gp::census_scatter", "gp::census_mark", "gp::census_pack"):
-            for c in ("FETCH_SIZE", "WRITE_SIZE"):
-                kb += t.get(name, {}).get(c, {}).get("sum_KB", 0.0)
+            e = t.get(name, {})
+            kb += e.get("FETCH_SIZE_corrected", e.get("FETCH_SIZE", {})).get("sum_KB", 0.0)
+            kb += e.get("WRITE_SIZE", {}).get("sum_KB", 0.0)
         return int(kb * 1024 / max(loc["FETCH_SIZE"]["launches"], 1))
     return None
 
@@ -179,6 +182,8 @@ def gather_to_rank0(lens, payload, rank, world):
     meta = torch.tensor([payload.numel(), lens.numel()], dtype=torch.int64, device=lens.device)
     metas = [torch.zeros_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta)
+    # (nothing of zero length is sent or received: a rank with no batches, or whose records were all
+    # dropped, takes part in the all-gather of sizes only -- both sides know that from `metas`)
     if rank == 0:
         out = [(lens, payload)]
         reqs = []
@@ -186,12 +191,19 @@ def gather_to_rank0(lens, payload, rank, world):
             nb, nl = int(metas[r][0]), int(metas[r][1])
             b = torch.empty(nb, dtype=torch.uint8, device=lens.device)
             l = torch.empty(nl, dtype=torch.int64, device=lens.device)
-            reqs += [dist.irecv(l, src=r), dist.irecv(b, src=r)]
+            if nl:
+                reqs.append(dist.irecv(l, src=r))
+            if nb:
+                reqs.append(dist.irecv(b, src=r))
             out.append((l, b))
         for q in reqs:
             q.wait()
         return out
-    reqs = [dist.isend(lens, dst=0), dist.isend(payload, dst=0)]
+    reqs = []
+    if lens.numel():
+        reqs.append(dist.isend(lens, dst=0))
+    if payload.numel():
+        reqs.append(dist.isend(payload, dst=0))
     for q in reqs:
         q.wait()
     return None
@@ -223,13 +235,34 @@ def input_order(rank_of, per_rank_records):
     return out
 
 
-def cpu_baseline(w, ks, desc, gpu_out=None):
+def host_cores():
+    """(hardware threads this process may use, physical cores of the box, hardware threads of the box)"""
+    seen = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    phys = set()
+    try:
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                pid = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                cid = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    return seen, (len(phys) or None), (os.cpu_count() or seen)
+
+
+def cpu_baseline(w, ks, desc, gpu_out=None, sample=None, threads=None, label="a GPU's share of the host"):
     """The oracle (a C port of the reference path, oracle/) timed on this box's host cores on
-    a bounded sample of the SAME workload: its first contigs, batches in parallel over every
-    core the process may use -- one OpenMP task per batch, each batch serial, which is how the
-    reference spreads batches over threads (goldpolish_targeted_bfs.cpp:189-246,
-    scripts/goldpolish:496-514).  The reference itself cannot be built on this box (btllib,
-    boost); its per-batch process / Python / file overhead is NOT in this number."""
+    a bounded sample of the SAME workload, batches in parallel -- one OpenMP task per batch, each
+    batch serial, which is how the reference spreads batches over threads
+    (goldpolish_targeted_bfs.cpp:189-246, scripts/goldpolish:496-514).  The reference itself
+    cannot be built on this box (btllib, boost); its per-batch process / Python / file overhead is
+    NOT in this number.  `sample`: batch indices (default: the first 30 per thread); `threads`:
+    default a GPU's share of the node, 16 (GP_BENCH_CPU_THREADS overrides)."""
     sys.path.insert(0, str(ROOT / "tests"))
     import subprocess
     import oracle_lib
@@ -237,17 +270,19 @@ def cpu_baseline(w, ks, desc, gpu_out=None):
     if not so.exists():
         subprocess.check_call(["make", "-C", str(ROOT / "oracle"), "libgpo.so"])
     O = oracle_lib.Oracle(str(so))
-    # A GPU box hands one GPU's job 16 host cores (the node shows all of them: 256 threads on
-    # the whole job made it slower per thread, 0.43 Mbp/s in 230 s); GP_BENCH_CPU_THREADS overrides.
-    seen = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = int(os.environ.get("GP_BENCH_CPU_THREADS", "0")) or min(seen, 16)
+    # A GPU box hands one GPU's job 16 host cores (the node shows all of them)
+    seen, physical, logical = host_cores()
+    cores = threads or int(os.environ.get("GP_BENCH_CPU_THREADS", "0")) or min(seen, 16)
     # about 15 s: a 25 kbp batch of the full cascade costs one core about half a second, a
     # single long contig (one batch: no batch parallelism to be had) is taken whole
-    n = w.n_contigs if w.n_contigs <= 4 else min(w.n_contigs, 30 * cores)
-    names = w.names[:n]
-    seqs = [w.contig(i) for i in range(n)]
-    reads = [w.reads_of(i) for i in range(n)]
-    thr = [int(x) for x in w.kmer_threshold[:n]]
+    if sample is None:
+        n = w.n_contigs if w.n_contigs <= 4 else min(w.n_contigs, 30 * cores)
+        sample = list(range(n))
+    n = len(sample)
+    names = [w.names[i] for i in sample]
+    seqs = [w.contig(i) for i in sample]
+    reads = [w.reads_of(i) for i in sample]
+    thr = [int(w.kmer_threshold[i]) for i in sample]
     params = O.batch_params(k_values=tuple(ks))
     t = time.perf_counter()
     outs, used = O.polish_batches(names, seqs, reads, thr, list(range(n + 1)), params, n_threads=cores)
@@ -258,17 +293,97 @@ def cpu_baseline(w, ks, desc, gpu_out=None):
         # the oracle's output for the sample is there anyway: the device path's polished records
         # for the same batches, from the timed job, must be the same bytes (parity at the bench's
         # full size, not only in tests/)
-        bad = [i for i in range(n) if gpu_out[i] != outs[i]]
+        bad = [i for j, i in enumerate(sample) if gpu_out[i] != outs[j]]
         if bad:
             raise SystemExit(f"bench.py: {len(bad)} of the {n} sampled batches differ from the oracle (first: {w.names[bad[0]]})")
         parity = {"batches_compared_with_the_oracle": n, "identical": True}
+    which = (f"the first {n}" if sample == list(range(n)) else f"{n} (the shortest that fit the time bound)")
     return {
         **({"parity_sample": parity} if parity else {}),
         "value": round(bp / dt / 1e6, 4), "unit": "Mbp/s", "cores": int(min(used, n)), "kind": "port",
-        "sample": f"the first {n} of {w.n_contigs} batches of this workload ({bp} bp + their reads), whole path, "
+        "threads_used": int(min(used, n)), "threads_are": label,
+        "host": {"hardware_threads_visible": seen, "hardware_threads_of_the_box": logical, "physical_cores_of_the_box": physical},
+        "sample": f"{which} of {w.n_contigs} batches of this workload ({bp} bp + their reads), whole path, "
                   f"k={','.join(map(str, ks))}, {dt:.1f} s: the C oracle, one OpenMP task per batch on "
                   f"{used} threads",
     }
+
+
+def cpu_sample_by_cost(w, cores, sec_per_mbp, budget_s):
+    """batch indices for a CPU sample of about budget_s seconds on `cores` threads: the shortest
+    batches first, each thread given about budget_s of work (a long contig is one serial batch:
+    the sample's wall time is its longest batch)"""
+    lens = np.diff(np.asarray(w.contig_off, dtype=np.int64))
+    order = np.argsort(lens, kind="stable")
+    pick, load = [], 0.0
+    for i in order:
+        cost = float(lens[i]) / 1e6 * sec_per_mbp
+        if pick and (cost > budget_s or load + cost > budget_s * cores):
+            break
+        pick.append(int(i))
+        load += cost
+    return sorted(pick)
+
+
+def read_selection_cost(w):
+    """What read ranking (gp_rank_reads: truncated phred descending, id ascending, the first
+    size_t(len * s / 1e4)) would add to a step of this workload: timed here, on one host core, over every
+    contig's reads with synthetic ids and phreds.  It is outside the timed region (the workload is born
+    selected); SURVEY 8d's region starts at "reads + mappings resident", so the figure is given."""
+    from goldpolish_amd import core
+    rng = np.random.default_rng(1)
+    crb = np.asarray(w.contig_read_begin, dtype=np.int64)
+    roff = np.asarray(w.read_off, dtype=np.int64)
+    lens_c = np.diff(np.asarray(w.contig_off, dtype=np.int64))
+    n_c = min(w.n_contigs, 400)
+    t = time.perf_counter()
+    n_reads = 0
+    for c in range(n_c):
+        a, b = int(crb[c]), int(crb[c + 1])
+        ids = [b"r%08d" % i for i in range(a, b)]
+        ph = rng.uniform(7, 20, b - a)
+        core.rank_reads(ids, ph, np.diff(roff[a:b + 1]), int(lens_c[c]), 40.0)
+        n_reads += b - a
+    dt = time.perf_counter() - t
+    scale = w.n_contigs / max(n_c, 1)
+    return {"in_timed_region": False, "gp_rank_reads_ms_per_step_one_core": round(dt * 1e3 * scale, 1),
+            "measured_on": f"{n_c} of {w.n_contigs} contigs ({n_reads} reads) through the Python binding, scaled"}
+
+
+def dry_run(world):
+    """Per rank of `bench.py --gpus world`: contigs, bases, and the bytes it will hold -- host pageable
+    (the generated workload), host pinned (staging chunks, result buffers, rank 0's gather buffers) and
+    device (two sets of inputs in flight, one set of work buffers) -- from the assembly's lengths alone:
+    no GPU, no reads generated.  The device model is checked against what one rank's share measured
+    on one MI355X (137 GiB for 375 Mbp in 15000 batches at 30x: DESIGN 6)."""
+    from goldpolish_amd import core
+    seed, cov, n_k = 4, 30, 4
+    rng = np.random.default_rng(seed)
+    per_gpu = int(os.environ.get("GP_BENCH_NODE_CONTIGS", "15000"))
+    lens = np.clip(rng.lognormal(np.log(22_000.0), 0.5, size=per_gpu * world), 5_000, 100_000).astype(np.int64)
+    cost = (lens * (1 + cov)).astype(np.uint64)
+    rank_of, load = core.partition_batches(cost, world)
+    rank_of = np.asarray(rank_of)
+    ranks = []
+    for r in range(world):
+        mine = lens[rank_of == r]
+        bp, nb = int(mine.sum()), int(mine.size)
+        reads = bp * cov + bp * cov // 15000            # + one separator per read of about 15 kb
+        inputs = reads + bp
+        dev = (2 * inputs                                # two sets in flight (upload beside polish)
+               + nb * n_k * (512 << 10)                  # Bloom filters, results of stage A
+               + min(nb * n_k, 512) * (10 << 20)         # counting-filter arena
+               + (16 << 30) + (1 << 30)                  # census record slots, settled tables
+               + 150 * bp                                # stage B/C per-base state (two sequence slots of 1.5 x, node lists, bitmaps, 16-byte site records, Sealer's gap tables): fitted to 59 GiB for configs[2]
+               + int(7.3 * 2**30))                       # Sealer arenas (read-length contigs)
+        pinned = 2 * 2 * (64 << 20) + 2 * int(bp * 1.02) + (int(1.1 * bp * (world - 1)) if r == 0 and world > 1 else 0)
+        ranks.append({"rank": r, "batches": nb, "contig_bp": bp, "host_pageable_bytes": inputs + 16 * (reads // 15000 + nb),
+                      "host_pinned_bytes": pinned, "device_bytes": dev})
+    return {"dry_run": True, "n_gpus": world, "assembly_bp": int(lens.sum()), "batches": int(lens.size),
+            "partition_load_min_max": [int(min(load)), int(max(load))], "ranks": ranks,
+            "host_total_GiB": round(sum(x["host_pageable_bytes"] + x["host_pinned_bytes"] for x in ranks) / 2**30, 1),
+            "device_GiB_per_rank_max": round(max(x["device_bytes"] for x in ranks) / 2**30, 1),
+            "notes": "generation forks a pool of workers per rank (each holds one chunk of contigs); HBM per MI355X: 288 GB"}
 
 
 class _DevView:
@@ -290,6 +405,11 @@ def main():
     ap.add_argument("--jobs-per-gpu", type=int, default=1,
                     help="HBM-resident extra only: jobs the batches are cut into and kept in flight (gp_jobs_polish)")
     ap.add_argument("--no-aux", action="store_true")
+    ap.add_argument("--aux-steps", type=int, default=2,
+                    help="timed steps of the long-contig block (aux_survey3: SURVEY 8d config 3's own shape, about 10 s a step)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU, no generation of reads: print what every rank of --gpus N would hold in host "
+                         "(pageable + pinned) and device memory, then exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cache", default=os.environ.get("GP_BENCH_CACHE", ""),
                     help="directory of generated workloads (.npz): loaded when there, written when not -- a run "
@@ -325,8 +445,15 @@ def main():
         w_main, ks_main, desc_main, extra_cfg = cached(f"node_{world}_{rank}", lambda: node_share(world, rank))
     else:
         w_main, ks_main, desc_main = cached(f"{kind}_{2 + rank}", lambda: make_workload(kind, seed=2 + rank))
+    if args.dry_run:
+        print(json.dumps(dry_run(args.gpus)))
+        return
     want_aux = world == 1 and rank == 0 and not args.no_aux and kind == "config3"
     aux_in = cached("config2_2", lambda: make_workload("config2", seed=2)) if want_aux else None
+    # the regimes SURVEY 8d describes beside the headline's: its own long-contig shape of config 3, and
+    # contigs shaped like the reference's fixture (thousands of short, ragged batches)
+    aux_ragged_in = cached("ragged_2", lambda: make_workload("ragged", seed=2)) if want_aux else None
+    aux_survey_in = cached("survey3_2", lambda: make_workload("survey3", seed=2)) if want_aux and args.aux_steps > 0 else None
     if args.prepare_only:
         return
 
@@ -611,7 +738,10 @@ def main():
             "workload": desc_main,
             "timed_region": "SURVEY 8d: reads + contigs resident in host memory -> polished bytes in host memory at "
                             "rank 0, steady state: every step holds one upload (H2D, beside the polishing of the step "
-                            "before), the path, the download (D2H)" + (" and the gather on rank 0" if world > 1 else ""),
+                            "before), the path, the download (D2H)" + (" and the gather on rank 0" if world > 1 else "") +
+                            ".  NOT inside: read ranking and selection (gp_rank_reads / gp_job_create_from_files, "
+                            "serve_batch's goldpolish_targeted_bfs.cpp:96-123) -- the synthetic reads are generated per "
+                            "contig, already selected; what it would add per step is config.read_selection",
             "contigs_per_gpu": main_res["n_contigs"], "bp_per_gpu": main_res["bp_per_rank"], "bp_total": total_bp,
             "read_coverage": round(main_res["coverage"], 2), "k": ",".join(map(str, ks_main)),
             "parallelism": f"batches sharded over {world} GPU(s), one process per GPU; gp_pipeline (upload | polish | "
@@ -644,19 +774,51 @@ def main():
                     "records left packed in HBM: no PCIe in the timed region",
             "same_output_bytes": rs["output_checksum"]["bytes"] == main_res["output_checksum"]["bytes"],
         }
+    def aux_block(w_aux, ks_aux, desc_aux, name, steps, cpu_sample, note=""):
+        """one more workload through the same timed region, with a roofline and a CPU sample of its own"""
+        core.device_pool_trim()   # the blocks of the workload before are of another shape
+        aux = run_stream(w_aux, ks_aux, steps, 1)
+        blk = {
+            "workload": desc_aux + note,
+            "value": round(aux["bp_per_rank"] * aux["steps"] / aux["dt"] / 1e6, 3),
+            "unit": "Mbp/s", "ms_per_step": round(aux["dt"] / aux["steps"] * 1e3, 2), "steps": aux["steps"],
+            "stream": aux["stream"], "roofline": roofline(aux, name), "counters": aux["counters"],
+            "device_GiB_in_use": round(aux["device_bytes"] / 2**30, 1),
+        }
+        if cpu_sample is not None and not args.no_cpu_baseline:
+            blk["cpu_baseline"] = cpu_baseline(w_aux, ks_aux, desc_aux, aux.get("polished"), sample=cpu_sample)
+        return blk
+
     if want_aux:
         w_aux, ks_aux, desc_aux = aux_in
-        aux = run_stream(w_aux, ks_aux, max(1, min(args.steps, 5)), 1)
-        r = roofline(aux, "config2")
-        line["aux"] = {
-            "workload": desc_aux + " (its one pair of 10 MiB / 512 KiB filters saturates, as the "
-                        "reference's would: ntEdit and Sealer find nothing to do, the step is the filter build)",
-            "value": round(aux["bp_per_rank"] * aux["steps"] / aux["dt"] / 1e6, 3),
-            "unit": "Mbp/s", "ms_per_step": round(aux["dt"] / aux["steps"] * 1e3, 2),
-            "stream": aux["stream"], "roofline": r, "counters": aux["counters"],
-        }
+        line["aux"] = aux_block(w_aux, ks_aux, desc_aux, "config2", max(1, min(args.steps, 5)), None,
+                                " (its one pair of 10 MiB / 512 KiB filters saturates, as the reference's would: "
+                                "ntEdit and Sealer find nothing to do, the step is the filter build)")
+        del w_aux, aux_in
+        threads = int(os.environ.get("GP_BENCH_CPU_THREADS", "0")) or min(host_cores()[0], 16)
+        w_aux, ks_aux, desc_aux = aux_ragged_in
+        line["aux_ragged"] = aux_block(w_aux, ks_aux, desc_aux, "ragged", max(1, min(args.steps, 5)),
+                                       list(range(min(w_aux.n_contigs, 60 * threads))))
+        del w_aux, aux_ragged_in
+        if aux_survey_in:
+            w_aux, ks_aux, desc_aux = aux_survey_in
+            # the oracle needs about 28 s per Mbp of such a contig on one core (17 s for a 0.6 Mbp batch)
+            line["aux_survey3"] = aux_block(w_aux, ks_aux, desc_aux, "survey3", args.aux_steps,
+                                            cpu_sample_by_cost(w_aux, threads, 28.0, 25.0),
+                                            " -- the regime SURVEY 8d describes for configs 3 and 4; the fixed 10 MiB / "
+                                            "512 KiB filters (src/goldpolish_targeted_bfs.cpp:270-272) saturate on such contigs")
+            del w_aux, aux_survey_in
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(w_main, ks_main, desc_main, main_res.get("polished"))
+        seen, physical, logical = host_cores()
+        if seen > line["cpu_baseline"]["threads_used"] and w_main.n_contigs > 4:
+            # once more on every hardware thread the process may use: the whole node's CPU figure, so that
+            # the 8-GPU ratio needs no extrapolation from a 16-thread share
+            n_all = min(w_main.n_contigs, 12 * seen)
+            line["cpu_baseline_all_cores"] = cpu_baseline(w_main, ks_main, desc_main, main_res.get("polished"),
+                                                          sample=list(range(n_all)), threads=seen,
+                                                          label="every hardware thread the process may use")
+        line["config"]["read_selection"] = read_selection_cost(w_main)
     if rank == 0:
         print(json.dumps(line))
     if dist:

@@ -36,7 +36,7 @@ SYMBOLS = [
     "gp_jobs_polish", "gp_filter_save", "gp_filter_save_btllib", "gp_filter_load", "gp_job_write_fasta",
     "gp_sealer_consensus", "gp_device_pool_bytes", "gp_device_pool_trim",
     "gp_pipeline_create", "gp_pipeline_submit", "gp_pipeline_collect", "gp_pipeline_kernel_time",
-    "gp_pipeline_destroy", "gp_job_reset",
+    "gp_pipeline_destroy", "gp_job_reset", "gp_debug_fail_alloc", "gp_debug_nthash",
 ]
 
 
@@ -183,6 +183,10 @@ def load_library(path=None):
     L.gp_pipeline_kernel_time.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), u64p, u64p]
     L.gp_pipeline_destroy.argtypes = [C.c_void_p]
     L.gp_pipeline_destroy.restype = None
+    L.gp_debug_fail_alloc.argtypes = [C.c_uint64]
+    L.gp_debug_fail_alloc.restype = C.c_uint64
+    L.gp_debug_nthash.restype = C.c_int64
+    L.gp_debug_nthash.argtypes = [C.c_void_p, C.c_int, u8p, C.c_uint64, C.c_uint32, C.c_uint32, u64p, u64p, u64p, u8p]
     return L
 
 
@@ -223,6 +227,29 @@ def device_pool_bytes() -> int:
 
 def device_pool_trim():
     lib().gp_device_pool_trim()
+
+
+def debug_fail_alloc(nth: int):
+    """the n-th device allocation from now on fails (0: off) -- tests of the out-of-memory paths;
+    returns the number of device allocations made so far"""
+    return int(lib().gp_debug_fail_alloc(int(nth)))
+
+
+def debug_nthash(ctx, variant, seq: bytes, k, hash_num=4):
+    """The kernels' own ntHash over one sequence (include/gpcore.h: gp_debug_nthash):
+    (fwd[n], rev[n], hashes[n, hash_num], valid[n]) as numpy arrays."""
+    buf = np.frombuffer(seq, dtype=np.uint8).copy()
+    n_max = max(len(seq), 8)
+    f = np.zeros(n_max, dtype=np.uint64)
+    r = np.zeros(n_max, dtype=np.uint64)
+    h = np.zeros(n_max * hash_num, dtype=np.uint64)
+    v = np.zeros(n_max, dtype=np.uint8)
+    n = lib().gp_debug_nthash(ctx._h, int(variant), buf.ctypes.data_as(u8p), buf.size, int(k), int(hash_num),
+                              f.ctypes.data_as(u64p), r.ctypes.data_as(u64p), h.ctypes.data_as(u64p),
+                              v.ctypes.data_as(u8p))
+    if n < 0:
+        _check(int(n))
+    return f[:n], r[:n], h[:n * hash_num].reshape(n, hash_num), v[:n]
 
 
 def kmer_threshold(bases: int) -> int:

@@ -26,64 +26,103 @@ void track_device_bytes(long long delta) { g_device_bytes += delta; }
 void set_error(const std::string& msg) { g_err = msg; }
 
 // ---- device memory pool (see gp_internal.h) ---------------------------------------------------
-// Free blocks per device, keyed by size.  A request takes the smallest free block that holds it
-// and is at most an eighth larger; otherwise hipMalloc (after which, on failure, the pool is
-// emptied and hipMalloc tried once more).  What the pool may hold is capped (GP_POOL_GIB, default
-// 200; 0 turns pooling off): beyond it the largest free blocks go back to the driver.
+// Free blocks PER DEVICE, keyed by size.  A request takes the smallest free block that holds it
+// and is at most an eighth larger; otherwise hipMalloc (after which, on failure, that device's
+// pool is emptied and hipMalloc tried once more).  What a device's pool may hold is capped by the
+// most this library has ever had in use on that device at one time (a stream of equal jobs
+// recycles one job's worth of blocks; nothing more is worth keeping) and by GP_POOL_GIB (default
+// 200; 0 turns pooling off); beyond the cap the largest free blocks go back to the driver.  The
+// pool of a device is emptied when the last context on it is destroyed and by
+// gp_device_pool_trim(): other allocators in the process (torch's, RCCL's) cannot make this
+// library give memory back, so a caller that mixes them in trims at its own quiet points.
 namespace {
+constexpr int kMaxDev = 16;
 struct DevPool {
     std::mutex mu;
-    std::multimap<size_t, void*> free_blocks[16];
+    std::multimap<size_t, void*> free_blocks;
     size_t pooled = 0;
+    size_t in_use = 0, high_water = 0;
+    int contexts = 0;
 };
-DevPool g_pool;
+DevPool g_pool[kMaxDev];
 std::atomic<long long> g_pool_bytes{0};
+std::atomic<long long> g_fail_countdown{0};
+std::atomic<unsigned long long> g_alloc_calls{0};
 
-size_t pool_cap()
+size_t pool_cap_env()
 {
     static const size_t cap = (size_t)env_u64("GP_POOL_GIB", 200) << 30;
     return cap;
 }
 
-void pool_trim_locked(size_t keep)
+size_t pool_cap_locked(const DevPool& P) { return std::min(pool_cap_env(), P.high_water); }
+
+void pool_trim_locked(DevPool& P, size_t keep)
 {
-    for (auto& m : g_pool.free_blocks)
-        while (!m.empty() && g_pool.pooled > keep) {
-            auto it = std::prev(m.end());
-            (void)hipFree(it->second);
-            g_pool.pooled -= it->first;
-            m.erase(it);
-        }
-    g_pool_bytes = (long long)g_pool.pooled;
+    while (!P.free_blocks.empty() && P.pooled > keep) {
+        auto it = std::prev(P.free_blocks.end());
+        (void)hipFree(it->second);
+        P.pooled -= it->first;
+        g_pool_bytes -= (long long)it->first;
+        P.free_blocks.erase(it);
+    }
 }
 } // namespace
+
+void pool_context_born(int dev)
+{
+    if (dev < 0 || dev >= kMaxDev)
+        return;
+    std::lock_guard<std::mutex> g(g_pool[dev].mu);
+    g_pool[dev].contexts++;
+}
+
+void pool_context_gone(int dev)
+{
+    if (dev < 0 || dev >= kMaxDev)
+        return;
+    std::lock_guard<std::mutex> g(g_pool[dev].mu);
+    if (--g_pool[dev].contexts <= 0) {
+        g_pool[dev].contexts = 0;
+        pool_trim_locked(g_pool[dev], 0);
+    }
+}
 
 int dev_alloc(size_t bytes, void** out, size_t* cap_bytes)
 {
     int dev = 0;
     (void)hipGetDevice(&dev);
     bytes = (bytes + 255) & ~(size_t)255;
-    if (dev >= 0 && dev < 16 && pool_cap()) {
-        std::lock_guard<std::mutex> g(g_pool.mu);
-        auto& m = g_pool.free_blocks[dev];
-        auto it = m.lower_bound(bytes);
-        if (it != m.end() && it->first <= bytes + bytes / 8) {
+    g_alloc_calls++;
+    // test hook (gp_debug_fail_alloc): the n-th allocation from now on fails
+    if (g_fail_countdown.load() > 0 && g_fail_countdown.fetch_sub(1) == 1) {
+        set_error("hipMalloc of " + std::to_string(bytes) + " bytes failed: injected by gp_debug_fail_alloc");
+        return GP_ERR_OOM;
+    }
+    const bool pooled_dev = dev >= 0 && dev < kMaxDev && pool_cap_env();
+    if (pooled_dev) {
+        DevPool& P = g_pool[dev];
+        std::lock_guard<std::mutex> g(P.mu);
+        auto it = P.free_blocks.lower_bound(bytes);
+        if (it != P.free_blocks.end() && it->first <= bytes + bytes / 8) {
             *out = it->second;
             *cap_bytes = it->first;
-            g_pool.pooled -= it->first;
-            g_pool_bytes = (long long)g_pool.pooled;
-            m.erase(it);
+            P.pooled -= it->first;
+            g_pool_bytes -= (long long)it->first;
+            P.free_blocks.erase(it);
+            P.in_use += *cap_bytes;
+            P.high_water = std::max(P.high_water, P.in_use);
             track_device_bytes((long long)*cap_bytes);
             return GP_OK;
         }
     }
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, bytes);
-    if (e != hipSuccess) {
+    if (e != hipSuccess && pooled_dev) {
         (void)hipGetLastError();
         {
-            std::lock_guard<std::mutex> g(g_pool.mu);
-            pool_trim_locked(0);
+            std::lock_guard<std::mutex> g(g_pool[dev].mu);
+            pool_trim_locked(g_pool[dev], 0);
         }
         e = hipMalloc(&q, bytes);
     }
@@ -94,6 +133,11 @@ int dev_alloc(size_t bytes, void** out, size_t* cap_bytes)
     }
     *out = q;
     *cap_bytes = bytes;
+    if (dev >= 0 && dev < kMaxDev) {
+        std::lock_guard<std::mutex> g(g_pool[dev].mu);
+        g_pool[dev].in_use += bytes;
+        g_pool[dev].high_water = std::max(g_pool[dev].high_water, g_pool[dev].in_use);
+    }
     track_device_bytes((long long)bytes);
     return GP_OK;
 }
@@ -105,18 +149,23 @@ void dev_free(void* q, size_t cap_bytes)
     track_device_bytes(-(long long)cap_bytes);
     hipPointerAttribute_t attr{};
     int dev = -1;
-    if (pool_cap() && hipPointerGetAttributes(&attr, q) == hipSuccess)
+    if (hipPointerGetAttributes(&attr, q) == hipSuccess)
         dev = attr.device;
     else
         (void)hipGetLastError();
-    if (dev >= 0 && dev < 16 && cap_bytes <= pool_cap()) {
-        std::lock_guard<std::mutex> g(g_pool.mu);
-        g_pool.free_blocks[dev].emplace(cap_bytes, q);
-        g_pool.pooled += cap_bytes;
-        if (g_pool.pooled > pool_cap())
-            pool_trim_locked(pool_cap());
-        g_pool_bytes = (long long)g_pool.pooled;
-        return;
+    if (dev >= 0 && dev < kMaxDev) {
+        DevPool& P = g_pool[dev];
+        std::lock_guard<std::mutex> g(P.mu);
+        P.in_use -= std::min(P.in_use, cap_bytes);
+        const size_t cap = pool_cap_locked(P);
+        if (cap && cap_bytes <= cap && P.contexts > 0) {
+            P.free_blocks.emplace(cap_bytes, q);
+            P.pooled += cap_bytes;
+            g_pool_bytes += (long long)cap_bytes;
+            if (P.pooled > cap)
+                pool_trim_locked(P, cap);
+            return;
+        }
     }
     (void)hipFree(q);
 }
@@ -170,11 +219,56 @@ uint64_t gp_device_pool_bytes(void)
     return v > 0 ? (uint64_t)v : 0;
 }
 
+uint64_t gp_debug_fail_alloc(uint64_t nth)
+{
+    g_fail_countdown = (long long)nth;
+    return g_alloc_calls.load();
+}
+
+int64_t gp_debug_nthash(gp_ctx* ctx, int variant, const uint8_t* seq, uint64_t len, uint32_t k, uint32_t hash_num,
+                        uint64_t* out_fwd, uint64_t* out_rev, uint64_t* out_hashes, uint8_t* valid)
+try {
+    if (!ctx || !seq || !out_fwd || !out_rev || !out_hashes || !valid || k < 4 || k > 63 || hash_num == 0 ||
+        hash_num > (uint32_t)kMaxHash || variant < 0 || variant > 4) {
+        set_error("gp_debug_nthash: bad argument (k must be 4..63, hash_num 1..8, variant 0..4)");
+        return GP_ERR_INVALID_ARG;
+    }
+    if (len < k)
+        return 0;
+    GP_HIP(hipSetDevice(ctx->device));
+    const uint64_t n = variant == 4 ? 7 : len - k + 1;
+    DevBuf<uint8_t> d_seq, d_valid;
+    DevBuf<uint64_t> d_f, d_r, d_h;
+    int rc;
+    if ((rc = d_seq.alloc(len + 64)) != GP_OK || (rc = d_valid.alloc(len + 8)) != GP_OK || (rc = d_f.alloc(len + 8)) != GP_OK ||
+        (rc = d_r.alloc(len + 8)) != GP_OK || (rc = d_h.alloc((len + 8) * hash_num)) != GP_OK)
+        return rc;
+    hipStream_t s = ctx->stream;
+    GP_HIP(hipMemcpyAsync(d_seq.p, seq, len, hipMemcpyHostToDevice, s));
+    GP_HIP(hipMemsetAsync(d_valid.p, 0, len, s));
+    if (variant <= 1)
+        rc = debug_nthash_stage_a(s, d_seq.p, len, k, hash_num, variant, d_f.p, d_r.p, d_h.p, d_valid.p);
+    else if (variant == 3)
+        rc = debug_nthash_stage_c(s, d_seq.p, len, k, hash_num, d_f.p, d_r.p, d_h.p, d_valid.p);
+    else
+        rc = debug_nthash_stage_b(s, d_seq.p, len, k, hash_num, variant, d_f.p, d_r.p, d_h.p, d_valid.p);
+    if (rc != GP_OK)
+        return rc;
+    GP_HIP(hipMemcpyAsync(out_fwd, d_f.p, n * 8, hipMemcpyDeviceToHost, s));
+    GP_HIP(hipMemcpyAsync(out_rev, d_r.p, n * 8, hipMemcpyDeviceToHost, s));
+    GP_HIP(hipMemcpyAsync(out_hashes, d_h.p, n * 8 * hash_num, hipMemcpyDeviceToHost, s));
+    GP_HIP(hipMemcpyAsync(valid, d_valid.p, n, hipMemcpyDeviceToHost, s));
+    GP_HIP(hipStreamSynchronize(s));
+    return (int64_t)n;
+} GP_CATCH("gp_debug_nthash")
+
 void gp_device_pool_trim(void)
 {
     try {
-        std::lock_guard<std::mutex> g(g_pool.mu);
-        pool_trim_locked(0);
+        for (DevPool& P : g_pool) {
+            std::lock_guard<std::mutex> g(P.mu);
+            pool_trim_locked(P, 0);
+        }
     } catch (...) {
     }
 }
@@ -234,6 +328,7 @@ try {
         delete c;
         return GP_ERR_HIP;
     }
+    pool_context_born(device);
     *out = c;
     return GP_OK;
 } GP_CATCH("gp_ctx_create")
@@ -251,6 +346,7 @@ void gp_ctx_destroy(gp_ctx* ctx)
     }
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
+    pool_context_gone(ctx->device); // the last context on a device takes its pool along
     delete ctx;
 }
 
@@ -872,11 +968,13 @@ try {
                 // thread waits for ever
                 int r;
                 try {
-                    r = ensure_work(jobs[i], "gp_jobs_polish");
-                    if (r == GP_OK && hipSetDevice(jobs[i]->ctx->device) != hipSuccess) {
+                    // a new thread's current device is 0: the job's device first, then the lazy
+                    // allocations of ensure_work (dev_alloc allocates on the current device)
+                    if (hipSetDevice(jobs[i]->ctx->device) != hipSuccess) {
                         set_error("gp_jobs_polish: hipSetDevice failed");
                         r = GP_ERR_HIP;
-                    }
+                    } else
+                        r = ensure_work(jobs[i], "gp_jobs_polish");
                     if (r == GP_OK) {
                         jobs[i]->ctx->stream = front_stream;
                         r = stage_a_run(jobs[i]); // returns with the filters complete (both its streams drained)

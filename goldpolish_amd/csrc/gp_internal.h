@@ -202,6 +202,13 @@ int stage_c_run(gp_job* job);
 int stage_upper(gp_job* job);
 int sealer_consensus_sets(gp_ctx* ctx, uint32_t n_sets, const uint32_t* set_seq_begin, const uint8_t* seq_buf,
                           const uint64_t* seq_off, uint8_t* out_buf, uint64_t out_stride, uint32_t* out_len);
+// gp_debug_nthash: the hashing of each stage's kernels over one sequence (device pointers)
+int debug_nthash_stage_a(hipStream_t s, const uint8_t* d_seq, uint64_t len, uint32_t k, uint32_t hash_num, int variant,
+                         uint64_t* d_f, uint64_t* d_r, uint64_t* d_h, uint8_t* d_valid);
+int debug_nthash_stage_b(hipStream_t s, const uint8_t* d_seq, uint64_t len, uint32_t k, uint32_t hash_num, int variant,
+                         uint64_t* d_f, uint64_t* d_r, uint64_t* d_h, uint8_t* d_valid);
+int debug_nthash_stage_c(hipStream_t s, const uint8_t* d_seq, uint64_t len, uint32_t k, uint32_t hash_num,
+                         uint64_t* d_f, uint64_t* d_r, uint64_t* d_h, uint8_t* d_valid);
 int stage_lengths(gp_job* job, uint64_t* lengths, uint8_t* dropped, uint64_t* total);
 int stage_sequences(gp_job* job, uint8_t* buf, uint64_t buf_bytes);
 int stage_sequences_device(gp_job* job, void* d_buf, uint64_t buf_bytes);

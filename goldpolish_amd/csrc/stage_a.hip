@@ -422,6 +422,94 @@ __global__ __launch_bounds__(kBlock) void cbf_first_pass(AArgs a)
         atomicAdd(&a.stats[threadIdx.x], s_stats[threadIdx.x]);
 }
 
+// gp_debug_nthash, variants 0 and 1: the hashing of the stage-A kernels over one sequence, by the same
+// primitives in the same arrangement -- a lane starts its run of kPerThread positions from the table of
+// rotated seeds (kmer_hash_from_table) and rolls from there; variant 0 rolls and extends the way
+// cbf_first_pass / cbf_local do (select chains, ext_hash), variant 1 the way census_scatter does (the
+// roll tables in LDS, hashes 1-3 from one multiply: ExtHash3).  tests/test_gpu_nthash.py compares
+// them with the known answers made from the reference's own header (tests/golden/nthash_kat.json).
+__global__ __launch_bounds__(kBlock) void debug_nthash_a(const uint8_t* seq, uint64_t len, KConsts kc, uint32_t hash_num,
+                                                         int variant, uint64_t* out_f, uint64_t* out_r,
+                                                         uint64_t* out_h, uint8_t* valid)
+{
+    __shared__ uint8_t codes[kTile + kHalo];
+    __shared__ uint64_t seed_t[kSeedTableWords];
+    __shared__ ulonglong2 roll_in[8], roll_out[8];
+    const uint32_t k = kc.k;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kTile;
+    fill_seed_table(seed_t);
+    if (threadIdx.x < 8) {
+        const uint32_t cd = threadIdx.x;
+        roll_in[cd] = cd < 4 ? make_ulonglong2(seed_of_code(cd), kc.in_rev[cd]) : make_ulonglong2(0, 0);
+        roll_out[cd] = cd < 4 ? make_ulonglong2(kc.out_fwd[cd], seed_of_code(cd ^ 2)) : make_ulonglong2(0, 0);
+    }
+    for (int i = threadIdx.x; i < kTile + kHalo; i += kBlock) {
+        const uint64_t p = tile0 + i;
+        codes[i] = base_code(p < len ? seq[p] : (uint8_t)'\n');
+    }
+    __syncthreads();
+    const int t0 = threadIdx.x * kPerThread;
+    const ExtHash3 eh = make_ext_hash3(k);
+    const uint64_t ext_m = (uint64_t)k * kMultiSeed;
+    uint64_t fh = 0, rh = 0;
+    int last_bad = -1;
+    if (tile0 + t0 + k <= len)
+        kmer_hash_from_table(seed_t, codes + t0, k, fh, rh, last_bad);
+    for (int j = 0; j < kPerThread; j++) {
+        const uint64_t pos = tile0 + t0 + j;
+        if (pos + k > len)
+            break;
+        if (j > 0) {
+            const uint32_t out = codes[t0 + j - 1], in = codes[t0 + j + k - 1];
+            if (variant == 0) {
+                const uint64_t s_in = in < 4 ? seed_of_code(in) : 0ULL;
+                const uint64_t s_outk = out < 4 ? kc.out_fwd[out] : 0ULL;
+                const uint64_t r_ink = in < 4 ? kc.in_rev[in] : 0ULL;
+                const uint64_t r_out = out < 4 ? seed_of_code(out ^ 2) : 0ULL;
+                fh = srol1(fh) ^ s_in ^ s_outk;
+                rh = sror1(rh ^ r_ink ^ r_out);
+            } else {
+                const ulonglong2 ri = roll_in[in], ro = roll_out[out];
+                fh = srol1(fh) ^ ri.x ^ ro.x;
+                rh = sror1(rh ^ ri.y ^ ro.y);
+            }
+            if (in >= 4)
+                last_bad = j + (int)k - 1;
+        }
+        out_f[pos] = fh;
+        out_r[pos] = rh;
+        valid[pos] = last_bad < j ? 1 : 0;
+        const uint64_t base = fh + rh;
+        for (uint32_t h = 0; h < hash_num; h++) {
+            uint64_t v;
+            if (h == 0)
+                v = base;
+            else if (variant == 1 && h < 4) {
+                const uint64_t t = base * ext_m + ext_addend(base, eh.d[h]);
+                v = t ^ (t >> kMultiShift);
+            } else
+                v = ext_hash(base, k, h);
+            out_h[pos * hash_num + h] = v;
+        }
+    }
+}
+
+int debug_nthash_stage_a(hipStream_t s, const uint8_t* d_seq, uint64_t len, uint32_t k, uint32_t hash_num, int variant,
+                         uint64_t* d_f, uint64_t* d_r, uint64_t* d_h, uint8_t* d_valid)
+{
+    KConsts kc{};
+    kc.k = k;
+    for (uint32_t c = 0; c < 4; c++) {
+        kc.out_fwd[c] = sroln(seed_of_code(c), k);
+        kc.in_rev[c] = sroln(seed_of_code(c ^ 2), k);
+    }
+    const uint32_t grid = (uint32_t)((len + kTile - 1) / kTile);
+    hipLaunchKernelGGL(debug_nthash_a, dim3(grid), dim3(kBlock), 0, s, d_seq, len, kc, hash_num, variant, d_f, d_r, d_h,
+                       d_valid);
+    GP_HIP(hipGetLastError());
+    return GP_OK;
+}
+
 // Has a (batch, k) filter pair stopped changing?  Counters only matter through "is the
 // minimum >= thr-1", so once every counter is >= thr-1 (for the largest threshold any contig
 // of the batch uses) every later operation settles; once every bit of the Bloom filter is
@@ -1799,27 +1887,50 @@ int stage_a_prepare(gp_job* job)
 
 void stage_a_release(gp_job* job)
 {
+    // Idempotent: every handle is null once it is gone, so ensure_work's failure path followed by
+    // gp_job_destroy (or by a second try) destroys nothing twice; the work buffers go back too.
     if (job->h_count_pinned)
         (void)hipHostFree(job->h_count_pinned);
     job->h_count_pinned = nullptr;
-    for (uint32_t i = 0; i < kRing; i++) {
-        if (job->a_ev[i])
-            (void)hipEventDestroy(job->a_ev[i]);
-        if (job->a_ev_b[i])
-            (void)hipEventDestroy(job->a_ev_b[i]);
-    }
-    if (job->a_ev_init)
-        (void)hipEventDestroy(job->a_ev_init);
+    auto drop = [](hipEvent_t& e) {
+        if (e)
+            (void)hipEventDestroy(e);
+        e = nullptr;
+    };
+    for (hipEvent_t& e : job->a_ev)
+        drop(e);
+    for (hipEvent_t& e : job->a_ev_b)
+        drop(e);
+    drop(job->a_ev_init);
+    for (hipEvent_t& e : job->a_ev_census)
+        drop(e);
     if (job->a_stream2)
         (void)hipStreamDestroy(job->a_stream2);
     if (job->a_stream3)
         (void)hipStreamDestroy(job->a_stream3);
     job->a_stream2 = job->a_stream3 = nullptr;
-    for (hipEvent_t& e : job->a_ev_census)
-        if (e) {
-            (void)hipEventDestroy(e);
-            e = nullptr;
-        }
+    job->d_resv.release();
+    job->d_pending[0].release();
+    job->d_pending[1].release();
+    job->d_sat.release();
+    job->d_batch_thr_max.release();
+    job->d_batch_pos.release();
+    job->d_batch_order.release();
+    job->d_batch_slot.release();
+    job->d_queue.release();
+    job->d_cand.release();
+    job->d_kset.release();
+    job->d_census_cnt.release();
+    job->d_census_rec.release();
+    job->d_census_over.release();
+    job->d_census_tab32.release();
+    job->d_pair_mode.release();
+    job->d_census_tab64.release();
+    job->d_pair_bit_off.release();
+    job->d_counts.release();
+    job->d_stats.release();
+    job->d_seg_smax.release();
+    job->d_batch_seg.release();
 }
 
 int stage_a_run(gp_job* job)

@@ -2558,6 +2558,71 @@ __global__ __launch_bounds__(256) void ntedit_scan(WalkArgs a, uint32_t n_contig
     }
 }
 
+// gp_debug_nthash, variants 2 and 4: stage B's hashing over one sequence of raw bytes (HashTab with
+// fcode / rcode: IUPAC letters and N hash as the reference's seed tables have them, nthash.hpp:14-46).
+// Variant 2: a lane starts four positions from scratch (hash_kmer) and rolls (roll_f / roll_r);
+// variant 4: the first k-mer with its last base replaced by A, C, G, T, a, N, Y in turn (changelast,
+// nthash.hpp:146-152,171-178): entries 0..6.
+__global__ __launch_bounds__(256) void debug_nthash_b(const uint8_t* seq, uint64_t len, uint32_t k, uint32_t hash_num,
+                                                      int variant, uint64_t* out_f, uint64_t* out_r, uint64_t* out_h,
+                                                      uint8_t* valid)
+{
+    __shared__ HashTab ht;
+    if (threadIdx.x < 5) {
+        const uint32_t code = threadIdx.x;
+        const uint64_t s = code < 4 ? seed_of_code(code) : 0ULL;
+        ht.f[code] = s;
+        ht.r[code] = s;
+        ht.fk[code] = sroln(s, k);
+        ht.rk[code] = sroln(s, k);
+    }
+    __syncthreads();
+    auto emit = [&](uint64_t at, uint64_t fh, uint64_t rh, bool ok) {
+        out_f[at] = fh;
+        out_r[at] = rh;
+        valid[at] = ok ? 1 : 0;
+        const uint64_t base = fh + rh;
+        for (uint32_t h = 0; h < hash_num; h++)
+            out_h[at * hash_num + h] = h ? ext_hash(base, k, h) : base;
+    };
+    if (variant == 4) {
+        if (blockIdx.x == 0 && threadIdx.x < 7 && len >= k) {
+            uint64_t fh, rh;
+            hash_kmer(ht, seq, k, fh, rh);
+            changelast(ht, fh, rh, seq[k - 1], "ACGTaNY"[threadIdx.x]);
+            emit(threadIdx.x, fh, rh, true);
+        }
+        return;
+    }
+    const uint64_t p0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    uint64_t fh = 0, rh = 0;
+    for (int j = 0; j < 4; j++) {
+        const uint64_t p = p0 + j;
+        if (p + k > len)
+            break;
+        if (j == 0)
+            hash_kmer(ht, seq + p, k, fh, rh);
+        else {
+            fh = roll_f(ht, fh, seq[p - 1], seq[p + k - 1]);
+            rh = roll_r(ht, rh, seq[p - 1], seq[p + k - 1]);
+        }
+        bool ok = true;
+        for (uint32_t i = 0; i < k; i++)
+            ok &= fcode(seq[p + i]) < 4;
+        emit(p, fh, rh, ok);
+    }
+}
+
+int debug_nthash_stage_b(hipStream_t s, const uint8_t* d_seq, uint64_t len, uint32_t k, uint32_t hash_num, int variant,
+                         uint64_t* d_f, uint64_t* d_r, uint64_t* d_h, uint8_t* d_valid)
+{
+    const uint32_t grid = (uint32_t)((len + 1023) / 1024);
+    hipLaunchKernelGGL(debug_nthash_b, dim3(grid), dim3(256), 0, s, d_seq, len, k, hash_num, variant, d_f, d_r, d_h,
+                       d_valid);
+    GP_HIP(hipGetLastError());
+    return GP_OK;
+}
+
 // ------------------------------------------------------------- small kernels
 __global__ __launch_bounds__(256) void copy_contigs(const uint8_t* src, const uint64_t* src_off,
                                                     const uint32_t* src_len, uint8_t* dst,
@@ -3224,11 +3289,22 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     // 2. the ordered walk, one workgroup per contig; 3. copy the edited contigs out
     if ((rc = job->t_walk.begin(s, job->h_contig_off[job->n_contigs])) != GP_OK)
         return rc;
+    struct TimerScope { // every way out of the walk section closes the timer's interval
+        KernelTimer& t;
+        hipStream_t s;
+        bool open;
+        ~TimerScope()
+        {
+            if (open)
+                (void)t.end(s);
+        }
+    } walk_timer{ job->t_walk, s, true };
     // 2a. contigs of several segment lengths are cut into segments, each walked by a workgroup of
     // its own (SegDesc above).  GP_WALK_SEG: k-mer starts per segment (0: never cut), default 16384 (walk 1.4 s per step with 16384, 2.5 s with 32768, 4.2 s with 65536, 37 s uncut).
     const uint64_t seg_len = env_u64("GP_WALK_SEG", 16384);
     std::vector<SegDesc> h_segs;
     std::vector<SegContig> h_segc;
+    std::vector<uint32_t> h_len; // the contigs' lengths going into this pass (filled when a contig is cut)
     {
         // only contigs of GP_WALK_SEG_MIN starts and more (default 131072; two segment lengths at least)
         // are cut: a job of thousands of 30-100 kbp contigs fills the chip with one workgroup per
@@ -3239,7 +3315,7 @@ int stage_b_pass(gp_job* job, uint32_t ki)
             any_long = job->h_contig_off[c + 1] - job->h_contig_off[c] >= seg_min;
         if (any_long) {
             // the contigs' current lengths (edits of the earlier passes have changed them)
-            std::vector<uint32_t> h_len(job->n_contigs);
+            h_len.assign(job->n_contigs, 0);
             std::vector<uint8_t> h_drop(job->n_contigs);
             GP_HIP(hipMemcpyAsync(h_len.data(), a.len_cur, (size_t)job->n_contigs * 4, hipMemcpyDeviceToHost, s));
             GP_HIP(hipMemcpyAsync(h_drop.data(), a.dropped, job->n_contigs, hipMemcpyDeviceToHost, s));
@@ -3392,12 +3468,9 @@ int stage_b_pass(gp_job* job, uint32_t ki)
         GP_HIP(hipStreamSynchronize(s));
         std::vector<uint32_t> order;
         std::vector<RestoreReq> restores;
-        std::vector<uint32_t> len_of(job->n_contigs, 0);
-        auto contig_len = [&](uint32_t cid) -> uint32_t {
-            if (!len_of[cid])
-                (void)hipMemcpy(&len_of[cid], a.len_cur + cid, 4, hipMemcpyDeviceToHost);
-            return len_of[cid];
-        };
+        // (len_cur is this pass's INPUT length: the walk writes len_next, so the copy made for the
+        // cut planning still holds)
+        auto contig_len = [&](uint32_t cid) -> uint32_t { return h_len[cid]; };
         const size_t n_first = h_segs.size();
         for (SegContig& sc : h_segc) {
             const uint32_t first = sc.seg_first, n = sc.n_seg;
@@ -3544,6 +3617,7 @@ int stage_b_pass(gp_job* job, uint32_t ki)
                        (const uint32_t*)a.n_nodes, (const uint32_t*)b->tile_contig.p,
                        (const uint32_t*)b->tile_first.p);
     GP_HIP(hipGetLastError());
+    walk_timer.open = false;
     if ((rc = job->t_walk.end(s)) != GP_OK)
         return rc;
     if (a.prof) {

@@ -467,6 +467,94 @@ __device__ bool kmer_of(const Search& S, const uint8_t* s, uint64_t km[2], uint6
     return true;
 }
 
+// hashes of a vertex's neighbours in O(1) from its own: the successor drops the k-mer's first base and
+// appends b, the predecessor drops its last base and puts b in front (codes A0 C1 G2 T3)
+__device__ inline void succ_hash(const SeedTab& st, uint64_t pfh, uint64_t prh, uint32_t first, uint32_t b,
+                                 uint64_t& fh, uint64_t& rh)
+{
+    fh = srol1(pfh) ^ st.s[b] ^ st.sk[first];
+    rh = sror1(prh ^ st.sk[3 - b] ^ st.s[3 - first]);
+}
+
+__device__ inline void pred_hash(const SeedTab& st, uint64_t pfh, uint64_t prh, uint32_t last, uint32_t b,
+                                 uint64_t& fh, uint64_t& rh)
+{
+    fh = sror1(pfh ^ st.s[last]) ^ st.sk1[b];
+    rh = srol1(prh ^ st.sk1[3 - last]) ^ st.s[3 - b];
+}
+
+__device__ inline void seed_tab_init(SeedTab& st, uint32_t k)
+{
+    const uint64_t seeds[4] = { kSeedA, kSeedC, kSeedG, kSeedT };
+    for (int c = 0; c < 4; c++) {
+        st.s[c] = seeds[c];
+        st.sk[c] = sroln(seeds[c], k);
+        st.sk1[c] = sroln(seeds[c], k - 1);
+    }
+}
+
+// gp_debug_nthash, variant 3: stage C's hashing over one upper-case sequence.  Lane i of a run of four
+// positions: the first from scratch (kmer_of), the next three as successors of the one before
+// (succ_hash: the forward search's step); and, as a check of the backward search's step, every k-mer
+// is ALSO derived as the predecessor of the k-mer one to its right (pred_hash) -- a position whose two
+// derivations differ is reported invalid.
+__global__ __launch_bounds__(256) void debug_nthash_c(const uint8_t* seq, uint64_t len, uint32_t k, uint32_t hash_num,
+                                                      uint64_t* out_f, uint64_t* out_r, uint64_t* out_h, uint8_t* valid)
+{
+    __shared__ Search S; // (only k and the seed table are used)
+    if (threadIdx.x == 0) {
+        S.k = k;
+        seed_tab_init(S.st, k);
+    }
+    __syncthreads();
+    const uint64_t p0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    uint64_t fh = 0, rh = 0, km[2];
+    bool run_ok = false;
+    for (int j = 0; j < 4; j++) {
+        const uint64_t p = p0 + j;
+        if (p + k > len)
+            break;
+        bool ok;
+        if (j == 0 || !run_ok) {
+            ok = kmer_of(S, seq + p, km, fh, rh);
+        } else {
+            const uint32_t first = code_acgt(seq[p - 1]), b = code_acgt(seq[p + k - 1]);
+            ok = b < 4;
+            if (ok)
+                succ_hash(S.st, fh, rh, first, b, fh, rh);
+        }
+        run_ok = ok;
+        if (ok && p + k < len && code_acgt(seq[p + k]) < 4) {
+            uint64_t km2[2], f2, r2, pf, pr;
+            if (kmer_of(S, seq + p + 1, km2, f2, r2)) {
+                pred_hash(S.st, f2, r2, code_acgt(seq[p + k]), code_acgt(seq[p]), pf, pr);
+                ok = pf == fh && pr == rh;
+                if (!ok) { // a real disagreement, not a non-ACGT byte: make it visible as a wrong value
+                    out_f[p] = pf;
+                    out_r[p] = pr;
+                    valid[p] = 2;
+                    continue;
+                }
+            }
+        }
+        out_f[p] = fh;
+        out_r[p] = rh;
+        valid[p] = ok ? 1 : 0;
+        const uint64_t base = fh + rh;
+        for (uint32_t h = 0; h < hash_num; h++)
+            out_h[p * hash_num + h] = h ? ext_hash(base, k, h) : base;
+    }
+}
+
+int debug_nthash_stage_c(hipStream_t s, const uint8_t* d_seq, uint64_t len, uint32_t k, uint32_t hash_num,
+                         uint64_t* d_f, uint64_t* d_r, uint64_t* d_h, uint8_t* d_valid)
+{
+    const uint32_t grid = (uint32_t)((len + 1023) / 1024);
+    hipLaunchKernelGGL(debug_nthash_c, dim3(grid), dim3(256), 0, s, d_seq, len, k, hash_num, d_f, d_r, d_h, d_valid);
+    GP_HIP(hipGetLastError());
+    return GP_OK;
+}
+
 // getStartKmerPos, FORWARD direction (both call sites), rolling from the flank end backwards
 __device__ uint32_t start_kmer_pos(Search& S, const uint8_t* seq, uint32_t len, uint32_t need)
 {
@@ -777,12 +865,10 @@ __device__ int bidi_search(Search& S)
             uint64_t km[2], fh, rh;
             if (dir == FWD) {
                 km_store(((pk << 2) | b) & all, km);
-                fh = srol1(pu.fh) ^ S.st.s[b] ^ S.st.sk[first];
-                rh = sror1(pu.rh ^ S.st.sk[3 - b] ^ S.st.s[3 - first]);
+                succ_hash(S.st, pu.fh, pu.rh, first, b, fh, rh);
             } else {
                 km_store((pk >> 2) | ((u128)b << (2 * (k - 1))), km);
-                fh = sror1(pu.fh ^ S.st.s[last]) ^ S.st.sk1[b];
-                rh = srol1(pu.rh ^ S.st.sk1[3 - last]) ^ S.st.s[3 - b];
+                pred_hash(S.st, pu.fh, pu.rh, last, b, fh, rh);
             }
             if (!bf_has(S, fh + rh))
                 continue;
@@ -914,12 +1000,7 @@ __device__ bool connect_one(const CArgs& a, Search& S, uint32_t gi, uint32_t wid
     S.a = &a;
     S.bf = a.bf + ((uint64_t)a.contig_batch[g.contig] * a.n_k + a.ki) * a.bf_words;
     S.k = k;
-    const uint64_t seeds[4] = { kSeedA, kSeedC, kSeedG, kSeedT };
-    for (int c = 0; c < 4; c++) {
-        S.st.s[c] = seeds[c];
-        S.st.sk[c] = sroln(seeds[c], k);
-        S.st.sk1[c] = sroln(seeds[c], k - 1);
-    }
+    seed_tab_init(S.st, k);
     S.tests = 0;
     uint32_t sp = start_kmer_pos(S, r1, l1, 3);
     uint32_t gp = kNoMatch;
@@ -1393,7 +1474,7 @@ int sealer_consensus_sets(gp_ctx* ctx, uint32_t n_sets, const uint32_t* set_seq_
     GP_HIP(hipHostMalloc((void**)&h_prog, kNwWorkers * sizeof(uint32_t), hipHostMallocMapped));
     struct FreeProg {
         uint32_t* p;
-        ~FreeProg() { (void)hipHostFree(p); }
+        ~FreeProg() { if (p) (void)hipHostFree(p); }
     } free_prog{ h_prog };
     std::memset(h_prog, 0, kNwWorkers * sizeof(uint32_t));
     uint32_t* d_prog = nullptr;
@@ -1412,19 +1493,34 @@ int sealer_consensus_sets(gp_ctx* ctx, uint32_t n_sets, const uint32_t* set_seq_
                        d_out.p, d_len.p, d_err.p, d_prog);
     GP_HIP(hipGetLastError());
     // a consensus takes milliseconds; a launch that has not come back after a minute is reported,
-    // with how far every worker got, instead of waited for
+    // with how far every worker got.  The buffers of a launch that may still be running must not be
+    // recycled (the pool hands blocks out again without the device-wide wait of hipFree, and the
+    // progress page is host memory): the report goes to stderr at once, then the stream is waited
+    // for; if that wait fails too the buffers are leaked on purpose and the context is unusable.
+    auto give_up = [&](const std::string& msg) {
+        fprintf(stderr, "libgpcore: %s\n", msg.c_str());
+        if (hipStreamSynchronize(s) != hipSuccess) {
+            (void)hipGetLastError();
+            auto leak = [](auto& b) { b.p = nullptr; b.n = 0; b.cap_bytes = 0; };
+            leak(d_seq); leak(d_out); leak(d_off); leak(d_begin); leak(d_len); leak(d_err); leak(d_nw);
+            free_prog.p = nullptr;
+        }
+        set_error(msg);
+        return GP_ERR_HIP;
+    };
     for (int waited_ms = 0;; waited_ms += 2) {
         const hipError_t q = hipStreamQuery(s);
         if (q == hipSuccess)
             break;
-        if (q != hipErrorNotReady)
-            return hip_fail(q, "consensus_sets", __FILE__, __LINE__);
+        if (q != hipErrorNotReady) {
+            (void)hip_fail(q, "consensus_sets", __FILE__, __LINE__);
+            return give_up(gp_last_error());
+        }
         if (waited_ms >= 60000) {
             std::string msg = "gp_sealer_consensus: the device did not finish within a minute; sets done per worker:";
             for (uint32_t w = 0; w < workers; w++)
                 msg += " " + std::to_string(h_prog[w]);
-            set_error(msg);
-            return GP_ERR_HIP;
+            return give_up(msg);
         }
         struct timespec ts = { 0, 2000000 };
         nanosleep(&ts, nullptr);

@@ -130,16 +130,42 @@ typedef struct gp_counters {
 /* ---- library / context ------------------------------------------------- */
 const char* gp_last_error(void);
 int gp_version(void);
-/* Device memory (bytes, all devices) this library holds right now: lets a caller size its jobs.
+/* Device memory (bytes, all devices) that live jobs and contexts of this library hold right now:
+ * lets a caller size its jobs.  Blocks kept for re-use are NOT in it (gp_device_pool_bytes): what
+ * the process really holds on its devices is the sum of the two.
  * A job needs about n_batches * n_k * (cbf_bytes + bf_bytes) for the filters, 30 bytes per contig
  * base and 1 byte per read base, plus 3 to 6 GiB of Sealer search arenas per job with run_sealer (39 GiB where contigs of 200 kbp and more are polished). */
 uint64_t gp_device_bytes_in_use(void);
-/* Device memory the library keeps for re-use: blocks of destroyed jobs go to a pool, so that the
- * next job of a like shape costs no hipMalloc / hipFree (a stream of jobs: gp_pipeline_*).  The
- * pool never holds more than GP_POOL_GIB GiB (environment, default 200; 0 = no pooling) and is
- * emptied before an allocation is allowed to fail; gp_device_pool_trim gives everything back. */
+/* Device memory the library keeps for re-use: blocks of destroyed jobs go to a pool PER DEVICE, so
+ * that the next job of a like shape costs no hipMalloc / hipFree (a stream of jobs:
+ * gp_pipeline_*).  A device's pool never holds more than the most the library has had in use on
+ * that device at one time, nor more than GP_POOL_GIB GiB (environment, default 200; 0 = no
+ * pooling); it is emptied before an allocation of this library on that device is allowed to
+ * fail, and when the last gp_ctx on the device is destroyed.  Other allocators in the process
+ * (PyTorch's caching allocator, RCCL) cannot make this library give memory back: a caller that
+ * mixes them in calls gp_device_pool_trim (all devices, everything) at its own quiet points. */
 uint64_t gp_device_pool_bytes(void);
 void gp_device_pool_trim(void);
+/* Test hooks, not part of the reference's interface.  gp_debug_fail_alloc(n): the n-th device
+ * allocation of this library from now on fails with GP_ERR_OOM (0 = off; tests of the
+ * out-of-memory paths); returns the number of device allocations the library has made so far.
+ * gp_debug_nthash: the kernels' OWN ntHash code over one sequence, so that it can be compared with
+ * values made from the reference's header (subprojects/ntedit/lib/nthash.hpp:100-191,305-325)
+ * directly and not only through the filters it fills.  variant 0: stage A as cbf_first_pass /
+ * cbf_local hash (first k-mer of a lane's run from the table of rotated seeds, then rolls; ext_hash);
+ * 1: stage A as census_scatter hashes (roll tables in LDS, extension hashes 1-3 from one multiply);
+ * 2: stage B (ntedit_scan / the walker: seed classes of raw bytes, from scratch + roll_f / roll_r);
+ * 3: stage C (kmer_of, then successor hashes as the forward search derives them; every value is also
+ * derived as a predecessor, the backward search's step: a disagreement gives valid = 2);
+ * 4: stage B's changelast -- the first k-mer with its last base replaced by A, C, G, T, a, N, Y: seven
+ * entries (the output arrays must hold max(len, 8) entries).
+ * For every k-mer start i in [0, len - k]: out_fwd[i], out_rev[i], out_hashes[i * hash_num + h]
+ * (h = 0 canonical = fwd + rev, then the extensions); valid[i] = 0 where the k-mer holds a byte
+ * outside ACGTacgt (stage A skips those; their values are unspecified for variants 0, 1, 3).
+ * Returns the number of entries written, or a negative GP_ERR_*.  k <= 63. */
+uint64_t gp_debug_fail_alloc(uint64_t nth);
+int64_t gp_debug_nthash(gp_ctx* ctx, int variant, const uint8_t* seq, uint64_t len, uint32_t k, uint32_t hash_num,
+                        uint64_t* out_fwd, uint64_t* out_rev, uint64_t* out_hashes, uint8_t* valid);
 void gp_default_params(gp_params* p);
 int gp_ctx_create(int device, gp_ctx** out);
 void gp_ctx_destroy(gp_ctx* ctx);

@@ -143,3 +143,69 @@ def test_fasta_that_cannot_be_written_whole_is_an_error_and_leaves_no_partial_fi
         assert e.value.code == -10
         job.write_fasta(app, names=w.names, append=True)
         assert app.read_bytes() == b">x\nACGT\n" + want
+
+
+def test_a_failed_allocation_leaves_a_job_that_can_be_destroyed_or_tried_again(gp):
+    """Every device allocation a polish makes is failed once (gp_debug_fail_alloc): the call answers
+    GP_ERR_OOM, nothing is destroyed twice when the job is destroyed right after (stage A's events
+    used to be), and the same job polished again -- memory 'freed' -- gives the bytes of an undisturbed
+    run.  ensure_work's allocations (filters, stage A's buffers, stage B/C's arenas) come first."""
+    core, ctx = gp
+    w = synth.make_workload([7000, 3000, 5000], 20, seed=77)
+    p = core.default_params()
+    core.debug_fail_alloc(0)
+    with core.Job.from_workload(ctx, p, w) as job:
+        before = core.debug_fail_alloc(0)
+        job.polish()
+        n_allocs = core.debug_fail_alloc(0) - before
+        want = job.sequences()
+    assert n_allocs >= 20
+    try:
+        for nth in sorted(set(list(range(1, min(n_allocs, 24) + 1)) + list(range(24, n_allocs + 1, 5)))):
+            core.device_pool_trim()  # the same sequence of allocations every time
+            job = core.Job.from_workload(ctx, p, w)
+            core.debug_fail_alloc(nth)
+            with pytest.raises(core.GpError) as e:
+                job.polish()
+            assert e.value.code == -4 and "injected" in str(e.value), (nth, str(e.value))
+            core.debug_fail_alloc(0)
+            if nth % 2:
+                job.close()          # destroyed right after the failure
+                continue
+            try:
+                job.polish()         # ... or tried again
+                assert job.sequences() == want, nth
+            except core.GpError as e2:
+                # the one documented dead end: the slots were being regrown (work_state 2)
+                assert e2.code == -6, (nth, str(e2))
+            job.close()
+    finally:
+        core.debug_fail_alloc(0)
+
+
+def test_jobs_and_pipeline_on_a_second_device():
+    """gp_jobs_polish's filter-build thread and gp_pipeline's threads allocate lazily: on a device
+    other than 0 those allocations must land on the job's device (a new thread's current device is
+    0).  Needs two visible GPUs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    from goldpolish_amd import core
+    w = synth.make_workload([9000, 4000, 6000, 5000], 20, seed=78)
+    p = core.default_params()
+    with core.Context(0) as c0, core.Job.from_workload(c0, p, w) as one:
+        one.polish()
+        want = one.sequences()
+    base0 = torch.cuda.mem_get_info(0)[0]
+    ctxs = [core.Context(1) for _ in range(2)]
+    jobs = [core.Job(ctxs[i], p, **core.slice_workload(w, 2 * i, 2 * i + 2)) for i in range(2)]
+    try:
+        core.polish_jobs(jobs)
+        assert [s for j in jobs for s in j.sequences()] == want
+        # nothing of it was allocated on device 0 (the filters alone are 4 x 4 x 10.5 MiB per batch)
+        assert base0 - torch.cuda.mem_get_info(0)[0] < (256 << 20)
+    finally:
+        for j in jobs:
+            j.close()
+        for c in ctxs:
+            c.close()

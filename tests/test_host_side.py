@@ -69,44 +69,82 @@ sys.path.insert(0, sys.argv[3])
 import torch.distributed as dist
 import bench
 from goldpolish_amd import core
-rank, world = int(sys.argv[1]), int(sys.argv[2])
+rank, world, scenario = int(sys.argv[1]), int(sys.argv[2]), sys.argv[5]
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[4], RANK=str(rank), WORLD_SIZE=str(world))
 dist.init_process_group("gloo", rank=rank, world_size=world)
 import numpy as np, torch
-# one fixed assembly of 23 single-contig batches; every rank computes the same partition by itself
+# one fixed assembly of single-contig batches; every rank computes the same partition by itself
 rng = np.random.default_rng(11)
-lens = rng.integers(40, 400, size=23)
+n_batches = {"even": 23, "few": 5, "drop": 41, "skew": 30}[scenario]
+lens = rng.integers(40, 400, size=n_batches)
+if scenario == "skew":
+    lens[3] = 40000          # one batch outweighs the rest: its rank gets nothing else
 contigs = [bytes(rng.choice(list(b"acgt"), size=int(n)).astype(np.uint8)) for n in lens]
 cost = (lens * 31).astype(np.uint64)
 rank_of, load = core.partition_batches(cost, world)
+def polished_of(b):          # stand-in for the GPU path
+    if scenario == "drop" and rank_of[b] == world // 2:
+        return b""           # every record of one rank dropped: its payload is empty
+    return contigs[b].upper() if b % 7 else b""
 mine = [b for b in range(len(contigs)) if rank_of[b] == rank]          # ascending: the order a rank polishes in
-polished = [contigs[b].upper() if b % 7 else b"" for b in mine]         # stand-in for the GPU path; every 7th dropped
+polished = [polished_of(b) for b in mine]
 lens_t = torch.tensor([len(x) for x in polished], dtype=torch.int64)
 payload = torch.from_numpy(np.frombuffer(b"".join(polished) or b"\0", dtype=np.uint8).copy())[:sum(len(x) for x in polished)]
 out = bench.gather_to_rank0(lens_t, payload, rank, world)
 if rank == 0:
     per_rank = [bench.split_records(*out[r]) for r in range(world)]
     whole = bench.input_order(rank_of, per_rank)
-    assert whole == [c.upper() if b % 7 else b"" for b, c in enumerate(contigs)]
+    assert whole == [polished_of(b) for b in range(len(contigs))]
     assert sorted(int(x) for x in load) == sorted(int(cost[rank_of == r].sum()) for r in range(world))
-    print("PARTITION_GATHER_OK", [int(x) for x in np.bincount(rank_of, minlength=world)])
+    counts = [int(x) for x in np.bincount(rank_of, minlength=world)]
+    if scenario == "few":
+        assert counts.count(0) == world - n_batches        # ranks with no batch at all
+    if scenario == "skew":
+        assert counts[int(rank_of[3])] == 1
+    print("PARTITION_GATHER_OK", counts)
 dist.barrier()
 dist.destroy_process_group()
 '''
 
 
+def _run_ranks(tmp_path, world, scenario, port0):
+    script = tmp_path / "part_worker.py"
+    script.write_text(_PART_WORKER)
+    port = str(port0 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(ROOT), port, scenario],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=400)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "PARTITION_GATHER_OK" in outs[0]
+
+
 def test_partition_polish_order_gather_gloo_world2(tmp_path):
     """the multi-GPU flow end to end on CPU ranks: gp_partition_batches (same answer on every rank)
     -> each rank's batches in ascending order -> variable-length gather -> input order at rank 0"""
-    script = tmp_path / "part_worker.py"
-    script.write_text(_PART_WORKER)
-    port = str(31500 + os.getpid() % 2000)
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(ROOT), port],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-             for r in range(2)]
-    outs = [p.communicate(timeout=240)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
-    assert "PARTITION_GATHER_OK" in outs[0]
+    _run_ranks(tmp_path, 2, "even", 31500)
+
+
+@pytest.mark.parametrize("scenario", ["few", "drop", "skew"])
+def test_partition_polish_order_gather_gloo_world8(tmp_path, scenario):
+    """the same with the eight ranks of a node: fewer batches than ranks (three ranks hold nothing and
+    send nothing), a rank whose records were all dropped (empty payload), one batch that outweighs the
+    rest (uneven shares)"""
+    _run_ranks(tmp_path, 8, scenario, {"few": 33500, "drop": 35500, "skew": 37500}[scenario])
+
+
+def test_bench_dry_run_reports_every_rank_of_a_node():
+    """`bench.py --gpus 8 --dry-run`: what the driver's first 8-GPU run will hold per rank, without a GPU"""
+    import json
+    out = subprocess.check_output([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--dry-run"], text=True,
+                                  env=dict(os.environ, GP_BENCH_NODE_CONTIGS="15000"))
+    d = json.loads(out.strip().splitlines()[-1])
+    assert d["n_gpus"] == 8 and len(d["ranks"]) == 8 and d["batches"] == 120000
+    assert 2.9e9 < d["assembly_bp"] < 3.1e9
+    assert all(r["device_bytes"] < 200 * 2**30 for r in d["ranks"])         # inside 288 GB of HBM with room to spare
+    assert d["ranks"][0]["host_pinned_bytes"] > d["ranks"][1]["host_pinned_bytes"]   # rank 0 holds the gather buffers
+    lo, hi = d["partition_load_min_max"]
+    assert hi - lo < 0.001 * hi
 
 
 _ASAN = r'''
