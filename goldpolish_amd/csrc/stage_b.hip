@@ -157,9 +157,31 @@ __device__ inline uint32_t rcode(uint8_t c)
     }
 }
 
+// What the out-of-line parts of the walk (make_edit, indel_sweep, walk_site) need of the launch's
+// arguments, kept in LDS.  Nothing takes the address of the kernel's argument block: while a Ctx held
+// `&a` and was handed to those functions by reference, the whole WalkArgs lived in scratch -- every
+// lane stored its 330 bytes at kernel entry and every later `a.field` was a per-lane scratch load
+// (117 of them in the trip loop: most of the 57 GB the walk fetched per launch, r03 PMC) instead of a
+// scalar load from the kernel-argument segment.
+struct WalkCfg {
+    uint32_t k, hash_num, jump;
+    uint32_t max_ins_tries, max_del;
+    uint32_t need_missing, need_edit, need_del;
+    uint32_t insertion_cap, soft_mask;
+    FastMod bf_mod;
+    uint32_t* err;
+};
+
+struct Best {
+    uint32_t type; // 0 none, 1 sub, 2 ins, 3 del
+    uint8_t sub_base;
+    uint8_t indel[8];
+    uint32_t indel_len;
+    uint32_t sup;
+};
+
 struct Ctx {
     // per-workgroup constants
-    const WalkArgs* a;
     uint8_t* seq;       // this contig (mutable)
     Node* nd;
     uint32_t node_cap;
@@ -169,6 +191,9 @@ struct Ctx {
 
 struct Shared {
     HashTab ht;
+    WalkCfg cfg;              // (thread 0 fills cfg and ctx before the first barrier)
+    Ctx ctx;                  // the workgroup's contig, for the out-of-line functions
+    Best edit_best;           // make_edit's argument
     // walker state (thread 0 writes)
     uint32_t hi, ti, hn, tn, nn;
     uint64_t fh, rh;
@@ -232,6 +257,11 @@ struct Shared {
     uint32_t seg_refused;     // make_edit refused a repeat insertion (and dropped nodes of the list)
 };
 
+// The workgroup's LDS block lives at namespace scope, so that the out-of-line device functions below
+// address it as LDS (ds_read / ds_write with constant offsets) instead of through a generic reference
+// (flat loads) -- ntedit_walk and ntedit_site_eval both work in it.
+__shared__ Shared g_S;
+
 enum { REQ_DONE = 0, REQ_SCAN, REQ_SITE, REQ_NEXT, REQ_BITSCAN, REQ_REFILL, REQ_SWEEP };
 
 // What the trials at one confirmed site decide, worked out ahead of the walk for every site of
@@ -274,7 +304,8 @@ __device__ inline void hash_kmer(const HashTab& t, const uint8_t* z, uint32_t k,
     rh = r;
 }
 
-__device__ inline bool bf_contains(const WalkArgs& a, const uint32_t* bf, uint64_t base)
+template <typename A> // WalkArgs (kernel bodies: scalar loads from the argument segment) or WalkCfg (LDS)
+__device__ inline bool bf_contains(const A& a, const uint32_t* bf, uint64_t base)
 {
     bool all = true;
     for (uint32_t i = 0; i < a.hash_num; i++) {
@@ -318,7 +349,7 @@ __device__ inline void nd_put(const Ctx& c, Shared& S, uint32_t i, Node n)
     } else if (S.nn < c.node_cap) {
         c.nd[S.nn++] = n;
     } else {
-        atomicOr(c.a->err, 1u); // node list overflow
+        atomicOr(S.cfg.err, 1u); // node list overflow
     }
 }
 
@@ -439,7 +470,7 @@ __device__ void make_insertion(const Ctx& c, Shared& S, uint32_t& tn, int insert
             nre++;
         const uint32_t need = tn + nins + nre;
         if (need > c.node_cap) {
-            atomicOr(c.a->err, 1u);
+            atomicOr(S.cfg.err, 1u);
             return;
         }
         while (S.nn < need)
@@ -614,14 +645,6 @@ __device__ void drop_repeat_nodes(const Ctx& c, Shared& S, uint32_t tn, uint32_t
     }
 }
 
-struct Best {
-    uint32_t type; // 0 none, 1 sub, 2 ins, 3 del
-    uint8_t sub_base;
-    uint8_t indel[8];
-    uint32_t indel_len;
-    uint32_t sup;
-};
-
 // multi_possible_bases[first][i]: shortest first, then A<C<G<T
 __device__ inline uint32_t indel_string(uint8_t first, uint32_t i, uint8_t* out)
 {
@@ -640,8 +663,13 @@ __device__ inline uint32_t indel_string(uint8_t first, uint32_t i, uint8_t* out)
     return L;
 }
 
-__device__ void make_edit(const Ctx& c, Shared& S, uint8_t draft, Best& b)
+// thread 0 only; the edit to make is S.edit_best.  Out of line on purpose: it is the rare end of a
+// site's or a sweep's branch, and inlined its node-list surgery sat in the trip loop's register budget.
+__device__ __attribute__((noinline)) void make_edit(uint8_t draft)
 {
+    Shared& S = g_S;
+    const Ctx& c = S.ctx;
+    Best& b = S.edit_best;
     const HashTab& ht = S.ht;
     const uint32_t k = c.k;
     Node tnode = nd_cached(c, S, S.tn);
@@ -674,14 +702,14 @@ __device__ void make_edit(const Ctx& c, Shared& S, uint8_t draft, Best& b)
                 tn--;
             }
             if (np > 200) {
-                atomicOr(c.a->err, 2u);
+                atomicOr(S.cfg.err, 2u);
                 np = 200;
             }
         }
         if (np + b.indel_len >= k) {
             uint8_t* const kmer = S.me_kmer;
             if (is_repeat_insertion(prev, (int)np, lps) ||
-                np + b.indel_len >= c.a->insertion_cap) {
+                np + b.indel_len >= S.cfg.insertion_cap) {
                 drop_repeat_nodes(c, S, S.tn, S.ti, np);
                 if (find_accepted_kmer(c, S, S.hi, S.ti, S.hn, S.tn, kmer))
                     hash_kmer(ht, kmer, k, S.fh, S.rh);
@@ -729,7 +757,7 @@ __device__ void make_edit(const Ctx& c, Shared& S, uint8_t draft, Best& b)
         S.clean_from = max(S.clean_from, S.ti + 1);
         break;
     default:
-        if (c.a->soft_mask) {
+        if (S.cfg.soft_mask) {
             uint8_t lo = to_lower(draft);
             if (tnode.type == 0)
                 seq_store(c, S, S.ti, lo);
@@ -866,9 +894,11 @@ __device__ inline uint32_t block_sum(Shared& S, uint32_t v)
 
 // insertion / deletion sweep for one index char; every thread takes candidates
 // t, t+256, ...; result: S.best_key (0 = nothing passed)
-__device__ void indel_sweep(const Ctx& c, Shared& S, uint8_t index_char, uint32_t del_from)
+__device__ __forceinline__ void indel_sweep_body(uint8_t index_char, uint32_t del_from)
 {
-    const WalkArgs& a = *c.a;
+    Shared& S = g_S;
+    const Ctx& c = S.ctx;
+    const WalkCfg& a = S.cfg;
     const HashTab& ht = S.ht;
     const uint32_t k = c.k, jump = a.jump;
     const uint8_t draft = (uint8_t)S.draft;
@@ -942,6 +972,30 @@ __device__ void indel_sweep(const Ctx& c, Shared& S, uint8_t index_char, uint32_
     atomicAdd(&S.st_probes, (unsigned long long)probes);
 }
 
+// thread 0, before the workgroup's first barrier
+__device__ inline void fill_cfg(Shared& S, const WalkArgs& a, const Ctx& c)
+{
+    S.cfg.k = a.k;
+    S.cfg.hash_num = a.hash_num;
+    S.cfg.jump = a.jump;
+    S.cfg.max_ins_tries = a.max_ins_tries;
+    S.cfg.max_del = a.max_del;
+    S.cfg.need_missing = a.need_missing;
+    S.cfg.need_edit = a.need_edit;
+    S.cfg.need_del = a.need_del;
+    S.cfg.insertion_cap = a.insertion_cap;
+    S.cfg.soft_mask = a.soft_mask;
+    S.cfg.bf_mod = a.bf_mod;
+    S.cfg.err = a.err;
+    S.ctx = c;
+}
+
+// out of line for the walk (walk_site calls it up to three times); ntedit_site_eval inlines the body
+__device__ __attribute__((noinline)) void indel_sweep(uint8_t index_char, uint32_t del_from)
+{
+    indel_sweep_body(index_char, del_from);
+}
+
 // ---- every site of the untouched contig, ahead of the walk.
 // While everything right of the walker's head is untouched contig ("clean"), what happens at a
 // confirmed site -- which substitute k-mers are in the filter, which substitution / insertion /
@@ -960,7 +1014,7 @@ constexpr int kEvalTile = 256;
 __global__ __launch_bounds__(kWalkThreads, 6) void ntedit_site_eval(WalkArgs a, const uint32_t* tile_contig,
                                                                 const uint32_t* tile_first)
 {
-    __shared__ Shared S;
+    Shared& S = g_S;
     __shared__ uint32_t s_cand[kEvalTile], s_n;
     const uint32_t tid = threadIdx.x;
     // the tile tables are per 4096-position tile (kMatTile); this kernel cuts them in 16
@@ -979,7 +1033,6 @@ __global__ __launch_bounds__(kWalkThreads, 6) void ntedit_site_eval(WalkArgs a, 
         return;
     const uint64_t base_bit = a.off[cid];
     Ctx c;
-    c.a = &a;
     c.seq = a.seq + a.off[cid];
     c.nd = nullptr;
     c.node_cap = 0;
@@ -987,6 +1040,7 @@ __global__ __launch_bounds__(kWalkThreads, 6) void ntedit_site_eval(WalkArgs a, 
     c.len = len;
     c.k = k;
     if (tid == 0) {
+        fill_cfg(S, a, c);
         for (uint32_t code = 0; code < 5; code++) {
             uint64_t sd = code < 4 ? seed_of_code(code) : 0ULL;
             S.ht.f[code] = sd;
@@ -1171,11 +1225,8 @@ __global__ __launch_bounds__(kWalkThreads, 6) void ntedit_site_eval(WalkArgs a, 
             }
         }
         __syncthreads();
-        Best best;
-        best.type = 0;
-        best.sup = 0;
-        best.sub_base = 0;
-        best.indel_len = 0;
+        uint32_t best_type = 0, best_sup = 0, best_len = 0, best_order = 0; // (scalars: see walk_site)
+        uint8_t best_sub = 0, best_char = 0;
         uint32_t any_in_bf = 0;
         for (uint32_t si = 0; si < S.n_sub; si++) {
             if (!S.sub_in_bf[si])
@@ -1185,19 +1236,19 @@ __global__ __launch_bounds__(kWalkThreads, 6) void ntedit_site_eval(WalkArgs a, 
                 S.st_probes += 1 + (k + jump - 1) / jump;
             const uint32_t present = S.sub_present[si];
             if (present >= a.need_edit) {
-                if (present >= best.sup) {
-                    best.type = 1;
-                    best.sub_base = S.subs[si];
-                    best.sup = present;
+                if (present >= best_sup) {
+                    best_type = 1;
+                    best_sub = S.subs[si];
+                    best_sup = present;
                 }
                 continue;
             }
-            if (best.type != 1) {
+            if (best_type != 1) {
                 __syncthreads();
                 if (tid == 0)
                     S.best_key = 0;
                 __syncthreads();
-                indel_sweep(c, S, S.subs[si], S.num_del);
+                indel_sweep_body(S.subs[si], S.num_del);
                 __syncthreads();
                 const uint32_t key = S.best_key;
                 uint32_t n_del = (a.max_ins_tries > 0 && S.num_del <= a.max_del)
@@ -1209,13 +1260,14 @@ __global__ __launch_bounds__(kWalkThreads, 6) void ntedit_site_eval(WalkArgs a, 
                     S.num_del = del_from + n_del;
                 if (key) {
                     const uint32_t order = key & 0xFFFF;
-                    best.sup = key >> 16;
+                    best_sup = key >> 16;
                     if (order & 1) {
-                        best.type = 3;
-                        best.indel_len = del_from + (order >> 1);
+                        best_type = 3;
+                        best_len = del_from + (order >> 1);
                     } else {
-                        best.type = 2;
-                        best.indel_len = indel_string(S.subs[si], order >> 1, best.indel);
+                        best_type = 2;
+                        best_order = order >> 1;
+                        best_char = S.subs[si];
                     }
                     break;
                 }
@@ -1223,17 +1275,269 @@ __global__ __launch_bounds__(kWalkThreads, 6) void ntedit_site_eval(WalkArgs a, 
         }
         __syncthreads();
         if (tid == 0) {
+            // (the record is put together in LDS -- indel_string writes its bytes one by one -- and
+            // leaves as one 16-byte store)
+            Best& b = S.edit_best;
+            for (int i = 0; i < 8; i++)
+                b.indel[i] = 0;
+            const uint32_t ilen = best_type == 2 ? indel_string(best_char, best_order, b.indel) : best_len;
             SiteRec r;
-            r.type = (uint8_t)best.type;
-            r.sub_base = best.sub_base;
-            r.indel_len = (uint8_t)best.indel_len;
+            r.type = (uint8_t)best_type;
+            r.sub_base = best_sub;
+            r.indel_len = (uint8_t)ilen;
             r.flags = (uint8_t)(1u | (any_in_bf << 1));
             for (int i = 0; i < 8; i++)
-                r.indel[i] = (best.type == 2 && (uint32_t)i < best.indel_len) ? best.indel[i] : 0;
+                r.indel[i] = b.indel[i];
             r.probes = (uint32_t)S.st_probes;
             a.site_rec[base_bit + cand] = r;
         }
     }
+}
+
+// REQ_SITE: the trials of a site worked out on the spot (the head among edited nodes, or right
+// after an edit) -- gather the 2k + 12 window, confirm, substitutes, insertion / deletion sweep,
+// make_edit.  Every thread of the workgroup calls it.  Out of line: it is the rare request, and
+// inlined its dozen phases set the register budget of the whole trip loop (188 VGPRs unspilled; cut to
+// the 128 of four waves per SIMD it spilled 50 and reloaded them on every trip).
+__device__ __attribute__((noinline)) void walk_site(uint32_t nxt)
+{
+    Shared& S = g_S;
+    const Ctx& c = S.ctx;
+    const WalkCfg& cfg = S.cfg;
+    const uint32_t tid = threadIdx.x, k = c.k, jump = cfg.jump, len = c.len;
+    // ------------------------------------------------------------ REQ_SITE
+    if (tid == 0) {
+        const uint32_t want = 2 * k + 12;
+        Node hnode = nd_cached(c, S, S.hn);
+        const bool in_final = hnode.type == 0 && hnode.e == len - 1 && S.hi <= hnode.e;
+        const bool inside = hnode.type == 0 && S.hi + want - 1 <= hnode.e;
+        if (in_final || inside) {
+            S.fast_head = 1;
+            S.nz = min(want, hnode.e - S.hi + 1);
+        } else {
+            S.fast_head = 0;
+            S.nz = gather_plan(c, S, S.Z, want);
+        }
+        S.draft = to_upper((uint8_t)S.char_in);
+        S.best_key = 0;
+    }
+    __syncthreads();
+    // flags are read once, here, by everybody; thread 0 only rewrites them behind barriers
+    const uint32_t f_fast = S.fast_head, f_hash = S.need_hash, f_confirmed = S.confirmed;
+    if (f_fast) {
+        for (uint32_t i = tid; i < S.nz; i += blockDim.x) {
+            const uint32_t pos = S.hi + i;
+            S.Z[i] = pos - S.cp0 < S.cpn ? S.c_seq[pos - S.cp0] : c.seq[pos];
+        }
+        __syncthreads();
+    } else {
+        gather_fill(c, S, S.Z);
+        __syncthreads();
+    }
+    {
+        // prefix XORs of the rotated seeds of the whole window (one element per lane):
+        // PF[i] = xor_{j<i} ror^j(fwd(Z_j)), QR[i] = xor_{j<i} rol^j(rev(Z_j))
+        const uint32_t nzz = S.nz;
+        uint64_t tf = 0, tr = 0;
+        if (tid < nzz) {
+            tf = srorn(S.ht.f[fcode(S.Z[tid])], tid);
+            tr = sroln(S.ht.r[rcode(S.Z[tid])], tid);
+        }
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t uf = __shfl_up(tf, o), ur = __shfl_up(tr, o);
+            if (lane >= o) {
+                tf ^= uf;
+                tr ^= ur;
+            }
+        }
+        if (lane == 63) {
+            S.wave_f[wave] = tf;
+            S.wave_r[wave] = tr;
+        }
+        __syncthreads();
+        uint64_t pf = 0, pr = 0;
+        for (int w = 0; w < wave; w++) {
+            pf ^= S.wave_f[w];
+            pr ^= S.wave_r[w];
+        }
+        if (tid < nzz) {
+            S.PF[tid + 1] = tf ^ pf;
+            S.QR[tid + 1] = tr ^ pr;
+        }
+        if (tid == 0) {
+            S.PF[0] = 0;
+            S.QR[0] = 0;
+        }
+        __syncthreads();
+        if (f_hash && tid == 0) {
+            // the walker jumped here: rebuild its rolling state from the window
+            S.fh = win_f(S, 0, k);
+            S.rh = win_r(S, 0, k);
+            S.char_in = S.Z[k - 1];
+            S.draft = to_upper(S.Z[k - 1]);
+        }
+        __syncthreads();
+    }
+    if (!f_confirmed) {
+        // confirm: k more k-mers, every jump-th one probed
+        uint32_t miss = 0, bad = 0;
+        if (tid < k) {
+            const uint32_t q = tid;
+            if (k + q >= S.nz)
+                bad = 1;
+            else if (!is_accepted_u(S.Z[k + q]))
+                bad = 1;
+        }
+        bad = block_sum(S, bad);
+        if (!bad && tid < k && tid % jump == 0)
+            miss = bf_contains(cfg, c.bf, win_f(S, tid + 1, k) + win_r(S, tid + 1, k)) ? 0u : 1u;
+        miss = block_sum(S, miss);
+        if (tid == 0) {
+            S.confirm_bad = bad;
+            S.confirm_missing = miss;
+            S.st_probes += bad ? 0 : (k + jump - 1) / jump;
+        }
+        __syncthreads();
+    }
+    if (!f_confirmed && (S.confirm_bad || S.confirm_missing < cfg.need_missing)) {
+        if (tid == 0) {
+            S.req[nxt] = REQ_NEXT;
+            S.need_hash = 0;
+        }
+        __syncthreads();
+        return;
+    }
+
+    // substitution trials: one wave-sized slice of work per candidate base
+    if (tid == 0) {
+        S.st_sites++;
+        S.confirmed = 0;
+        S.need_hash = 0;
+        const char* s;
+        switch ((uint8_t)S.draft) {
+        case 'A': s = "TCG"; break;
+        case 'T': s = "ACG"; break;
+        case 'C': s = "ATG"; break;
+        case 'G': s = "ATC"; break;
+        case 'R': s = "TC"; break;
+        case 'Y': s = "AG"; break;
+        case 'S': s = "AT"; break;
+        case 'W': s = "CG"; break;
+        case 'K': s = "AC"; break;
+        case 'M': s = "TG"; break;
+        case 'B': s = "A"; break;
+        case 'D': s = "C"; break;
+        case 'H': s = "G"; break;
+        case 'V': s = "T"; break;
+        default: s = ""; break;
+        }
+        uint32_t n = 0;
+        for (; s[n]; n++)
+            S.subs[n] = (uint8_t)s[n];
+        S.n_sub = n;
+        for (uint32_t i = 0; i < 4; i++)
+            S.sub_in_bf[i] = S.sub_present[i] = 0;
+        S.num_del = 1;
+    }
+    __syncthreads();
+    {
+        // thread (si*64 + q): q == 63 probes the changed k-mer itself,
+        // q < k probes the k-mer after q+1 rolls when q % jump == 0
+        const uint32_t q = tid & 63;
+        for (uint32_t si = tid >> 6; si < S.n_sub; si += blockDim.x / 64) { // (128-thread workgroups: two waves for up to three substitutes)
+            const uint8_t sb = S.subs[si];
+            if (q == 63) {
+                uint64_t fh = S.fh, rh = S.rh;
+                changelast(S.ht, fh, rh, (uint8_t)S.draft, sb);
+                if (bf_contains(cfg, c.bf, fh + rh))
+                    S.sub_in_bf[si] = 1;
+            } else if (q < k && q % jump == 0 && k + q < S.nz) {
+                // k-mer = Z[q+1 .. q+1+k) with Z[k-1] replaced by sb: O(1) from the prefixes
+                const uint32_t a0 = q + 1, site = k - 1;
+                uint64_t f = win_f(S, a0, k), r = win_r(S, a0, k);
+                if (a0 <= site) {
+                    const uint8_t old_c = S.Z[site];
+                    f ^= sroln(S.ht.f[fcode(old_c)] ^ S.ht.f[fcode(sb)], (a0 + k - 1) - site);
+                    r ^= sroln(S.ht.r[rcode(old_c)] ^ S.ht.r[rcode(sb)], site - a0);
+                }
+                if (bf_contains(cfg, c.bf, f + r))
+                    atomicAdd(&S.sub_present[si], 1u);
+            }
+        }
+    }
+    __syncthreads();
+
+    // replay the reference's control flow over the trial results (uniform)
+    // (the winner as scalars: a private Best -- its indel[] is indexed at run time -- would be promoted to
+    // 24 bytes of LDS per lane)
+    uint32_t best_type = 0, best_sup = 0, best_len = 0, best_order = 0;
+    uint8_t best_sub = 0, best_char = 0;
+    for (uint32_t si = 0; si < S.n_sub; si++) {
+        if (!S.sub_in_bf[si])
+            continue;
+        if (tid == 0) {
+            // trial + revert leaves the UPPER-case draft base behind (:1608-1615)
+            Node tnode = nd_cached(c, S, S.tn);
+            if (tnode.type == 0) {
+                seq_store(c, S, S.ti, (uint8_t)S.draft);
+            } else if (tnode.type == 1) {
+                c.nd[S.tn].c = S.draft;
+                nd_cache_drop(S);
+            }
+            S.st_probes += 1 + (k + jump - 1) / jump;
+        }
+        const uint32_t present = S.sub_present[si];
+        if (present >= cfg.need_edit) {
+            if (present >= best_sup) {
+                best_type = 1;
+                best_sub = S.subs[si];
+                best_sup = present;
+            }
+            continue; // modes 0/1: a good substitution ends this base's turn
+        }
+        if (best_type != 1) {
+            __syncthreads();
+            if (tid == 0)
+                S.best_key = 0;
+            __syncthreads();
+            indel_sweep(S.subs[si], S.num_del);
+            __syncthreads();
+            const uint32_t key = S.best_key;
+            // deletions del_from.. were consumed by this call
+            uint32_t n_del = (cfg.max_ins_tries > 0 && S.num_del <= cfg.max_del)
+                                 ? min(cfg.max_del - S.num_del + 1, cfg.max_ins_tries)
+                                 : 0u;
+            const uint32_t del_from = S.num_del;
+            __syncthreads();
+            if (tid == 0)
+                S.num_del = del_from + n_del;
+            if (key) {
+                const uint32_t order = key & 0xFFFF;
+                best_sup = key >> 16;
+                if (order & 1) {
+                    best_type = 3;
+                    best_len = del_from + (order >> 1);
+                } else {
+                    best_type = 2;
+                    best_order = order >> 1;
+                    best_char = S.subs[si];
+                }
+                break; // tryIndels returned true (modes 0/1)
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        Best& b = S.edit_best;
+        b.type = best_type;
+        b.sub_base = best_sub;
+        b.sup = best_sup;
+        b.indel_len = best_type == 2 ? indel_string(best_char, best_order, b.indel) : best_len;
+        make_edit((uint8_t)S.draft);
+        S.req[nxt] = REQ_NEXT;
+    }
+    __syncthreads();
 }
 
 // kMinWaves: 1 = as many registers as the compiler likes (136: three workgroups per CU, the
@@ -1243,7 +1547,7 @@ __global__ __launch_bounds__(kWalkThreads, 6) void ntedit_site_eval(WalkArgs a, 
 template <int kMinWaves, bool SEG>
 __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs a)
 {
-    __shared__ Shared S;
+    Shared& S = g_S;
     const uint32_t tid = threadIdx.x;
     uint32_t cid = blockIdx.x;
     uint32_t seg_begin = 0, seg_end = 0xFFFFFFFFu, seg_index = 0; // k-mer starts this workgroup walks
@@ -1272,7 +1576,6 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
         return;
     }
     Ctx c;
-    c.a = &a;
     c.seq = a.seq + a.off[cid];
     c.nd = a.nodes + a.node_off[cid];
     c.node_cap = (uint32_t)(a.node_off[cid + 1] - a.node_off[cid]);
@@ -1288,6 +1591,7 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
     const bool seg_open = SEG && seg_end != 0xFFFFFFFFu; // a right neighbour takes over at seg_end
 
     if (tid == 0) {
+        fill_cfg(S, a, c);
         S.seg_failed = 0;
         S.seg_busy = 0;
         S.seg_arrived = 0;
@@ -1785,14 +2089,14 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                         hash_kmer(S.ht, c.seq + first, k, S.fh, S.rh);
                         S.char_in = raw;
                         S.draft = draft;
-                        Best b;
+                        Best& b = S.edit_best;
                         b.type = r.type;
                         b.sub_base = r.sub_base;
                         b.indel_len = r.indel_len;
                         b.sup = 0;
                         for (int i = 0; i < 8; i++)
                             b.indel[i] = r.indel[i];
-                        make_edit(c, S, draft, b);
+                        make_edit(draft);
                         S.req[nxt] = REQ_NEXT;
                     }
                 }
@@ -1934,234 +2238,8 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
             continue;
         }
 
-        // ------------------------------------------------------------ REQ_SITE
-        if (tid == 0) {
-            const uint32_t want = 2 * k + 12;
-            Node hnode = nd_cached(c, S, S.hn);
-            const bool in_final = hnode.type == 0 && hnode.e == len - 1 && S.hi <= hnode.e;
-            const bool inside = hnode.type == 0 && S.hi + want - 1 <= hnode.e;
-            if (in_final || inside) {
-                S.fast_head = 1;
-                S.nz = min(want, hnode.e - S.hi + 1);
-            } else {
-                S.fast_head = 0;
-                S.nz = gather_plan(c, S, S.Z, want);
-            }
-            S.draft = to_upper((uint8_t)S.char_in);
-            S.best_key = 0;
-        }
-        __syncthreads();
-        // flags are read once, here, by everybody; thread 0 only rewrites them behind barriers
-        const uint32_t f_fast = S.fast_head, f_hash = S.need_hash, f_confirmed = S.confirmed;
-        if (f_fast) {
-            for (uint32_t i = tid; i < S.nz; i += blockDim.x) {
-                const uint32_t pos = S.hi + i;
-                S.Z[i] = pos - S.cp0 < S.cpn ? S.c_seq[pos - S.cp0] : c.seq[pos];
-            }
-            __syncthreads();
-        } else {
-            gather_fill(c, S, S.Z);
-            __syncthreads();
-        }
-        {
-            // prefix XORs of the rotated seeds of the whole window (one element per lane):
-            // PF[i] = xor_{j<i} ror^j(fwd(Z_j)), QR[i] = xor_{j<i} rol^j(rev(Z_j))
-            const uint32_t nzz = S.nz;
-            uint64_t tf = 0, tr = 0;
-            if (tid < nzz) {
-                tf = srorn(S.ht.f[fcode(S.Z[tid])], tid);
-                tr = sroln(S.ht.r[rcode(S.Z[tid])], tid);
-            }
-            const int lane = tid & 63, wave = tid >> 6;
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint64_t uf = __shfl_up(tf, o), ur = __shfl_up(tr, o);
-                if (lane >= o) {
-                    tf ^= uf;
-                    tr ^= ur;
-                }
-            }
-            if (lane == 63) {
-                S.wave_f[wave] = tf;
-                S.wave_r[wave] = tr;
-            }
-            __syncthreads();
-            uint64_t pf = 0, pr = 0;
-            for (int w = 0; w < wave; w++) {
-                pf ^= S.wave_f[w];
-                pr ^= S.wave_r[w];
-            }
-            if (tid < nzz) {
-                S.PF[tid + 1] = tf ^ pf;
-                S.QR[tid + 1] = tr ^ pr;
-            }
-            if (tid == 0) {
-                S.PF[0] = 0;
-                S.QR[0] = 0;
-            }
-            __syncthreads();
-            if (f_hash && tid == 0) {
-                // the walker jumped here: rebuild its rolling state from the window
-                S.fh = win_f(S, 0, k);
-                S.rh = win_r(S, 0, k);
-                S.char_in = S.Z[k - 1];
-                S.draft = to_upper(S.Z[k - 1]);
-            }
-            __syncthreads();
-        }
-        if (!f_confirmed) {
-            // confirm: k more k-mers, every jump-th one probed
-            uint32_t miss = 0, bad = 0;
-            if (tid < k) {
-                const uint32_t q = tid;
-                if (k + q >= S.nz)
-                    bad = 1;
-                else if (!is_accepted_u(S.Z[k + q]))
-                    bad = 1;
-            }
-            bad = block_sum(S, bad);
-            if (!bad && tid < k && tid % jump == 0)
-                miss = bf_contains(a, c.bf, win_f(S, tid + 1, k) + win_r(S, tid + 1, k)) ? 0u : 1u;
-            miss = block_sum(S, miss);
-            if (tid == 0) {
-                S.confirm_bad = bad;
-                S.confirm_missing = miss;
-                S.st_probes += bad ? 0 : (k + jump - 1) / jump;
-            }
-            __syncthreads();
-        }
-        if (!f_confirmed && (S.confirm_bad || S.confirm_missing < a.need_missing)) {
-            if (tid == 0) {
-                S.req[nxt] = REQ_NEXT;
-                S.need_hash = 0;
-            }
-            __syncthreads();
-            continue;
-        }
-
-        // substitution trials: one wave-sized slice of work per candidate base
-        if (tid == 0) {
-            S.st_sites++;
-            S.confirmed = 0;
-            S.need_hash = 0;
-            const char* s;
-            switch ((uint8_t)S.draft) {
-            case 'A': s = "TCG"; break;
-            case 'T': s = "ACG"; break;
-            case 'C': s = "ATG"; break;
-            case 'G': s = "ATC"; break;
-            case 'R': s = "TC"; break;
-            case 'Y': s = "AG"; break;
-            case 'S': s = "AT"; break;
-            case 'W': s = "CG"; break;
-            case 'K': s = "AC"; break;
-            case 'M': s = "TG"; break;
-            case 'B': s = "A"; break;
-            case 'D': s = "C"; break;
-            case 'H': s = "G"; break;
-            case 'V': s = "T"; break;
-            default: s = ""; break;
-            }
-            uint32_t n = 0;
-            for (; s[n]; n++)
-                S.subs[n] = (uint8_t)s[n];
-            S.n_sub = n;
-            for (uint32_t i = 0; i < 4; i++)
-                S.sub_in_bf[i] = S.sub_present[i] = 0;
-            S.num_del = 1;
-        }
-        __syncthreads();
-        {
-            // thread (si*64 + q): q == 63 probes the changed k-mer itself,
-            // q < k probes the k-mer after q+1 rolls when q % jump == 0
-            const uint32_t q = tid & 63;
-            for (uint32_t si = tid >> 6; si < S.n_sub; si += blockDim.x / 64) { // (128-thread workgroups: two waves for up to three substitutes)
-                const uint8_t sb = S.subs[si];
-                if (q == 63) {
-                    uint64_t fh = S.fh, rh = S.rh;
-                    changelast(S.ht, fh, rh, (uint8_t)S.draft, sb);
-                    if (bf_contains(a, c.bf, fh + rh))
-                        S.sub_in_bf[si] = 1;
-                } else if (q < k && q % jump == 0 && k + q < S.nz) {
-                    // k-mer = Z[q+1 .. q+1+k) with Z[k-1] replaced by sb: O(1) from the prefixes
-                    const uint32_t a0 = q + 1, site = k - 1;
-                    uint64_t f = win_f(S, a0, k), r = win_r(S, a0, k);
-                    if (a0 <= site) {
-                        const uint8_t old_c = S.Z[site];
-                        f ^= sroln(S.ht.f[fcode(old_c)] ^ S.ht.f[fcode(sb)], (a0 + k - 1) - site);
-                        r ^= sroln(S.ht.r[rcode(old_c)] ^ S.ht.r[rcode(sb)], site - a0);
-                    }
-                    if (bf_contains(a, c.bf, f + r))
-                        atomicAdd(&S.sub_present[si], 1u);
-                }
-            }
-        }
-        __syncthreads();
-
-        // replay the reference's control flow over the trial results (uniform)
-        Best best;
-        best.type = 0;
-        best.sup = 0;
-        best.sub_base = 0;
-        best.indel_len = 0;
-        for (uint32_t si = 0; si < S.n_sub; si++) {
-            if (!S.sub_in_bf[si])
-                continue;
-            if (tid == 0) {
-                // trial + revert leaves the UPPER-case draft base behind (:1608-1615)
-                Node tnode = nd_cached(c, S, S.tn);
-                if (tnode.type == 0) {
-                    seq_store(c, S, S.ti, (uint8_t)S.draft);
-                } else if (tnode.type == 1) {
-                    c.nd[S.tn].c = S.draft;
-                    nd_cache_drop(S);
-                }
-                S.st_probes += 1 + (k + jump - 1) / jump;
-            }
-            const uint32_t present = S.sub_present[si];
-            if (present >= a.need_edit) {
-                if (present >= best.sup) {
-                    best.type = 1;
-                    best.sub_base = S.subs[si];
-                    best.sup = present;
-                }
-                continue; // modes 0/1: a good substitution ends this base's turn
-            }
-            if (best.type != 1) {
-                __syncthreads();
-                if (tid == 0)
-                    S.best_key = 0;
-                __syncthreads();
-                indel_sweep(c, S, S.subs[si], S.num_del);
-                __syncthreads();
-                const uint32_t key = S.best_key;
-                // deletions del_from.. were consumed by this call
-                uint32_t n_del = (a.max_ins_tries > 0 && S.num_del <= a.max_del)
-                                     ? min(a.max_del - S.num_del + 1, a.max_ins_tries)
-                                     : 0u;
-                const uint32_t del_from = S.num_del;
-                __syncthreads();
-                if (tid == 0)
-                    S.num_del = del_from + n_del;
-                if (key) {
-                    const uint32_t order = key & 0xFFFF;
-                    best.sup = key >> 16;
-                    if (order & 1) {
-                        best.type = 3;
-                        best.indel_len = del_from + (order >> 1);
-                    } else {
-                        best.type = 2;
-                        best.indel_len = indel_string(S.subs[si], order >> 1, best.indel);
-                    }
-                    break; // tryIndels returned true (modes 0/1)
-                }
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            make_edit(c, S, (uint8_t)S.draft, best);
-            S.req[nxt] = REQ_NEXT;
-        }
-        __syncthreads();
+        // ------------------------------------------------------------ REQ_SITE (out of line: walk_site)
+        walk_site(nxt);
     }
 
     // ---- lay the edited contig out: every live node learns where its bytes go
@@ -3435,6 +3513,10 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     auto launch_walk = [&](unsigned grid, bool seg) {
         if (seg)
             hipLaunchKernelGGL((ntedit_walk<1, true>), dim3(grid), dim3(kWalkThreads), 0, s, a);
+        else if (walk_waves >= 6)
+            hipLaunchKernelGGL((ntedit_walk<6, false>), dim3(grid), dim3(walk_threads), 0, s, a);
+        else if (walk_waves == 5)
+            hipLaunchKernelGGL((ntedit_walk<5, false>), dim3(grid), dim3(walk_threads), 0, s, a);
         else if (walk_waves >= 4)
             hipLaunchKernelGGL((ntedit_walk<4, false>), dim3(grid), dim3(walk_threads), 0, s, a);
         else

@@ -60,7 +60,7 @@ constexpr uint32_t kBigWorkers = 256;
 constexpr int kNwWorkers = 16;
 
 enum { FWD = 0, REV = 1 };
-enum { R_FOUND = 0, R_TOO_MANY_PATHS, R_TOO_MANY_BRANCHES, R_CYCLE, R_MAX_COST, R_MEM, R_NO_PATH, R_DEFER };
+enum { R_FOUND = 0, R_TOO_MANY_PATHS, R_TOO_MANY_BRANCHES, R_CYCLE, R_MAX_COST, R_MEM, R_NO_PATH, R_DEFER, R_SIMPLE };
 enum { V_SUCCESS = 0, V_SKIP, V_ABORT };
 
 struct Gap {
@@ -899,6 +899,8 @@ __device__ int bidi_search(Search& S)
         return R_MAX_COST;
     if (S.overflow)
         return R_MEM;
+    if (S.small && S.found_n == 0 && S.n_ce == 1)
+        return R_SIMPLE; // one common edge: small_unique_path tries it without a worker's scratch
     if (S.small && (S.found_n || S.n_ce))
         return R_DEFER; // paths to enumerate: that needs a worker's scratch
     int overall = S.found_n ? R_FOUND : R_NO_PATH;
@@ -965,6 +967,99 @@ __device__ void write_merged(const CArgs& a, uint32_t gi, const uint8_t* r1, uin
         }
     a.fill_off[gi] = at;
     a.fill_len[gi] = lm;
+}
+
+// The lane-per-gap phase's own pathsToGoal for the case nearly every closed gap is (one in seven
+// searches of configs[2] ends with a path, every one of those a plain chain): ONE common edge (u, v),
+// and from u back to the start and from v on to the goal the traversal-history graphs are simple
+// chains -- every vertex on the way has exactly one successor, the end vertex has none.
+// build_paths_edge / all_paths (Graph/AllPathsSearch.h:28-104) then find exactly one path each
+// way, push every vertex once (cost = edges walked, checked against what is left of max_cost after
+// every push as the DFS does; no vertex deeper than max_depth is extended), and the gap's connecting
+// sequence is the start k-mer followed by the last base of every later vertex -- written straight
+// into the pool, so that no path has to be stored.  Anything else (a fork, a dead end, a limit, a
+// length outside [min_len, max_len]) returns false and the gap goes to a worker as before.
+__device__ bool small_unique_path(const CArgs& a, Search& S, uint32_t gi, const uint8_t* r1, uint32_t l1,
+                                  const uint8_t* r2, uint32_t l2, uint32_t sp, uint32_t gp)
+{
+    const uint32_t NONE = 0xFFFFFFFFu, k = S.k;
+    const uint32_t u = S.ce_u[0], v = S.ce_v[0];
+    if (S.cost > S.max_cost)
+        return false;
+    uint32_t cost = S.cost;
+    // chain length (vertices) from `from` to `to` in history graph gi, 0 if it is not a simple chain within the limits
+    auto chain = [&](int gi_, uint32_t from, uint32_t to) -> uint32_t {
+        const uint32_t budget = S.max_cost - cost;
+        uint32_t n = 1, cur = from, c = 0;
+        while (cur != to) {
+            const uint32_t h = S.v[cur].head[gi_];
+            if (h == NONE || S.e[h].next != NONE)
+                return 0; // dead end or fork
+            if (n - 1 >= S.max_depth[gi_])
+                return 0; // the DFS does not extend a vertex this deep
+            cur = S.e[h].to;
+            n++;
+            c++;
+            if (c > budget || n > S.nv)
+                return 0; // cost limit; (n > nv: a cycle, which a chain cannot hold -- belt and braces)
+        }
+        if (S.v[to].head[gi_] != NONE)
+            return 0; // the DFS would go on past the target
+        cost += c;
+        return n;
+    };
+    const uint32_t nL = chain(FWD, u, S.start);
+    if (!nL)
+        return false;
+    const uint32_t nR = chain(REV, v, S.goal);
+    if (!nR)
+        return false;
+    const uint32_t tot = nL + nR;
+    if (tot < S.min_len || tot > S.max_len || tot > kPathCap)
+        return false;
+    const uint32_t lc = k + tot - 1, lm = sp + lc + gp;
+    const uint64_t at = pool_alloc(a, lm);
+    if (at == ~0ULL)
+        return true; // (error flagged; nothing to write, as write_merged)
+    uint8_t* m = a.pool + at;
+    for (uint32_t i = 0; i < sp; i++)
+        m[i] = r1[i];
+    uint8_t* cons = m + sp;
+    // left part, walked from u (path index nL - 1) down to the start (index 0)
+    for (uint32_t cur = u, idx = nL - 1;; idx--) {
+        const Vert& x = S.v[cur];
+        if (idx == 0) {
+            const u128 x0 = km_load(x.km);
+            for (uint32_t i = 0; i < k; i++)
+                cons[i] = (uint8_t)("ACGT"[(uint32_t)(x0 >> (2 * (k - 1 - i))) & 3]);
+            break;
+        }
+        cons[k - 1 + idx] = (uint8_t)("ACGT"[x.km[0] & 3]);
+        cur = S.e[x.head[FWD]].to;
+    }
+    for (uint32_t cur = v, idx = nL;; idx++) {
+        const Vert& x = S.v[cur];
+        cons[k - 1 + idx] = (uint8_t)("ACGT"[x.km[0] & 3]);
+        if (cur == S.goal)
+            break;
+        cur = S.e[x.head[REV]].to;
+    }
+    for (uint32_t i = 0; i < gp; i++)
+        m[sp + lc + i] = comp_base(r2[gp - 1 - i]);
+    // maskNew(mask = 0), as write_merged
+    for (uint32_t i = 0; i < l1 && i < lm; i++)
+        if (r1[i] == m[i])
+            m[i] = up(r1[i]);
+    if (l2 <= lm)
+        for (uint32_t i = 0; i < l2; i++) {
+            const uint8_t c = comp_base(r2[l2 - 1 - i]);
+            const uint32_t pos = i + lm - l2;
+            if (c == m[pos])
+                m[pos] = up(c);
+        }
+    a.fill_off[gi] = at;
+    a.fill_len[gi] = lm;
+    return true;
 }
 
 struct SmallArena {
@@ -1098,9 +1193,17 @@ __device__ bool connect_one(const CArgs& a, Search& S, uint32_t gi, uint32_t wid
         S.found_len[0] = 1;
         S.found_n = 1;
     }
-    const int rc = bidi_search(S);
+    int rc = bidi_search(S);
     if (sm && (rc == R_DEFER || rc == R_MEM))
         return true;
+    bool written = false;
+    if (rc == R_SIMPLE) {
+        if (!small_unique_path(a, S, gi, r1, l1, r2, l2, sp, gp))
+            return true; // not the plain case after all: a worker's business
+        rc = R_FOUND;
+        S.found_n = 1;
+        written = true;
+    }
     if (!sm && a.tier == 0 && rc == R_MEM)
         return true; // outgrew the medium arena: a worker with a full one does it again (nothing counted, nothing written)
     atomicAdd(&a.stats[6], S.tests);
@@ -1118,7 +1221,9 @@ __device__ bool connect_one(const CArgs& a, Search& S, uint32_t gi, uint32_t wid
     // closing removes every gap that shares this left flank from the later k runs
     atomicMin(&a.closed_at[g.left_rep], a.ki + 1);
     atomicAdd(&a.stats[5], 1ull);
-    if (S.found_n == 1) {
+    if (written) {
+        // (small_unique_path wrote the merged sequence already)
+    } else if (S.found_n == 1) {
         const uint32_t lc = path_to_seq(S, 0, tmp);
         write_merged(a, gi, r1, l1, r2, l2, sp, gp, tmp, lc);
     } else {
