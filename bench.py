@@ -694,6 +694,7 @@ def main():
             out["stage_a"] = {"census_ms": round(k["cbf_census"]["ms"], 3), "replay_ms": round(k["cbf_local"]["ms"], 3),
                               "operations": c["a_ops"], "replayed": c.get("a_replayed", 0),
                               "replayed_found_settled": c.get("a_settled_hits", 0),
+                              "candidates_settled_by_their_kmers_count": c.get("a_counted", 0),
                               "alg_GBps": round((1 + 2 * H) * k["cbf_local"]["units"] / (sa_ms / 1e3) / 1e9, 2)}
         if name == "cbf_local" and kk["ms"]:
             # what bounds this kernel: random memory transactions, one line each -- a look-up in the

@@ -36,7 +36,7 @@ SYMBOLS = [
     "gp_jobs_polish", "gp_filter_save", "gp_filter_save_btllib", "gp_filter_load", "gp_job_write_fasta",
     "gp_sealer_consensus", "gp_device_pool_bytes", "gp_device_pool_trim",
     "gp_pipeline_create", "gp_pipeline_submit", "gp_pipeline_collect", "gp_pipeline_kernel_time",
-    "gp_pipeline_destroy", "gp_job_reset", "gp_debug_fail_alloc", "gp_debug_nthash",
+    "gp_pipeline_destroy", "gp_job_reset", "gp_debug_fail_alloc", "gp_debug_nthash", "gp_ctx_create_masked",
 ]
 
 
@@ -74,7 +74,7 @@ class Counters(C.Structure):
         "a_positions", "a_ops", "a_ordered_ops", "a_rounds", "b_scan_kmers", "b_sites",
         "b_probes", "b_edits", "c_gaps", "c_closed", "c_vertex_tests", "a_reservations",
         "c_no_start_goal", "c_no_path", "c_unique_path", "c_multiple_paths", "c_too_many_paths",
-        "c_too_many_branches", "c_max_cost", "a_replayed", "a_settled_hits")]
+        "c_too_many_branches", "c_max_cost", "a_replayed", "a_settled_hits", "a_counted")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -125,6 +125,7 @@ def load_library(path=None):
     L.gp_device_bytes_in_use.restype = C.c_uint64
     L.gp_default_params.argtypes = [C.POINTER(Params)]
     L.gp_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.gp_ctx_create_masked.argtypes = [C.c_int, u32p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.gp_ctx_destroy.argtypes = [C.c_void_p]
     L.gp_ctx_stream.restype = C.c_void_p
     L.gp_ctx_stream.argtypes = [C.c_void_p]
@@ -279,9 +280,17 @@ def partition_batches(cost, n_ranks):
 
 
 class Context:
-    def __init__(self, device=0):
+    def __init__(self, device=0, cu_mask=None):
+        """cu_mask: iterable of CU indices the context's streams may use (None: all)"""
         self._h = C.c_void_p()
-        _check(lib().gp_ctx_create(device, C.byref(self._h)))
+        if cu_mask is None:
+            _check(lib().gp_ctx_create(device, C.byref(self._h)))
+        else:
+            cus = sorted(set(int(x) for x in cu_mask))
+            words = np.zeros(max(cus) // 32 + 1, dtype=np.uint32)
+            for cu in cus:
+                words[cu // 32] |= np.uint32(1 << (cu % 32))
+            _check(lib().gp_ctx_create_masked(device, words.ctypes.data_as(u32p), words.size, C.byref(self._h)))
 
     @property
     def stream(self):

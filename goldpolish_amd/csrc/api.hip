@@ -301,8 +301,41 @@ void gp_default_params(gp_params* p)
     p->run_sealer = 1;
 }
 
+} // extern "C"
+
+namespace gp {
+int ctx_stream_create(const gp_ctx* ctx, hipStream_t* out)
+{
+    if (ctx->cu_mask.empty())
+        GP_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    else
+        GP_HIP(hipExtStreamCreateWithCUMask(out, (uint32_t)ctx->cu_mask.size(), ctx->cu_mask.data()));
+    return GP_OK;
+}
+} // namespace gp
+
+static int ctx_create(int device, const uint32_t* cu_mask, uint32_t mask_words, gp_ctx** out);
+
+extern "C" {
+
 int gp_ctx_create(int device, gp_ctx** out)
 try {
+    return ctx_create(device, nullptr, 0, out);
+} GP_CATCH("gp_ctx_create")
+
+int gp_ctx_create_masked(int device, const uint32_t* cu_mask, uint32_t mask_words, gp_ctx** out)
+try {
+    if (!cu_mask || mask_words == 0) {
+        set_error("gp_ctx_create_masked: no mask");
+        return GP_ERR_INVALID_ARG;
+    }
+    return ctx_create(device, cu_mask, mask_words, out);
+} GP_CATCH("gp_ctx_create_masked")
+
+} // extern "C"
+
+static int ctx_create(int device, const uint32_t* cu_mask, uint32_t mask_words, gp_ctx** out)
+{
     if (!out) {
         set_error("gp_ctx_create: out is NULL");
         return GP_ERR_INVALID_ARG;
@@ -322,8 +355,10 @@ try {
     if (!c)
         return GP_ERR_OOM;
     c->device = device;
+    if (cu_mask)
+        c->cu_mask.assign(cu_mask, cu_mask + mask_words);
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&c->prop, device) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        ctx_stream_create(c, &c->stream) != GP_OK) {
         set_error("gp_ctx_create: could not initialise the device");
         delete c;
         return GP_ERR_HIP;
@@ -331,7 +366,10 @@ try {
     pool_context_born(device);
     *out = c;
     return GP_OK;
-} GP_CATCH("gp_ctx_create")
+}
+
+extern "C" {
+
 
 void gp_ctx_destroy(gp_ctx* ctx)
 {

@@ -106,6 +106,9 @@ struct gp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop{};
+    // CUs the context's streams may use (gp_ctx_create_masked; empty: all of them).  Streams the
+    // stages create for themselves (the filter build's second and third) take the same mask.
+    std::vector<uint32_t> cu_mask;
     // Two pinned staging chunks for uploads (gp_job_create), allocated on first use and kept for
     // the context's life: the host fills one while the DMA engine drains the other.
     uint8_t* stage[2] = { nullptr, nullptr };
@@ -158,7 +161,7 @@ struct gp_job {
     gp::DevBuf<uint32_t> d_batch_slot;    // [n_batches] first arena slot of a batch of the grid-wide schedule
     gp::DevBuf<uint32_t> d_queue;         // cbf_local's pair counter
     // census of first touches (stage_a.hip): work buffers of a cohort, results for the whole job
-    gp::DevBuf<unsigned long long> d_cand, d_kset;
+    gp::DevBuf<unsigned long long> d_cand, d_cand2, d_kset;
     gp::DevBuf<uint8_t> d_census_cnt;
     gp::DevBuf<uint32_t> d_census_rec, d_census_over, d_census_tab32, d_pair_mode;
     gp::DevBuf<uint64_t> d_census_tab64, d_pair_bit_off;
@@ -189,6 +192,7 @@ struct gp_job {
 };
 
 namespace gp {
+int ctx_stream_create(const gp_ctx* ctx, hipStream_t* out); // a non-blocking stream with the context's CU mask
 int stage_a_prepare(gp_job* job);            // allocate work buffers
 int stage_a_run(gp_job* job);                // enqueue + drive the filter build
 void stage_a_release(gp_job* job);

@@ -89,9 +89,10 @@ struct AArgs {
     const uint32_t* batch_slot; // per batch: first arena slot of its n_k counter arrays while its group is worked on
     uint32_t* queue;     // cbf_local: next (batch, k) pair to replay
     // census (see census_scatter): per queue entry of cbf_local
-    const uint32_t* pair_mode;              // 1: only the operations marked in `cand` are replayed, thresholds one lower (2: census overflowed)
+    const uint32_t* pair_mode;              // 1: only the operations marked in `cand` are replayed, thresholds one lower (2: census overflowed; 3: those marked in `cand2`)
     const uint64_t* pair_bit_off;           // first bit of the pair in `cand` (multiple of 64)
     const unsigned long long* cand;         // bit (pair_bit_off + position in the batch's reads)
+    const unsigned long long* cand2;        // pair_mode 3: the candidates left for the replay once the private k-mers have been counted (ckc_apply)
     // census pairs: the k-mers cbf_local has seen settled for good (see there), a table per workgroup
     unsigned long long* kset;
     uint32_t kset_mask;                     // entries per table - 1 (0: none)
@@ -129,7 +130,7 @@ struct AArgs {
     const uint32_t* batch_order; // batches in the order the groups take them (long ones first, then the cbf_local ones)
     uint32_t grp_first, grp_n, tiles_per_batch;
     uint64_t off, slice;
-    unsigned long long* stats; // [0] positions [1] ops [2] ordered ops [3] tail / local rounds [4] reservation atomics [5] replayed [6] settled-table hits
+    unsigned long long* stats; // [0] positions [1] ops [2] ordered ops [3] tail / local rounds [4] reservation atomics [5] replayed [6] settled-table hits [7] candidate operations settled by their k-mer's count (ckc_apply)
 };
 
 __device__ inline uint32_t resv_slot(const AArgs& a, uint32_t bits, uint32_t stream, uint32_t idx)
@@ -1221,6 +1222,385 @@ __global__ __launch_bounds__(256) void census_pack(AArgs a, CensusArgs c)
     }
 }
 
+// ------------------------------------------------- candidates by k-mer: most of the replay is a count
+// The candidates of a census pair are a conservative-update replay among themselves (census_scatter).
+// Call a candidate k-mer PRIVATE when none of its counters is touched by a candidate of a different
+// k-mer: its counters then only ever see its own copies, its i-th candidate copy finds all of them at
+// min(i, thr') and goes into the filter iff i >= thr' - 1, so the k-mer is in the Bloom filter iff it has
+// >= thr - 1 candidate copies (thr' = thr - 1 the candidates' threshold, uniform over the pair) -- a
+// count, no replay.  The k-mers that are not private are closed under "shares a counter": they are
+// replayed by themselves, on the arena slot as before.  On 25 kbp contigs at 40x, 91-93 % of the
+// candidate operations belong to private k-mers (tests/test_private_kmer_model.py checks the closed form
+// against the serial replay and measures the fraction); what cbf_local replays goes from 23 % of the
+// operations to under 2 %, and with it most of its random counter transactions.
+// Streaming passes, all in the record space the census has just finished with:
+//   ckc_scatter  candidates (64-bit hash, position) into hash buckets of their pair: LDS staging, whole
+//                chunks per bucket and half-stretch, one cursor atomic per chunk;
+//   ckc_group    a workgroup per bucket: an LDS hash set of its distinct k-mers (a slot each, written back
+//                into the records); every new k-mer sends its counters, tagged (bucket, slot), to the
+//                group of their counter range;
+//   ckc_share    a workgroup per counter group: an exact LDS table counter -> k-mer; a second k-mer on a
+//                counter flags both (a bit per (bucket, slot));
+//   ckc_apply    a workgroup per bucket again: copies per slot; unflagged with enough copies -> the
+//                filter's bits; flagged -> their copies' bits in the SECOND candidate bitmap, which is
+//                what cbf_local replays for the pair (pair_mode 3).
+// Anything that does not fit (a bucket, a table, a group) sets the pair's overflow word and the pair
+// keeps the whole candidate replay.
+__device__ inline uint32_t select64(unsigned long long w, uint32_t r); // (below, with cbf_local)
+
+constexpr uint32_t kCkcSlots = 2048;        // distinct k-mers a bucket's LDS set holds (load <= 7/8)
+constexpr uint32_t kCkcShareSlots = 8192;   // (counter, k-mer) entries a counter group's LDS table holds (load <= 3/4)
+constexpr uint32_t kCkcStage = 3072;        // records staged in LDS per half-stretch by ckc_scatter (16 bytes each)
+constexpr uint32_t kCkcStageE = 5120;       // entries staged in LDS by ckc_group (8 bytes each)
+constexpr uint32_t kCkcMaxBuckets = 128, kCkcMaxGroups = 256;
+constexpr uint32_t kCkcHdrWords = 1024;     // [0,256) bucket cursors, [256,512) group cursors, [512] overflow
+constexpr uint32_t kCkcHalf = kCStretch / 2;
+
+struct CkcArgs {
+    const uint32_t* pair_nb;    // [pairs] hash buckets of the pair (a power of two; 0: not eligible, the pair keeps the whole candidate replay)
+    const uint32_t* pair_capb;  // [pairs] records a bucket holds
+    const uint32_t* pair_capg;  // [pairs] entries a counter group holds
+    const uint32_t* pair_need;  // [pairs] candidate copies from which a private k-mer is in the filter (thr - 1)
+    uint32_t gshift, n_groups;  // a counter group holds 1 << gshift counters; groups per pair
+    unsigned long long* cand2;  // the candidates that still need the replay (same bit positions as `cand`)
+};
+
+struct CkcRegion {
+    uint32_t* cur_b;       // bucket cursors
+    uint32_t* cur_g;       // group cursors
+    uint32_t* over;        // != 0: the pair keeps the whole candidate replay
+    uint32_t* flags;       // [nb][kCkcSlots / 32]: k-mers that share a counter with another
+    uint4* rec;            // [nb][capb]: {hash lo, hash hi, position in the pair, slot}
+    unsigned long long* ent; // [n_groups][capg]: (counter within its group << 32) | (bucket << 11 | slot)
+};
+
+__device__ inline CkcRegion ckc_region(const CensusArgs& c, const CkcArgs& g, uint32_t pair)
+{
+    uint32_t* base = c.rec + c.pair_rec_off[pair];
+    const uint32_t nb = g.pair_nb[pair];
+    CkcRegion r;
+    r.cur_b = base;
+    r.cur_g = base + 256;
+    r.over = base + 512;
+    r.flags = base + kCkcHdrWords;
+    r.rec = reinterpret_cast<uint4*>(base + kCkcHdrWords + nb * (kCkcSlots / 32));
+    r.ent = reinterpret_cast<unsigned long long*>(r.rec + (uint64_t)nb * g.pair_capb[pair]);
+    return r;
+}
+
+__device__ inline uint64_t ckc_mix(uint64_t base) { return base * 0x9E3779B97F4A7C15ULL; }
+
+__global__ __launch_bounds__(256) void ckc_init(CensusArgs c, CkcArgs g, uint32_t n_pairs)
+{
+    const uint32_t pair = blockIdx.x;
+    if (pair >= n_pairs || !g.pair_nb[pair])
+        return;
+    uint32_t* base = c.rec + c.pair_rec_off[pair];
+    const uint32_t n = kCkcHdrWords + g.pair_nb[pair] * (kCkcSlots / 32);
+    for (uint32_t i = threadIdx.x; i < n; i += 256)
+        base[i] = 0;
+    if (threadIdx.x == 0 && c.overflow[pair])
+        base[512] = 1u; // the census gave the pair up: nothing to group
+}
+
+// A workgroup per stretch (the census's table of stretches): the candidates of each half-stretch,
+// one per lane and turn, hashed from the table of rotated seeds and staged per bucket.
+__global__ __launch_bounds__(256) void ckc_scatter(AArgs a, CensusArgs c, CkcArgs g)
+{
+    __shared__ uint8_t codes[kCStretch + kHalo];
+    __shared__ uint64_t seed_t[kSeedTableWords];
+    __shared__ uint4 stage[kCkcStage];
+    __shared__ uint32_t s_cnt[kCkcMaxBuckets], s_base[kCkcMaxBuckets];
+    __shared__ unsigned long long s_cw[kCkcHalf / 64];
+    __shared__ uint32_t s_cpre[kCkcHalf / 64 + 1];
+    const uint32_t pair = c.wg_pair[blockIdx.x];
+    const uint32_t nb = g.pair_nb[pair];
+    if (!nb)
+        return;
+    const CkcRegion R = ckc_region(c, g, pair);
+    if (*R.over)
+        return;
+    const uint32_t b = c.pair_batch[pair], ki = c.pair_ki[pair], k = a.kc[ki].k;
+    const uint64_t b_start = a.batch_pos[b], b_end = a.batch_pos[b + 1];
+    const uint64_t pos0 = c.wg_pos0[blockIdx.x];
+    const uint64_t stretch_end = min(b_end, pos0 + (uint64_t)kCStretch);
+    const uint32_t capb = g.pair_capb[pair], cap_s = kCkcStage / nb, tid = threadIdx.x;
+    fill_seed_table(seed_t);
+    for (uint32_t i = tid; i < kCStretch + kHalo; i += 256) {
+        const uint64_t p = pos0 + i;
+        codes[i] = base_code(p < a.n_pos ? a.reads[p] : (uint8_t)'\n');
+    }
+    if (tid < nb)
+        s_cnt[tid] = 0;
+    const unsigned long long* const cand = c.cand + ((c.pair_bit_off[pair] + (pos0 - b_start)) >> 6);
+    for (uint32_t half = 0; half < 2; half++) {
+        const uint64_t h0 = pos0 + (uint64_t)half * kCkcHalf;
+        if (h0 >= stretch_end)
+            break; // uniform
+        __syncthreads(); // codes, the table and the counters are set; the half before is flushed
+        if (tid < kCkcHalf / 64) { // one wave: the half's candidate words and their prefix counts
+            const uint64_t first = h0 + (uint64_t)tid * 64;
+            unsigned long long w = first < stretch_end ? cand[half * (kCkcHalf / 64) + tid] : 0ull; // (nothing is read past the pair's bits)
+            if (first < stretch_end && stretch_end - first < 64)
+                w &= (1ULL << (stretch_end - first)) - 1;
+            s_cw[tid] = w;
+            const uint32_t cnt = (uint32_t)__popcll(w);
+            uint32_t inc = cnt;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = (uint32_t)__shfl_up((int)inc, o);
+                if ((int)tid >= o)
+                    inc += u;
+            }
+            s_cpre[tid] = inc - cnt;
+            if (tid == kCkcHalf / 64 - 1)
+                s_cpre[kCkcHalf / 64] = inc;
+        }
+        __syncthreads();
+        const uint32_t n_c = s_cpre[kCkcHalf / 64];
+        for (uint32_t ci = tid; ci < n_c; ci += 256) {
+            uint32_t wlo = 0;
+            for (uint32_t step = kCkcHalf / 128; step; step >>= 1)
+                if (s_cpre[wlo + step] <= ci)
+                    wlo += step;
+            const uint32_t prel = half * kCkcHalf + wlo * 64 + select64(s_cw[wlo], ci - s_cpre[wlo]);
+            uint64_t fh = 0, rh = 0;
+            int no_bad = -1; // a candidate is a k-mer: no byte of it is bad
+            kmer_hash_from_table(seed_t, codes + prel, k, fh, rh, no_bad);
+            const uint64_t base = fh + rh;
+            const uint32_t bkt = (uint32_t)(ckc_mix(base) >> 56) & (nb - 1u);
+            const uint4 rec = make_uint4((uint32_t)base, (uint32_t)(base >> 32), (uint32_t)(pos0 + prel - b_start), 0u);
+            const uint32_t r = atomicAdd(&s_cnt[bkt], 1u);
+            if (r < cap_s) {
+                stage[bkt * cap_s + r] = rec;
+            } else { // more of one bucket than the staging holds: straight to memory
+                const uint32_t at = atomicAdd(&R.cur_b[bkt], 1u);
+                if (at < capb)
+                    R.rec[(uint64_t)bkt * capb + at] = rec;
+                else
+                    *R.over = 1u;
+            }
+        }
+        __syncthreads();
+        if (tid < nb) {
+            const uint32_t n = min(s_cnt[tid], cap_s);
+            uint32_t at = n ? atomicAdd(&R.cur_b[tid], n) : 0u;
+            if (at + n > capb) {
+                *R.over = 1u;
+                at = 0xFFFFFFFFu;
+            }
+            s_base[tid] = at;
+        }
+        __syncthreads();
+        for (uint32_t idx = tid; idx < nb * cap_s; idx += 256) {
+            const uint32_t bkt = idx / cap_s, i = idx - bkt * cap_s;
+            if (i < min(s_cnt[bkt], cap_s) && s_base[bkt] != 0xFFFFFFFFu)
+                R.rec[(uint64_t)bkt * capb + s_base[bkt] + i] = stage[idx];
+        }
+        __syncthreads();
+        if (tid < nb)
+            s_cnt[tid] = 0;
+    }
+}
+
+// A workgroup per (pair, bucket): the bucket's distinct k-mers.
+__global__ __launch_bounds__(256) void ckc_group(AArgs a, CensusArgs c, CkcArgs g, uint32_t span)
+{
+    __shared__ unsigned long long keys[kCkcSlots];
+    __shared__ unsigned long long stage[kCkcStageE];
+    __shared__ uint32_t s_cnt[kCkcMaxGroups], s_base[kCkcMaxGroups], s_ndist;
+    const uint32_t pair = blockIdx.x / span, bkt = blockIdx.x % span, tid = threadIdx.x; // (a 1-D grid: pairs x the most buckets a pair has)
+    const uint32_t nb = g.pair_nb[pair];
+    if (bkt >= nb)
+        return;
+    const CkcRegion R = ckc_region(c, g, pair);
+    if (*R.over)
+        return;
+    const uint32_t capb = g.pair_capb[pair], capg = g.pair_capg[pair];
+    const uint32_t n = R.cur_b[bkt]; // (<= capb: a chunk that did not fit set the overflow word)
+    const uint32_t ng = g.n_groups, cap_s = kCkcStageE / ng, gmask = (1u << g.gshift) - 1u;
+    const uint32_t k = a.kc[c.pair_ki[pair]].k;
+    const unsigned long long EMPTY = ~0ull;
+    for (uint32_t i = tid; i < kCkcSlots; i += 256)
+        keys[i] = EMPTY;
+    for (uint32_t i = tid; i < ng; i += 256)
+        s_cnt[i] = 0;
+    if (tid == 0)
+        s_ndist = 0;
+    __syncthreads();
+    uint4* const rec = R.rec + (uint64_t)bkt * capb;
+    bool bad = false;
+    for (uint32_t i = tid; i < n; i += 256) {
+        const uint4 r = rec[i];
+        const unsigned long long key = ((unsigned long long)r.y << 32) | r.x;
+        if (key == EMPTY) {
+            bad = true; // (the one hash the set cannot hold)
+            continue;
+        }
+        uint32_t sl = (uint32_t)(ckc_mix(key) >> 40) & (kCkcSlots - 1u);
+        bool fresh = false, placed = false;
+        for (uint32_t probe = 0; probe < kCkcSlots; probe++, sl = (sl + 1u) & (kCkcSlots - 1u)) {
+            const unsigned long long old = atomicCAS(&keys[sl], EMPTY, key);
+            if (old == EMPTY) {
+                fresh = placed = true;
+                break;
+            }
+            if (old == key) {
+                placed = true;
+                break;
+            }
+        }
+        if (!placed) {
+            bad = true;
+            continue;
+        }
+        rec[i].w = sl;
+        if (fresh) {
+            if (atomicAdd(&s_ndist, 1u) >= kCkcSlots / 8 * 7)
+                bad = true;
+            const uint32_t ref = (bkt << 11) | sl;
+            for (uint32_t h = 0; h < a.hash_num; h++) {
+                const uint32_t ix = (uint32_t)fastmod(h ? ext_hash(key, k, h) : key, a.cbf_mod);
+                const uint32_t grp = ix >> g.gshift;
+                const unsigned long long e = ((unsigned long long)(ix & gmask) << 32) | ref;
+                const uint32_t q = atomicAdd(&s_cnt[grp], 1u);
+                if (q < cap_s) {
+                    stage[grp * cap_s + q] = e;
+                } else {
+                    const uint32_t at = atomicAdd(&R.cur_g[grp], 1u);
+                    if (at < capg)
+                        R.ent[(uint64_t)grp * capg + at] = e;
+                    else
+                        bad = true;
+                }
+            }
+        }
+    }
+    if (bad)
+        *R.over = 1u;
+    __syncthreads();
+    for (uint32_t grp = tid; grp < ng; grp += 256) {
+        const uint32_t m = min(s_cnt[grp], cap_s);
+        uint32_t at = m ? atomicAdd(&R.cur_g[grp], m) : 0u;
+        if (at + m > capg) {
+            *R.over = 1u;
+            at = 0xFFFFFFFFu;
+        }
+        s_base[grp] = at;
+    }
+    __syncthreads();
+    for (uint32_t idx = tid; idx < ng * cap_s; idx += 256) {
+        const uint32_t grp = idx / cap_s, i = idx - grp * cap_s;
+        if (i < min(s_cnt[grp], cap_s) && s_base[grp] != 0xFFFFFFFFu)
+            R.ent[(uint64_t)grp * capg + s_base[grp] + i] = stage[idx];
+    }
+}
+
+// A workgroup per (pair, counter group): which counters do two different candidate k-mers touch?
+__global__ __launch_bounds__(256) void ckc_share(CensusArgs c, CkcArgs g)
+{
+    __shared__ unsigned long long tab[kCkcShareSlots];
+    const uint32_t pair = blockIdx.x / g.n_groups, grp = blockIdx.x % g.n_groups, tid = threadIdx.x;
+    if (!g.pair_nb[pair] || grp >= g.n_groups)
+        return;
+    const CkcRegion R = ckc_region(c, g, pair);
+    if (*R.over)
+        return;
+    const uint32_t capg = g.pair_capg[pair];
+    const uint32_t n = R.cur_g[grp];
+    if (n > kCkcShareSlots / 4 * 3) {
+        if (tid == 0)
+            *R.over = 1u;
+        return;
+    }
+    const unsigned long long EMPTY = ~0ull;
+    for (uint32_t i = tid; i < kCkcShareSlots; i += 256)
+        tab[i] = EMPTY;
+    __syncthreads();
+    const unsigned long long* const ent = R.ent + (uint64_t)grp * capg;
+    for (uint32_t i = tid; i < n; i += 256) {
+        const unsigned long long e = ent[i];
+        const uint32_t key = (uint32_t)(e >> 32), ref = (uint32_t)e;
+        uint32_t sl = (key * 0x9E3779B1u) >> (32 - 13);
+        for (uint32_t probe = 0; probe < kCkcShareSlots; probe++, sl = (sl + 1u) & (kCkcShareSlots - 1u)) {
+            const unsigned long long old = atomicCAS(&tab[sl], EMPTY, e);
+            if (old == EMPTY)
+                break;
+            if ((uint32_t)(old >> 32) == key) {
+                const uint32_t other = (uint32_t)old;
+                if (other != ref) { // two k-mers on one counter: neither is private
+                    atomicOr(&R.flags[(ref >> 11) * (kCkcSlots / 32) + ((ref & 2047u) >> 5)], 1u << (ref & 31u));
+                    atomicOr(&R.flags[(other >> 11) * (kCkcSlots / 32) + ((other & 2047u) >> 5)], 1u << (other & 31u));
+                }
+                break;
+            }
+        }
+    }
+}
+
+// A workgroup per (pair, bucket): the count for the private k-mers, the second bitmap for the others.
+__global__ __launch_bounds__(256) void ckc_apply(AArgs a, CensusArgs c, CkcArgs g, uint32_t span)
+{
+    __shared__ uint32_t cnt[kCkcSlots], hlo[kCkcSlots], hhi[kCkcSlots], flg[kCkcSlots / 32];
+    __shared__ unsigned long long s_private;
+    const uint32_t pair = blockIdx.x / span, bkt = blockIdx.x % span, tid = threadIdx.x;
+    const uint32_t nb = g.pair_nb[pair];
+    if (bkt >= nb)
+        return;
+    const CkcRegion R = ckc_region(c, g, pair);
+    if (*R.over)
+        return; // the pair keeps the whole candidate replay (pair_mode stays 1)
+    const uint32_t capb = g.pair_capb[pair], n = R.cur_b[bkt], need = g.pair_need[pair];
+    const uint32_t b = c.pair_batch[pair], ki = c.pair_ki[pair], k = a.kc[ki].k, stream = b * a.n_k + ki;
+    for (uint32_t i = tid; i < kCkcSlots; i += 256)
+        cnt[i] = 0;
+    if (tid < kCkcSlots / 32)
+        flg[tid] = R.flags[bkt * (kCkcSlots / 32) + tid];
+    if (tid == 0)
+        s_private = 0;
+    __syncthreads();
+    const uint4* const rec = R.rec + (uint64_t)bkt * capb;
+    for (uint32_t i = tid; i < n; i += 256) {
+        const uint4 r = rec[i];
+        if (atomicAdd(&cnt[r.w], 1u) == 0u) { // (every record of a slot carries the same hash)
+            hlo[r.w] = r.x;
+            hhi[r.w] = r.y;
+        }
+    }
+    __syncthreads();
+    unsigned long long mine = 0;
+    for (uint32_t sl = tid; sl < kCkcSlots; sl += 256) {
+        const uint32_t m = cnt[sl];
+        if (!m || ((flg[sl >> 5] >> (sl & 31u)) & 1u))
+            continue;
+        mine += m;
+        if (m >= need) {
+            const uint64_t base = ((uint64_t)hhi[sl] << 32) | hlo[sl];
+            uint64_t hv[kMaxHash];
+            hv[0] = base;
+            for (uint32_t i = 1; i < a.hash_num; i++)
+                hv[i] = ext_hash(base, k, i);
+            bf_insert(a, stream, hv);
+        }
+    }
+    if (mine)
+        atomicAdd(&s_private, mine);
+    const uint64_t bit0 = c.pair_bit_off[pair];
+    for (uint32_t i = tid; i < n; i += 256) {
+        const uint4 r = rec[i];
+        if ((flg[r.w >> 5] >> (r.w & 31u)) & 1u) {
+            const uint64_t bit = bit0 + r.z;
+            atomicOr(&g.cand2[bit >> 6], 1ULL << (bit & 63));
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (s_private)
+            atomicAdd(&a.stats[7], s_private); // candidate operations settled by their k-mer's count
+        if (bkt == 0)
+            c.pair_mode[c.pair_queue[pair]] = 3u; // cbf_local replays the second bitmap's candidates
+    }
+}
+
 // ---- many small filters: one workgroup per (batch, k) pair replays its operations alone.
 // Nobody else touches the pair's counters, so the whole ordering problem stays inside the
 // workgroup: a tile of 512 consecutive positions is hashed, what is settled goes straight
@@ -1328,6 +1708,7 @@ constexpr int kLPer = 1;               // ... one per lane: 512-thread workgroup
 constexpr int kLBlock = kLTile / kLPer; // at 128 registers 16 waves per CU.  (Two operations per lane in 256-thread
                                         // workgroups -- 8 waves per CU -- took 0.54 s for configs[2]'s replay, this 0.48 s.)
 constexpr int kLWin = 2048;            // census pairs: positions whose candidates are gathered at a time
+constexpr int kLWinSparse = 8192;      // ... where only the candidates of shared k-mers are left (pair_mode 3: under 2 % of the positions)
 constexpr int kLocalSlotBits = 12;
 constexpr int kLocalSlots = 1 << kLocalSlotBits; // >= 2 x the counter touches of a tile (hash_num <= 4)
 constexpr uint32_t kLocalEmpty = 0xFFFFFFFFu;
@@ -1345,14 +1726,14 @@ __device__ inline void kset_put(unsigned long long* kset, uint32_t* s_kbits, uin
 
 __global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first, uint32_t n_pairs) // two 8-wave workgroups per CU: <= 128 VGPRs
 {
-    __shared__ uint8_t codes[kLWin + kHalo];
+    __shared__ uint8_t codes[kLWinSparse + kHalo];
     __shared__ uint64_t seed_t[kSeedTableWords];
     __shared__ uint32_t keys[kLocalSlots]; // counter index held by the slot
     __shared__ uint32_t vals[kLocalSlots]; // earliest waiting operation of the tile on that counter
     __shared__ unsigned long long s_stats[7]; // [5]: operations replayed (all of a plain pair, the candidates of a census pair), [6]: settled-table hits
     __shared__ uint32_t s_kbits[kLSetBits / 32];    // census: a bit per k-mer hash that has gone into the settled table
-    __shared__ unsigned long long s_cw[kLWin / 64]; // census: candidate bits of the window ...
-    __shared__ uint32_t s_cpre[kLWin / 64], s_ncand;   // ... candidates before each word, and in all
+    __shared__ unsigned long long s_cw[kLWinSparse / 64]; // census: candidate bits of the window ...
+    __shared__ uint32_t s_cpre[kLWinSparse / 64], s_ncand, s_wtot[2];   // ... candidates before each word, and in all
     // This workgroup's arena slot for the whole launch: the counting filter of whichever pair it
     // is replaying.  Pairs come from a queue (longest batches first), so the grid is as large as
     // the chip holds and no larger, and a short pair's workgroup goes on to the next one instead
@@ -1398,8 +1779,9 @@ __global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first,
     // census: only the candidates are replayed, every counter they see is already at level 1, so
     // the array holds level - 1 and every threshold is one lower (see census_scatter)
     const uint32_t pmode = a.pair_mode ? a.pair_mode[pair] : 0u; // 0 plain, 1 census, 2 plain after a census that overflowed
-    const uint32_t census = pmode == 1u ? 1u : 0u;
-    const unsigned long long* const cand_bits = census ? a.cand + (a.pair_bit_off[pair] >> 6) : nullptr;
+    const uint32_t census = (pmode == 1u || pmode == 3u) ? 1u : 0u;
+    const unsigned long long* const cand_bits = census ? (pmode == 3u ? a.cand2 : a.cand) + (a.pair_bit_off[pair] >> 6) : nullptr;
+    const uint32_t win = pmode == 3u ? (uint32_t)kLWinSparse : (uint32_t)kLWin, n_words = win / 64u;
     // Counter bytes carry the pair's epoch in their upper bits (ctr_vbits value bits below it: no
     // counter passes its threshold): a byte whose tag is not the current pair's reads as zero, so
     // the slot is cleared once per 2^(8 - vbits) - 1 pairs, not before every pair -- clearing 10 MiB
@@ -1533,41 +1915,52 @@ __global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first,
                 if (next0 >= b_end)
                     break;
                 win0 = next0;
-                next0 += kLWin;
+                next0 += win;
                 // the window's bases and its candidate bits in one round trip (the loads first, all
                 // in flight together, then the stores)
                 {
-                    constexpr int kPer = (kLWin + kHalo + kLBlock - 1) / kLBlock;
+                    constexpr int kPer = (kLWinSparse + kHalo + kLBlock - 1) / kLBlock;
                     uint8_t raw[kPer];
 #pragma unroll
                     for (int q = 0; q < kPer; q++) {
                         const uint64_t p = win0 + (uint64_t)(q * kLBlock) + threadIdx.x;
-                        raw[q] = p < a.n_pos ? a.reads[p] : (uint8_t)'\n';
+                        raw[q] = (q * kLBlock + (int)threadIdx.x < (int)win + kHalo && p < a.n_pos) ? a.reads[p] : (uint8_t)'\n';
                     }
 #pragma unroll
                     for (int q = 0; q < kPer; q++)
-                        if (q * kLBlock + (int)threadIdx.x < kLWin + kHalo)
+                        if (q * kLBlock + (int)threadIdx.x < (int)win + kHalo)
                             codes[q * kLBlock + threadIdx.x] = base_code(raw[q]);
                 }
-                if (threadIdx.x < kLWin / 64) { // lanes 0..31 of wave 0
-                    unsigned long long w = cand_bits[((win0 - b_start) >> 6) + threadIdx.x];
-                    const uint64_t first = win0 + (uint64_t)threadIdx.x * 64; // bits past the batch are not the census's
-                    if (first >= b_end)
-                        w = 0;
-                    else if (b_end - first < 64)
-                        w &= (1ULL << (b_end - first)) - 1;
-                    s_cw[threadIdx.x] = w;
+                if (threadIdx.x < 128) { // waves 0 and 1: a word per lane (32 words of a plain census window, 128 of a sparse one)
+                    unsigned long long w = 0;
+                    if (threadIdx.x < n_words) {
+                        const uint64_t first = win0 + (uint64_t)threadIdx.x * 64; // bits past the batch are not the census's
+                        if (first < b_end) {
+                            w = cand_bits[((win0 - b_start) >> 6) + threadIdx.x];
+                            if (b_end - first < 64)
+                                w &= (1ULL << (b_end - first)) - 1;
+                        }
+                        s_cw[threadIdx.x] = w;
+                    }
                     const uint32_t cnt = (uint32_t)__popcll(w);
                     uint32_t inc = cnt;
-                    for (int o = 1; o < kLWin / 64; o <<= 1) {
+                    for (int o = 1; o < 64; o <<= 1) {
                         const uint32_t u = (uint32_t)__shfl_up((int)inc, o);
-                        if ((int)threadIdx.x >= o)
+                        if ((int)(threadIdx.x & 63) >= o)
                             inc += u;
                     }
-                    s_cpre[threadIdx.x] = inc - cnt;
-                    if (threadIdx.x == kLWin / 64 - 1)
-                        s_ncand = inc;
+                    if ((threadIdx.x & 63) == 63)
+                        s_wtot[threadIdx.x >> 6] = inc;
+                    if (threadIdx.x < 64)
+                        s_cpre[threadIdx.x] = inc - cnt; // (the second wave's words get the first wave's total below)
+                    else if (threadIdx.x < n_words)
+                        s_cpre[threadIdx.x] = inc - cnt;
                 }
+                __syncthreads();
+                if (threadIdx.x >= 64 && threadIdx.x < n_words)
+                    s_cpre[threadIdx.x] += s_wtot[0];
+                if (threadIdx.x == 0)
+                    s_ncand = s_wtot[0] + (n_words > 64 ? s_wtot[1] : 0u);
                 __syncthreads();
                 n_c = s_ncand;
                 c0 = 0;
@@ -1588,7 +1981,7 @@ __global__ __launch_bounds__(kLBlock, 4) void cbf_local(AArgs a, uint32_t first,
                 continue;
             // the ci-th candidate of the window: its word, then its bit
             uint32_t wlo = 0;
-            for (uint32_t step = kLWin / 128; step; step >>= 1)
+            for (uint32_t step = n_words / 2; step; step >>= 1)
                 if (s_cpre[wlo + step] <= ci)
                     wlo += step;
             const uint32_t prel = wlo * 64 + select64(s_cw[wlo], ci - s_cpre[wlo]);
@@ -1878,8 +2271,9 @@ int stage_a_prepare(gp_job* job)
         GP_HIP(hipEventCreateWithFlags(&job->a_ev_b[i], hipEventDisableTiming));
     }
     GP_HIP(hipEventCreateWithFlags(&job->a_ev_init, hipEventDisableTiming));
-    GP_HIP(hipStreamCreateWithFlags(&job->a_stream2, hipStreamNonBlocking));
-    GP_HIP(hipStreamCreateWithFlags(&job->a_stream3, hipStreamNonBlocking));
+    int rcs;
+    if ((rcs = ctx_stream_create(job->ctx, &job->a_stream2)) != GP_OK || (rcs = ctx_stream_create(job->ctx, &job->a_stream3)) != GP_OK)
+        return rcs;
     for (hipEvent_t& e : job->a_ev_census)
         GP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return GP_OK;
@@ -1919,6 +2313,7 @@ void stage_a_release(gp_job* job)
     job->d_batch_slot.release();
     job->d_queue.release();
     job->d_cand.release();
+    job->d_cand2.release();
     job->d_kset.release();
     job->d_census_cnt.release();
     job->d_census_rec.release();
@@ -2094,6 +2489,8 @@ int stage_a_run(gp_job* job)
     // census tables: host copies stay alive until the stream has been synchronised at the end
     struct Cohort {
         std::vector<uint32_t> wg_pair, pair_batch, pair_ki, pair_nst, pair_queue, tab32;
+        std::vector<uint32_t> ckc_nb, ckc_capb, ckc_capg, ckc_need; // candidates by k-mer (ckc_*): per pair
+        uint32_t ckc_max_nb = 0;
         std::vector<uint64_t> wg_pos0, pair_rec_off, pair_cnt_off, pair_bit_off, tab64;
     };
     std::vector<Cohort> cohorts;
@@ -2126,6 +2523,7 @@ int stage_a_run(gp_job* job)
         a.pair_mode = nullptr;
         a.pair_bit_off = nullptr;
         a.cand = nullptr;
+        a.cand2 = nullptr;
         // counter ranges: a power of two wide, at most kCBuckets of them
         const bool wide = env_u64("GP_STAGE_A_CENSUS_WIDE", 1) != 0; // 32-byte groups of records (see kCBucketsWide)
         const uint64_t scatter_span = std::max<uint64_t>(1, env_u64("GP_STAGE_A_SCATTER_SPAN", 4)); // stretches per census_scatter workgroup
@@ -2150,6 +2548,28 @@ int stage_a_run(gp_job* job)
             const uint64_t rec_budget = (env_u64("GP_STAGE_A_CENSUS_MB", 16384) << 20) / 4 / n_sets; // (4-byte) record slots of a cohort
             h_pair_mode.assign(n_pairs, 0);
             h_pair_bit_off.assign(n_pairs, 0);
+            // candidates by k-mer (GP_STAGE_A_CKC=0: every candidate is replayed, as before round 4)
+            const bool ckc_on = env_u64("GP_STAGE_A_CKC", 1) != 0 && p.hash_num <= 4;
+            std::vector<uint8_t> batch_uniform_thr(job->n_batches, 0);
+            std::vector<uint32_t> batch_thr_seg(job->n_batches, 0); // a contig of the batch that has reads
+            for (uint32_t bi = 0; bi < job->n_batches; bi++) {
+                bool first_seen = false, uniform = true;
+                for (uint32_t cc = job->h_batch_contig_begin[bi]; cc < job->h_batch_contig_begin[bi + 1]; cc++) {
+                    if (job->h_seg_start[cc + 1] == job->h_seg_start[cc])
+                        continue;
+                    if (!first_seen) {
+                        first_seen = true;
+                        batch_thr_seg[bi] = cc;
+                    } else if (job->h_contig_thr[cc] != job->h_contig_thr[batch_thr_seg[bi]]) {
+                        uniform = false;
+                    }
+                }
+                batch_uniform_thr[bi] = first_seen && uniform;
+            }
+            uint32_t ckc_gshift = 2;
+            while (((p.cbf_bytes + (1ull << ckc_gshift) - 1) >> ckc_gshift) > 128)
+                ckc_gshift++;
+            const uint32_t ckc_groups = (uint32_t)((p.cbf_bytes + (1ull << ckc_gshift) - 1) >> ckc_gshift);
             uint64_t bits = 0, max_rec = 0, max_cnt = 0, max_pairs = 0, max_wg = 0;
             Cohort cur;
             uint64_t cur_rec = 0, cur_cnt = 0;
@@ -2186,6 +2606,28 @@ int stage_a_run(gp_job* job)
                     cur.pair_rec_off.push_back(cur_rec);
                     cur.pair_cnt_off.push_back(cur_cnt);
                     cur.pair_bit_off.push_back(bits);
+                    {
+                        // candidates by k-mer (ckc_scatter ...): for pairs with ONE threshold (the closed form
+                        // needs it; a batch of one contig always has), of up to 2 M positions, whose record
+                        // space -- free again once census_pack has read it -- holds the buckets
+                        uint32_t nb = 0, capb = 0, capg = 0;
+                        if (ckc_on && batch_uniform_thr[b] && pos <= (1ull << 21)) {
+                            nb = 16;
+                            while (nb < kCkcMaxBuckets && (uint64_t)nb * 16384 < pos)
+                                nb *= 2;
+                            capb = (uint32_t)((double)pos * 0.75 * 1.3 / nb) + 64;
+                            capg = (uint32_t)((double)pos * 0.08 * p.hash_num * 1.6 / ckc_groups) + 64;
+                            const uint64_t need_words = kCkcHdrWords + (uint64_t)nb * (kCkcSlots / 32) + (uint64_t)nb * capb * 4 +
+                                                        (uint64_t)ckc_groups * capg * 2;
+                            if (need_words > recs)
+                                nb = 0;
+                        }
+                        cur.ckc_nb.push_back(nb);
+                        cur.ckc_capb.push_back(capb);
+                        cur.ckc_capg.push_back(capg);
+                        cur.ckc_need.push_back(job->h_contig_thr[batch_thr_seg[b]] - 2 + ki - 1);
+                        cur.ckc_max_nb = std::max(cur.ckc_max_nb, nb);
+                    }
                     h_pair_mode[q] = 1;
                     h_pair_bit_off[q] = bits;
                     cur_rec += recs;
@@ -2201,18 +2643,21 @@ int stage_a_run(gp_job* job)
             if (!cohorts.empty()) {
                 int rcc;
                 max_rec = (max_rec + 63) / 64 * 64; // (a set's records start on a line)
-                const uint64_t tab32_n = (max_wg + 4 * max_pairs + 3) / 4 * 4, tab64_n = max_wg + 3 * max_pairs;
+                const uint64_t tab32_n = (max_wg + 8 * max_pairs + 3) / 4 * 4, tab64_n = max_wg + 3 * max_pairs;
                 if ((rcc = job->d_census_rec.ensure(n_sets * max_rec)) != GP_OK ||
                     (rcc = job->d_census_cnt.ensure(n_sets * max_cnt)) != GP_OK ||
                     (rcc = job->d_census_over.ensure(n_sets * max_pairs)) != GP_OK ||
                     (rcc = job->d_census_tab32.ensure(n_sets * tab32_n)) != GP_OK ||
                     (rcc = job->d_census_tab64.ensure(n_sets * tab64_n)) != GP_OK ||
-                    (rcc = job->d_cand.ensure(bits / 64)) != GP_OK || (rcc = job->d_pair_mode.ensure(n_pairs)) != GP_OK ||
+                    (rcc = job->d_cand.ensure(bits / 64)) != GP_OK || (rcc = job->d_cand2.ensure(ckc_on ? bits / 64 : 1)) != GP_OK ||
+                    (rcc = job->d_pair_mode.ensure(n_pairs)) != GP_OK ||
                     (rcc = job->d_pair_bit_off.ensure(n_pairs)) != GP_OK)
                     return rcc;
                 GP_HIP(hipMemcpyAsync(job->d_pair_mode.p, h_pair_mode.data(), n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice, s));
                 GP_HIP(hipMemcpyAsync(job->d_pair_bit_off.p, h_pair_bit_off.data(), n_pairs * sizeof(uint64_t),
                                       hipMemcpyHostToDevice, s));
+                if (ckc_on) // (on `s`, ahead of the first scatter: every later stream of the census is behind it)
+                    GP_HIP(hipMemsetAsync(job->d_cand2.p, 0, bits / 8, s));
                 if ((rcc = job->t_census.begin(s, units)) != GP_OK)
                     return rcc;
                 // census_scatter: a ring of eight record slots per range in LDS (40 KB at 1280 ranges:
@@ -2240,12 +2685,16 @@ int stage_a_run(gp_job* job)
                     uint32_t* const d_over = job->d_census_over.p + (uint64_t)set * max_pairs;
                     const size_t np = co.pair_batch.size(), nw = co.wg_pair.size();
                     // one table of 32-bit and one of 64-bit columns per cohort
-                    co.tab32.reserve(nw + 4 * np);
+                    co.tab32.reserve(nw + 8 * np);
                     co.tab32.insert(co.tab32.end(), co.wg_pair.begin(), co.wg_pair.end());
                     co.tab32.insert(co.tab32.end(), co.pair_batch.begin(), co.pair_batch.end());
                     co.tab32.insert(co.tab32.end(), co.pair_ki.begin(), co.pair_ki.end());
                     co.tab32.insert(co.tab32.end(), co.pair_nst.begin(), co.pair_nst.end());
                     co.tab32.insert(co.tab32.end(), co.pair_queue.begin(), co.pair_queue.end());
+                    co.tab32.insert(co.tab32.end(), co.ckc_nb.begin(), co.ckc_nb.end());
+                    co.tab32.insert(co.tab32.end(), co.ckc_capb.begin(), co.ckc_capb.end());
+                    co.tab32.insert(co.tab32.end(), co.ckc_capg.begin(), co.ckc_capg.end());
+                    co.tab32.insert(co.tab32.end(), co.ckc_need.begin(), co.ckc_need.end());
                     co.tab64.reserve(nw + 3 * np);
                     co.tab64.insert(co.tab64.end(), co.wg_pos0.begin(), co.wg_pos0.end());
                     co.tab64.insert(co.tab64.end(), co.pair_rec_off.begin(), co.pair_rec_off.end());
@@ -2318,6 +2767,24 @@ int stage_a_run(gp_job* job)
                     else
                         hipLaunchKernelGGL((census_pack<kCRun>), dim3((unsigned)nw), dim3(256), 0, sp, a, c);
                     GP_HIP(hipGetLastError());
+                    if (ckc_on && co.ckc_max_nb) {
+                        // candidates by k-mer, behind the pack in the record space it has just read
+                        CkcArgs g{};
+                        g.pair_nb = c.pair_queue + np;
+                        g.pair_capb = g.pair_nb + np;
+                        g.pair_capg = g.pair_capb + np;
+                        g.pair_need = g.pair_capg + np;
+                        g.gshift = ckc_gshift;
+                        g.n_groups = ckc_groups;
+                        g.cand2 = job->d_cand2.p;
+                        const uint32_t span = co.ckc_max_nb;
+                        hipLaunchKernelGGL(ckc_init, dim3((unsigned)np), dim3(256), 0, sp, c, g, (uint32_t)np);
+                        hipLaunchKernelGGL(ckc_scatter, dim3((unsigned)nw), dim3(256), 0, sp, a, c, g);
+                        hipLaunchKernelGGL(ckc_group, dim3((unsigned)(np * span)), dim3(256), 0, sp, a, c, g, span);
+                        hipLaunchKernelGGL(ckc_share, dim3((unsigned)(np * ckc_groups)), dim3(256), 0, sp, c, g);
+                        hipLaunchKernelGGL(ckc_apply, dim3((unsigned)(np * span)), dim3(256), 0, sp, a, c, g, span);
+                        GP_HIP(hipGetLastError());
+                    }
                     if (n_sets > 1)
                         GP_HIP(hipEventRecord(ev_packed, sp));
                 }
@@ -2329,6 +2796,7 @@ int stage_a_run(gp_job* job)
                 a.pair_mode = job->d_pair_mode.p;
                 a.pair_bit_off = job->d_pair_bit_off.p;
                 a.cand = job->d_cand.p;
+                a.cand2 = job->d_cand2.p;
             }
         }
         a.kset = nullptr;
@@ -2666,7 +3134,7 @@ int stage_a_run(gp_job* job)
     }
     unsigned long long* const st = job->h_readback;   // pinned: [0..4] statistics, [8] the tail's error flag
     st[8] = 0;
-    GP_HIP(hipMemcpyAsync(st, job->d_stats.p, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    GP_HIP(hipMemcpyAsync(st, job->d_stats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     GP_HIP(hipMemcpyAsync(st + 8, err_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     GP_HIP(hipStreamSynchronize(s));
     const uint32_t tail_err = (uint32_t)st[8];
@@ -2677,6 +3145,7 @@ int stage_a_run(gp_job* job)
     job->counters.a_reservations = st[4];
     job->counters.a_replayed = st[5];
     job->counters.a_settled_hits = st[6];
+    job->counters.a_counted = st[7];
     if (tail_err) {
         set_error("stage A: reservation rounds did not converge");
         return GP_ERR_STATE;

@@ -47,7 +47,7 @@ constexpr uint32_t kPathCap = 1024;          // vertices per stored path
 // to enumerate, is done again by the one-gap-per-wave workers with their big arenas
 constexpr uint32_t kSmallSlotBits = 8, kSmallVerts = 96, kSmallEdges = 256;
 constexpr uint32_t kSimtWaves = 4096;   // waves of the lane-per-gap kernel (four per SIMD: compiled for 128 registers it spills 13 and is still faster than three) ...
-constexpr uint32_t kSimtLanes = 32;     // ... and the lanes of each that take a gap (divergent walks serialise)
+constexpr uint32_t kSimtLanes = 64;     // ... arenas per wave; CArgs::simt_lanes of them take a gap (GP_SEALER_LANES, default 32: divergent walks serialise)
 constexpr uint32_t kNwMax = 1800;            // longest sequence the consensus aligner takes
 constexpr uint32_t kMaxWorkers = 4096;  // one-wave workers of sealer_connect (CState::n_workers: by job size)
 // Their arenas come in two sizes.  Nearly every search a worker takes stays below a few thousand
@@ -169,6 +169,7 @@ struct CArgs {
     uint32_t* m_scratch;
     uint32_t* m_epoch;
     uint32_t* defer2;    // gaps the medium arenas could not hold, count in queue[6]
+    uint32_t simt_lanes; // sealer_connect_lanes: lanes of a wave that take a gap (<= kSimtLanes)
     uint32_t tier;       // sealer_connect: 0 medium arenas (what overflows goes to defer2), 1 full arenas over defer2, 2 full arenas over defer (no medium pass)
     int32_t* nw;
     uint32_t* epoch;
@@ -381,7 +382,10 @@ struct SeedTab {
 };
 
 struct Search {
-    const CArgs* a;
+    // (what bf_has needs of the launch's arguments, by value: a pointer to the kernel's argument block
+    // here forced every lane to keep a copy of the whole block in scratch)
+    uint32_t hash_num;
+    FastMod bf_mod;
     const uint32_t* bf;
     uint32_t k;
     SeedTab st;
@@ -434,12 +438,11 @@ __device__ inline uint32_t code_acgt(uint8_t c)
 
 __device__ inline bool bf_has(Search& S, uint64_t base)
 {
-    const CArgs& a = *S.a;
     S.tests++;
     bool all = true;
-    for (uint32_t i = 0; i < a.hash_num; i++) {
+    for (uint32_t i = 0; i < S.hash_num; i++) {
         uint64_t h = i ? ext_hash(base, S.k, i) : base;
-        uint64_t n = fastmod(h, a.bf_mod);
+        uint64_t n = fastmod(h, S.bf_mod);
         all &= ((S.bf[n >> 5] >> (uint32_t)(n & 31)) & 1u) != 0;
     }
     return all;
@@ -1092,7 +1095,8 @@ __device__ bool connect_one(const CArgs& a, Search& S, uint32_t gi, uint32_t wid
     for (uint32_t i = 0; i < l2; i++)
         r2[i] = comp_base(up(s[f.re - 1 - i]));
 
-    S.a = &a;
+    S.hash_num = a.hash_num;
+    S.bf_mod = a.bf_mod;
     S.bf = a.bf + ((uint64_t)a.contig_batch[g.contig] * a.n_k + a.ki) * a.bf_words;
     S.k = k;
     seed_tab_init(S.st, k);
@@ -1265,12 +1269,12 @@ __global__ __launch_bounds__(64, 4) void sealer_connect_lanes(CArgs a, SmallAren
     for (;;) {
         uint32_t base = 0;
         if (lane == 0)
-            base = atomicAdd(&a.queue[1], kSimtLanes);
+            base = atomicAdd(&a.queue[1], a.simt_lanes);
         base = __shfl(base, 0);
         if (base >= n_work)
             break; // every wave leaves here once the queue has drained
         const uint32_t it = base + lane;
-        if (lane < kSimtLanes && it < n_work) {
+        if (lane < a.simt_lanes && it < n_work) {
             const uint32_t gi = a.work[it];
             if (connect_one(a, S, gi, 0, r1, r2, nullptr, mine))
                 a.defer[atomicAdd(&a.queue[4], 1u)] = gi;
@@ -1900,6 +1904,7 @@ int stage_c_run(gp_job* job)
     a.err = b->err.p;
     a.stats = b->stats.p;
     a.flags = b->flags.p;
+    a.simt_lanes = (uint32_t)std::min<uint64_t>(kSimtLanes, std::max<uint64_t>(1, env_u64("GP_SEALER_LANES", 32)));
 
     GP_HIP(hipMemsetAsync(c->queue.p, 0, 8 * sizeof(uint32_t), s));
     GP_HIP(hipMemsetAsync(c->pool_head.p, 0, sizeof(unsigned long long), s));

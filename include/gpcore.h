@@ -125,6 +125,7 @@ typedef struct gp_counters {
     uint64_t c_max_cost;          /* "Max cost exceeded" */
     uint64_t a_replayed;          /* operations cbf_local replayed: every one of a plain pair, the candidates of a census pair */
     uint64_t a_settled_hits;      /* ... of which found in the table of k-mers settled for good: one look-up each, nothing else */
+    uint64_t a_counted;           /* candidate operations that needed no replay: their k-mer shares no counter with another candidate k-mer, its filter bits follow from the number of its copies */
 } gp_counters;
 
 /* ---- library / context ------------------------------------------------- */
@@ -168,6 +169,11 @@ int64_t gp_debug_nthash(gp_ctx* ctx, int variant, const uint8_t* seq, uint64_t l
                         uint64_t* out_fwd, uint64_t* out_rev, uint64_t* out_hashes, uint8_t* valid);
 void gp_default_params(gp_params* p);
 int gp_ctx_create(int device, gp_ctx** out);
+/* The same with every stream of the context restricted to the compute units whose bits are set in
+ * cu_mask (hipExtStreamCreateWithCUMask: bit i of word i / 32 = CU i): two contexts with
+ * complementary masks share the chip side by side, e.g. the filter build of one job on three
+ * quarters of it beside the latency-bound ntEdit / Sealer kernels of another (gp_jobs_polish). */
+int gp_ctx_create_masked(int device, const uint32_t* cu_mask, uint32_t mask_words, gp_ctx** out);
 void gp_ctx_destroy(gp_ctx* ctx);
 /* HIP stream (hipStream_t) every kernel of this context is launched on, so a
  * caller can bracket gp_job_* calls with its own HIP events. */

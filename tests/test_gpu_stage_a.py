@@ -11,16 +11,20 @@ from goldpolish_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["grid", "local", "census"], autouse=True)
+@pytest.fixture(params=["grid", "local", "census", "census_all"], autouse=True)
 def stage_a_path(request, monkeypatch):
     """every case runs through the stage-A schedules: grid-wide reservation rounds
     (GP_STAGE_A_LOCAL=0), one workgroup per (batch, k) pair replaying every operation
-    (GP_STAGE_A_LOCAL=1, census off), and the same behind the census of first touches (forced
-    for batches of any length; pairs it does not apply to or whose buckets overflow fall back)"""
+    (GP_STAGE_A_LOCAL=1, census off), the same behind the census of first touches (forced
+    for batches of any length; pairs it does not apply to or whose buckets overflow fall back) with
+    the candidates of private k-mers settled by their count (ckc_*: the default), and the census with
+    every candidate replayed (GP_STAGE_A_CKC=0: rounds 2-3's path, which pairs the count does not apply
+    to still take)"""
     monkeypatch.setenv("GP_STAGE_A_LOCAL", "0" if request.param == "grid" else "1")
-    monkeypatch.setenv("GP_STAGE_A_CENSUS", "1" if request.param == "census" else "0")
+    monkeypatch.setenv("GP_STAGE_A_CENSUS", "1" if request.param.startswith("census") else "0")
     monkeypatch.setenv("GP_STAGE_A_CENSUS_MIN", "1")
-    return request.param
+    monkeypatch.setenv("GP_STAGE_A_CKC", "0" if request.param == "census_all" else "1")
+    return "census" if request.param == "census_all" else request.param
 
 
 @pytest.fixture(scope="module")
@@ -100,6 +104,11 @@ def test_filters_match_oracle_default_sizes(gp, oracle, stage_a_path):
         assert c["a_reservations"] == 0 and c["a_replayed"] == c["a_ops"]
     else:
         assert c["a_reservations"] == 0 and 0 < c["a_replayed"] < c["a_ops"] // 2
+        if os.environ.get("GP_STAGE_A_CKC") == "1":
+            # nine candidates in ten belong to k-mers that share no counter with another: counted, not replayed
+            assert c["a_counted"] > 5 * c["a_replayed"]
+        else:
+            assert c["a_counted"] == 0
 
 
 def test_small_filters_heavy_collisions_and_saturation(gp, oracle):
