@@ -470,7 +470,7 @@ def main():
     on_gpu = args.backend == "nccl"
     from goldpolish_amd import core
 
-    KERNELS = ("cbf_first_pass", "cbf_round", "cbf_census", "cbf_local", "ntedit_scan", "ntedit_walk", "mask",
+    KERNELS = ("cbf_first_pass", "cbf_round", "cbf_census", "cbf_ckc", "cbf_local", "ntedit_scan", "ntedit_walk", "mask",
                "sealer_bfs", "upper")
 
     def word_sum(a):
@@ -484,16 +484,17 @@ def main():
         whole workload: one upload, the path, one download (and at N > 1 the gather)."""
         params = core.default_params(k_values=ks)
         bs, keep = core.batch_set_of_workload(w)
-        pipe = core.Pipeline(device_index, params, depth=2)
+        DEPTH = 3   # sets in the pipeline: one uploading, one in the filter build, one in the back half
+        pipe = core.Pipeline(device_index, params, depth=DEPTH)
         sums, times = [], {"upload_ms": [], "polish_ms": [], "download_ms": []}
         last = {}
         pinned = {}
 
         def step(tag, timed):
             r = pipe.collect(copy=False)
-            # keep the stream full: the set after next is handed over before anything else, so that
-            # its upload runs beside the polishing of the next one
-            pipe.submit(bs, keep, tag + 2)
+            # keep the stream full: the next set is handed over before anything else, so that its upload
+            # runs beside the filter build and the back half of the sets before it
+            pipe.submit(bs, keep, tag + DEPTH)
             data = r["bytes"]
             if world > 1:
                 # polished records leave from HBM (the pipeline's packed copy), over xGMI; rank 0
@@ -529,8 +530,8 @@ def main():
                     times[k].append(r[k])
             last["r"] = r
 
-        pipe.submit(bs, keep, 0)
-        pipe.submit(bs, keep, 1)
+        for i in range(DEPTH):
+            pipe.submit(bs, keep, i)
         for i in range(warmup):
             step(i, False)
         if dist:
@@ -563,9 +564,9 @@ def main():
                "input_bytes": int(w.read_off[-1]) + int(w.contig_off[-1]),
                "gathered": last.get("gathered")}
         res["polished"] = core.split_polished(r) if rank == 0 and world == 1 else None
-        # the two sets still in flight (uploaded beside the last timed steps) are drained untimed
-        pipe.collect(copy=False)
-        pipe.collect(copy=False)
+        # the sets still in flight (uploaded and built beside the last timed steps) are drained untimed
+        for _ in range(DEPTH):
+            pipe.collect(copy=False)
         pipe.close()
         return res
 

@@ -735,6 +735,7 @@ void gp_job_destroy(gp_job* job)
     job->t_round.destroy();
     job->t_local.destroy();
     job->t_census.destroy();
+    job->t_ckc.destroy();
     job->t_scan.destroy();
     job->t_walk.destroy();
     job->t_bfs.destroy();
@@ -942,6 +943,38 @@ static int polish_back(gp_job* job)
     }
     return rc;
 }
+
+} // extern "C"
+
+namespace gp {
+int job_polish_front(gp_job* job)
+{
+    GP_HIP(hipSetDevice(job->ctx->device));
+    if (int rcb = ensure_work(job, "gp_pipeline (filter build)"))
+        return rcb;
+    int rc = stage_a_run(job);
+    if (rc == GP_OK)
+        rc = gp_job_sync(job);
+    // the filters are results; what built them is scratch: the next set's build takes it from the pool
+    // (the job is destroyed after its back half and never builds filters again)
+    stage_a_release(job);
+    job->d_cbf.release();
+    return rc;
+}
+
+int job_polish_back(gp_job* job)
+{
+    GP_HIP(hipSetDevice(job->ctx->device));
+    if (!job->bc || !job->filters_ready) {
+        set_error("gp_pipeline (back half): the filters have not been built");
+        return GP_ERR_STATE;
+    }
+    const int rc = polish_back(job);
+    return rc == GP_OK ? gp_job_sync(job) : rc;
+}
+} // namespace gp
+
+extern "C" {
 
 int gp_job_polish(gp_job* job, int sync)
 try {
@@ -1155,6 +1188,8 @@ try {
         t = &job->t_local;
     else if (!std::strcmp(kernel, "cbf_census"))
         t = &job->t_census;
+    else if (!std::strcmp(kernel, "cbf_ckc"))
+        t = &job->t_ckc; // (part of cbf_census's span: the candidates-by-k-mer kernels behind each cohort's pack, on the pack's stream)
     else if (!std::strcmp(kernel, "ntedit_scan"))
         t = &job->t_scan;
     else if (!std::strcmp(kernel, "ntedit_walk"))

@@ -183,7 +183,7 @@ struct gp_job {
     // path at the same time; pinned memory is written by the device directly
     unsigned long long* h_readback = nullptr; // 64 words
 
-    gp::KernelTimer t_first_pass, t_round, t_local, t_census, t_scan, t_walk, t_bfs, t_mask, t_upper;
+    gp::KernelTimer t_first_pass, t_round, t_local, t_census, t_ckc, t_scan, t_walk, t_bfs, t_mask, t_upper;
     gp_counters counters{};
     bool filters_ready = false;
     // 0: only the inputs are on the device (gp_job_create); 1: filters and work buffers allocated
@@ -193,6 +193,11 @@ struct gp_job {
 
 namespace gp {
 int ctx_stream_create(const gp_ctx* ctx, hipStream_t* out); // a non-blocking stream with the context's CU mask
+// gp_pipeline's two halves of gp_job_polish (api.hip): the filter build, after which the build's own
+// work buffers (counting-filter arena, census records, reservation tables) go back to the pool for the
+// next set's build; and everything behind it.  Both wait for the job's stream before they return.
+int job_polish_front(gp_job* job);
+int job_polish_back(gp_job* job);
 int stage_a_prepare(gp_job* job);            // allocate work buffers
 int stage_a_run(gp_job* job);                // enqueue + drive the filter build
 void stage_a_release(gp_job* job);

@@ -2,13 +2,22 @@
 // memory (SURVEY.md 8d's timed region: reads + contigs resident in host memory -> polished bytes
 // in host memory).  Host C++ only; the device work is gp_job_create / gp_job_polish.
 //
-// Three stages run side by side, each in a thread of its own, connected by bounded queues:
-//   upload   gp_job_create of set i + 1 on the pipeline's upload context (pinned staging, DMA on
+// Four stages run side by side, each in a thread of its own, connected by bounded queues:
+//   upload   gp_job_create of set i + 2 on the pipeline's upload context (pinned staging, DMA on
 //            that context's stream) ...
-//   polish   ... while set i runs the whole path on the polishing context; its polished records
+//   build    ... while the filters of set i + 1 are built on the build context, whose streams are
+//            restricted to 7 CUs in 8 (gp_ctx_create_masked): the filter build is streaming kernels that
+//            fill every wave slot they are given ...
+//   polish   ... while set i runs everything behind the filters (ntEdit cascade, mask, Sealer, upper) on
+//            the polishing context -- the eighth CU of every eight: latency-bound kernels of a few
+//            thousand small workgroups, 10 % slower there than on the whole chip -- its polished records
 //            are packed into an HBM buffer, copied to pinned host memory, and the job is destroyed
 //            (its device blocks go to the pool and are what the next job's first use takes) ...
 //   collect  ... while the caller still reads the result of set i - 1.
+// GP_PIPELINE_OVERLAP=0: build and polish in one thread on one unmasked context (round 3's three
+// stages); 2: four stages, no CU masks.  Measured with two jobs of 1000 x 25 kbp (tools/overlap_cu_probe.py):
+// one after the other 601 ms, two unmasked streams 598 ms, build on 224 CUs | back half on 32: 561 ms
+// (192 | 64 as contiguous ranges: 1139 ms -- a range of CU bits is a few shader engines, not a share of each).
 // Results come back in submission order -- the ordered append of scripts/goldpolish-reaper:51-73.
 // The reference overlaps the same things with processes: its filter server builds the next
 // batches' filters while polishing workers run (scripts/goldpolish:496-514).
@@ -28,8 +37,8 @@ using namespace gp;
 namespace {
 
 const char* const kTimerNames[] = { "cbf_first_pass", "cbf_round", "cbf_local", "cbf_census", "ntedit_scan",
-                                    "ntedit_walk",    "sealer_bfs", "mask",     "upper" };
-constexpr int kTimers = 9;
+                                    "ntedit_walk",    "sealer_bfs", "mask",     "upper",      "cbf_ckc" };
+constexpr int kTimers = 10;
 
 struct Slot { // one finished set
     uint64_t tag = 0;
@@ -54,7 +63,7 @@ struct Item {
     gp_job* job = nullptr;
     int rc = GP_OK;
     std::string msg;
-    double upload_ms = 0;
+    double upload_ms = 0, build_ms = 0;
 };
 
 double now_ms()
@@ -66,20 +75,22 @@ double now_ms()
 
 struct gp_pipeline {
     gp_ctx* up_ctx = nullptr;
+    gp_ctx* front_ctx = nullptr; // the filter build's (null: build and back half both on run_ctx, in the polishing thread)
     gp_ctx* run_ctx = nullptr;
     gp_params prm{};
     uint32_t depth = 2;
     std::mutex mu;
     std::condition_variable cv;
     std::deque<Item> submitted; // waiting for the upload thread
-    std::deque<Item> uploaded;  // on the device, waiting for the polishing thread (one at most)
+    std::deque<Item> uploaded;  // on the device, waiting for the build thread (one at most)
+    std::deque<Item> built;     // filters built, waiting for the polishing thread (one at most)
     std::deque<int> done;       // slots ready for collect, oldest first
     std::vector<int> free_slots;
     Slot slots[3];
     int held = -1;              // slot the caller is reading (released by the next collect)
     uint32_t in_flight = 0;     // submitted and not yet collected
     bool stop = false;
-    std::thread uploader, polisher;
+    std::thread uploader, builder, polisher;
 };
 
 static void upload_loop(gp_pipeline* p)
@@ -111,15 +122,52 @@ static void upload_loop(gp_pipeline* p)
     }
 }
 
+static void build_loop(gp_pipeline* p)
+{
+    for (;;) {
+        Item it;
+        {
+            std::unique_lock<std::mutex> g(p->mu);
+            p->cv.wait(g, [&] { return p->stop || (!p->uploaded.empty() && p->built.empty()); });
+            if (p->stop)
+                return;
+            it = std::move(p->uploaded.front());
+            p->uploaded.pop_front();
+        }
+        p->cv.notify_all(); // the upload thread may start on the next set
+        if (it.rc == GP_OK) {
+            const double t0 = now_ms();
+            try {
+                it.job->ctx = p->front_ctx; // the upload is complete (gp_job_create waits for it)
+                it.rc = job_polish_front(it.job);
+                if (it.rc != GP_OK)
+                    it.msg = gp_last_error();
+            } catch (...) {
+                it.rc = on_exception("gp_pipeline (filter build)");
+                try {
+                    it.msg = gp_last_error();
+                } catch (...) {
+                }
+            }
+            it.build_ms = now_ms() - t0;
+        }
+        {
+            std::lock_guard<std::mutex> g(p->mu);
+            p->built.push_back(std::move(it));
+        }
+        p->cv.notify_all();
+    }
+}
+
 static int polish_one(gp_pipeline* p, Item& it, Slot& s)
 {
     gp_job* job = it.job;
-    job->ctx = p->run_ctx; // the upload is complete (gp_job_create waits for it); from here on the polishing context's stream
+    job->ctx = p->run_ctx; // from here on the polishing context's stream
     double t0 = now_ms();
-    int rc = gp_job_polish(job, 1);
+    int rc = p->front_ctx ? job_polish_back(job) : gp_job_polish(job, 1);
     if (rc != GP_OK)
         return rc;
-    s.polish_ms = now_ms() - t0;
+    s.polish_ms = now_ms() - t0 + it.build_ms;
     t0 = now_ms();
     s.lengths.assign(job->n_contigs ? job->n_contigs : 1, 0);
     s.dropped.assign(s.lengths.size(), 0);
@@ -161,15 +209,16 @@ static void polish_loop(gp_pipeline* p)
         int si;
         {
             std::unique_lock<std::mutex> g(p->mu);
-            p->cv.wait(g, [&] { return p->stop || (!p->uploaded.empty() && !p->free_slots.empty()); });
+            std::deque<Item>& from = p->front_ctx ? p->built : p->uploaded;
+            p->cv.wait(g, [&] { return p->stop || (!from.empty() && !p->free_slots.empty()); });
             if (p->stop)
                 return;
-            it = std::move(p->uploaded.front());
-            p->uploaded.pop_front();
+            it = std::move(from.front());
+            from.pop_front();
             si = p->free_slots.back();
             p->free_slots.pop_back();
         }
-        p->cv.notify_all(); // the upload thread may start on the next set
+        p->cv.notify_all(); // the stage before may start on the next set
         Slot& s = p->slots[si];
         s.tag = it.tag;
         s.rc = it.rc;
@@ -223,13 +272,34 @@ try {
         }
     } owner{ p };
     int rc;
-    if ((rc = gp_ctx_create(device, &p->up_ctx)) != GP_OK || (rc = gp_ctx_create(device, &p->run_ctx)) != GP_OK)
+    if ((rc = gp_ctx_create(device, &p->up_ctx)) != GP_OK)
         return rc;
+    const uint64_t overlap = env_u64("GP_PIPELINE_OVERLAP", 1);
+    if (overlap == 0) {
+        if ((rc = gp_ctx_create(device, &p->run_ctx)) != GP_OK)
+            return rc;
+    } else {
+        // the back half on every eighth CU, the filter build on the other seven (bit i of the mask = CU i;
+        // interleaved, so that each gets its share of every shader engine)
+        const uint32_t n_cu = (uint32_t)p->up_ctx->prop.multiProcessorCount;
+        std::vector<uint32_t> front((n_cu + 31) / 32, 0), back((n_cu + 31) / 32, 0);
+        for (uint32_t cu = 0; cu < n_cu; cu++)
+            (cu % 8 == 7 ? back : front)[cu / 32] |= 1u << (cu % 32);
+        if (overlap == 1 && n_cu >= 16) {
+            if ((rc = gp_ctx_create_masked(device, front.data(), (uint32_t)front.size(), &p->front_ctx)) != GP_OK ||
+                (rc = gp_ctx_create_masked(device, back.data(), (uint32_t)back.size(), &p->run_ctx)) != GP_OK)
+                return rc;
+        } else if ((rc = gp_ctx_create(device, &p->front_ctx)) != GP_OK || (rc = gp_ctx_create(device, &p->run_ctx)) != GP_OK) {
+            return rc;
+        }
+    }
     p->prm = *params;
     p->depth = depth < 1 ? 1 : depth > 8 ? 8 : depth;
     for (int i = 0; i < 3; i++)
         p->free_slots.push_back(i);
     p->uploader = std::thread(upload_loop, p);
+    if (p->front_ctx)
+        p->builder = std::thread(build_loop, p);
     p->polisher = std::thread(polish_loop, p);
     owner.p = nullptr;
     *out = p;
@@ -340,9 +410,14 @@ void gp_pipeline_destroy(gp_pipeline* p)
         p->cv.notify_all();
         if (p->uploader.joinable())
             p->uploader.join();
+        if (p->builder.joinable())
+            p->builder.join();
         if (p->polisher.joinable())
             p->polisher.join();
         for (Item& it : p->uploaded)
+            if (it.job)
+                gp_job_destroy(it.job);
+        for (Item& it : p->built)
             if (it.job)
                 gp_job_destroy(it.job);
         if (p->run_ctx)
@@ -353,6 +428,7 @@ void gp_pipeline_destroy(gp_pipeline* p)
             s.d_bytes.release();
         }
         gp_ctx_destroy(p->up_ctx);
+        gp_ctx_destroy(p->front_ctx);
         gp_ctx_destroy(p->run_ctx);
         delete p;
     } catch (...) {

@@ -1235,7 +1235,7 @@ __global__ __launch_bounds__(256) void census_pack(AArgs a, CensusArgs c)
 // operations to under 2 %, and with it most of its random counter transactions.
 // Streaming passes, all in the record space the census has just finished with:
 //   ckc_scatter  candidates (64-bit hash, position) into hash buckets of their pair: LDS staging, whole
-//                chunks per bucket and half-stretch, one cursor atomic per chunk;
+//                chunks per bucket and quarter-stretch, one cursor atomic per chunk;
 //   ckc_group    a workgroup per bucket: an LDS hash set of its distinct k-mers (a slot each, written back
 //                into the records); every new k-mer sends its counters, tagged (bucket, slot), to the
 //                group of their counter range;
@@ -1250,11 +1250,9 @@ __device__ inline uint32_t select64(unsigned long long w, uint32_t r); // (below
 
 constexpr uint32_t kCkcSlots = 2048;        // distinct k-mers a bucket's LDS set holds (load <= 7/8)
 constexpr uint32_t kCkcShareSlots = 8192;   // (counter, k-mer) entries a counter group's LDS table holds (load <= 3/4)
-constexpr uint32_t kCkcStage = 3072;        // records staged in LDS per half-stretch by ckc_scatter (16 bytes each)
-constexpr uint32_t kCkcStageE = 5120;       // entries staged in LDS by ckc_group (8 bytes each)
+constexpr uint32_t kCkcStage = 3072;        // twice the records ckc_scatter stages in LDS per quarter-stretch (12 bytes each)
 constexpr uint32_t kCkcMaxBuckets = 128, kCkcMaxGroups = 256;
 constexpr uint32_t kCkcHdrWords = 1024;     // [0,256) bucket cursors, [256,512) group cursors, [512] overflow
-constexpr uint32_t kCkcHalf = kCStretch / 2;
 
 struct CkcArgs {
     const uint32_t* pair_nb;    // [pairs] hash buckets of the pair (a power of two; 0: not eligible, the pair keeps the whole candidate replay)
@@ -1303,16 +1301,22 @@ __global__ __launch_bounds__(256) void ckc_init(CensusArgs c, CkcArgs g, uint32_
         base[512] = 1u; // the census gave the pair up: nothing to group
 }
 
-// A workgroup per stretch (the census's table of stretches): the candidates of each half-stretch,
-// one per lane and turn, hashed from the table of rotated seeds and staged per bucket.
+// A workgroup per stretch (the census's table of stretches), a quarter of it (2048 positions) at a time:
+// a lane rolls over eight consecutive positions -- the k-step start from the table of rotated seeds
+// once, a roll per position after that, nothing at all where its eight candidate bits are clear -- and
+// stages its candidates per bucket; a quarter's chunks leave with one cursor atomic per bucket.
+// (First version: a candidate per lane and turn, each hashed from scratch, half-stretches, 63 KB of
+// LDS: two workgroups per CU, 32.8 ms per 1000 contigs of 25 kbp at 40x; this one: 24 KB.)
+constexpr uint32_t kCkcQuarter = kCStretch / 4, kCkcPerLane = kCkcQuarter / 256;
+static_assert(kCkcPerLane == 8, "a byte of candidate bits per lane");
+
 __global__ __launch_bounds__(256) void ckc_scatter(AArgs a, CensusArgs c, CkcArgs g)
 {
-    __shared__ uint8_t codes[kCStretch + kHalo];
+    __shared__ uint8_t codes[kCkcQuarter + kHalo];
     __shared__ uint64_t seed_t[kSeedTableWords];
-    __shared__ uint4 stage[kCkcStage];
+    __shared__ ulonglong2 roll_in[8], roll_out[8]; // what a base brings to {forward, reverse} when it enters / leaves a k-mer
+    __shared__ uint32_t st_h0[kCkcStage / 2], st_h1[kCkcStage / 2], st_pos[kCkcStage / 2];
     __shared__ uint32_t s_cnt[kCkcMaxBuckets], s_base[kCkcMaxBuckets];
-    __shared__ unsigned long long s_cw[kCkcHalf / 64];
-    __shared__ uint32_t s_cpre[kCkcHalf / 64 + 1];
     const uint32_t pair = c.wg_pair[blockIdx.x];
     const uint32_t nb = g.pair_nb[pair];
     if (!nb)
@@ -1320,64 +1324,66 @@ __global__ __launch_bounds__(256) void ckc_scatter(AArgs a, CensusArgs c, CkcArg
     const CkcRegion R = ckc_region(c, g, pair);
     if (*R.over)
         return;
-    const uint32_t b = c.pair_batch[pair], ki = c.pair_ki[pair], k = a.kc[ki].k;
+    const uint32_t b = c.pair_batch[pair], ki = c.pair_ki[pair];
+    const KConsts& kc = a.kc[ki];
+    const uint32_t k = kc.k;
     const uint64_t b_start = a.batch_pos[b], b_end = a.batch_pos[b + 1];
     const uint64_t pos0 = c.wg_pos0[blockIdx.x];
     const uint64_t stretch_end = min(b_end, pos0 + (uint64_t)kCStretch);
-    const uint32_t capb = g.pair_capb[pair], cap_s = kCkcStage / nb, tid = threadIdx.x;
+    const uint32_t capb = g.pair_capb[pair], cap_s = (kCkcStage / 2) / nb, tid = threadIdx.x;
     fill_seed_table(seed_t);
-    for (uint32_t i = tid; i < kCStretch + kHalo; i += 256) {
-        const uint64_t p = pos0 + i;
-        codes[i] = base_code(p < a.n_pos ? a.reads[p] : (uint8_t)'\n');
+    if (tid < 8) {
+        roll_in[tid] = tid < 4 ? make_ulonglong2(seed_of_code(tid), kc.in_rev[tid]) : make_ulonglong2(0, 0);
+        roll_out[tid] = tid < 4 ? make_ulonglong2(kc.out_fwd[tid], seed_of_code(tid ^ 2)) : make_ulonglong2(0, 0);
     }
     if (tid < nb)
         s_cnt[tid] = 0;
-    const unsigned long long* const cand = c.cand + ((c.pair_bit_off[pair] + (pos0 - b_start)) >> 6);
-    for (uint32_t half = 0; half < 2; half++) {
-        const uint64_t h0 = pos0 + (uint64_t)half * kCkcHalf;
-        if (h0 >= stretch_end)
+    const uint8_t* const cand = reinterpret_cast<const uint8_t*>(c.cand + ((c.pair_bit_off[pair] + (pos0 - b_start)) >> 6));
+    for (uint32_t q = 0; q < 4; q++) {
+        const uint64_t q0 = pos0 + (uint64_t)q * kCkcQuarter;
+        if (q0 >= stretch_end)
             break; // uniform
-        __syncthreads(); // codes, the table and the counters are set; the half before is flushed
-        if (tid < kCkcHalf / 64) { // one wave: the half's candidate words and their prefix counts
-            const uint64_t first = h0 + (uint64_t)tid * 64;
-            unsigned long long w = first < stretch_end ? cand[half * (kCkcHalf / 64) + tid] : 0ull; // (nothing is read past the pair's bits)
-            if (first < stretch_end && stretch_end - first < 64)
-                w &= (1ULL << (stretch_end - first)) - 1;
-            s_cw[tid] = w;
-            const uint32_t cnt = (uint32_t)__popcll(w);
-            uint32_t inc = cnt;
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t u = (uint32_t)__shfl_up((int)inc, o);
-                if ((int)tid >= o)
-                    inc += u;
-            }
-            s_cpre[tid] = inc - cnt;
-            if (tid == kCkcHalf / 64 - 1)
-                s_cpre[kCkcHalf / 64] = inc;
+        __syncthreads(); // the quarter before is flushed (and the tables are set)
+        for (uint32_t i = tid; i < kCkcQuarter + kHalo; i += 256) {
+            const uint64_t p = q0 + i;
+            codes[i] = base_code(p < a.n_pos ? a.reads[p] : (uint8_t)'\n');
         }
+        // the lane's eight candidate bits (little endian: byte j of the bitmap = positions 8 j .. 8 j + 7);
+        // nothing is read past the stretch's own bits
+        const uint64_t lane_pos0 = q0 + (uint64_t)tid * kCkcPerLane;
+        uint32_t bits = lane_pos0 < stretch_end ? cand[q * (kCkcQuarter / 8) + tid] : 0u;
+        if (lane_pos0 < stretch_end && stretch_end - lane_pos0 < 8)
+            bits &= (1u << (stretch_end - lane_pos0)) - 1u;
         __syncthreads();
-        const uint32_t n_c = s_cpre[kCkcHalf / 64];
-        for (uint32_t ci = tid; ci < n_c; ci += 256) {
-            uint32_t wlo = 0;
-            for (uint32_t step = kCkcHalf / 128; step; step >>= 1)
-                if (s_cpre[wlo + step] <= ci)
-                    wlo += step;
-            const uint32_t prel = half * kCkcHalf + wlo * 64 + select64(s_cw[wlo], ci - s_cpre[wlo]);
+        if (bits) {
+            const uint32_t t0 = tid * kCkcPerLane;
+            const uint32_t j0 = (uint32_t)__ffs((int)bits) - 1u; // the rolling starts at the lane's first candidate
             uint64_t fh = 0, rh = 0;
-            int no_bad = -1; // a candidate is a k-mer: no byte of it is bad
-            kmer_hash_from_table(seed_t, codes + prel, k, fh, rh, no_bad);
-            const uint64_t base = fh + rh;
-            const uint32_t bkt = (uint32_t)(ckc_mix(base) >> 56) & (nb - 1u);
-            const uint4 rec = make_uint4((uint32_t)base, (uint32_t)(base >> 32), (uint32_t)(pos0 + prel - b_start), 0u);
-            const uint32_t r = atomicAdd(&s_cnt[bkt], 1u);
-            if (r < cap_s) {
-                stage[bkt * cap_s + r] = rec;
-            } else { // more of one bucket than the staging holds: straight to memory
-                const uint32_t at = atomicAdd(&R.cur_b[bkt], 1u);
-                if (at < capb)
-                    R.rec[(uint64_t)bkt * capb + at] = rec;
-                else
-                    *R.over = 1u;
+            int no_bad = -1; // a candidate is a k-mer: no byte of it is bad (bytes between candidates may be: they hash as 0, and so do they in the rolls)
+            kmer_hash_from_table(seed_t, codes + t0 + j0, k, fh, rh, no_bad);
+            for (uint32_t j = j0; j < kCkcPerLane; j++) {
+                if (j > j0) {
+                    const ulonglong2 ri = roll_in[codes[t0 + j + k - 1]], ro = roll_out[codes[t0 + j - 1]];
+                    fh = srol1(fh) ^ ri.x ^ ro.x;
+                    rh = sror1(rh ^ ri.y ^ ro.y);
+                }
+                if (!((bits >> j) & 1u))
+                    continue;
+                const uint64_t base = fh + rh;
+                const uint32_t bkt = (uint32_t)(ckc_mix(base) >> 56) & (nb - 1u);
+                const uint32_t prel = (uint32_t)(q0 + t0 + j - b_start);
+                const uint32_t r = atomicAdd(&s_cnt[bkt], 1u);
+                if (r < cap_s) {
+                    st_h0[bkt * cap_s + r] = (uint32_t)base;
+                    st_h1[bkt * cap_s + r] = (uint32_t)(base >> 32);
+                    st_pos[bkt * cap_s + r] = prel;
+                } else { // more of one bucket than the staging holds: straight to memory
+                    const uint32_t at = atomicAdd(&R.cur_b[bkt], 1u);
+                    if (at < capb)
+                        R.rec[(uint64_t)bkt * capb + at] = make_uint4((uint32_t)base, (uint32_t)(base >> 32), prel, 0u);
+                    else
+                        *R.over = 1u;
+                }
             }
         }
         __syncthreads();
@@ -1394,7 +1400,7 @@ __global__ __launch_bounds__(256) void ckc_scatter(AArgs a, CensusArgs c, CkcArg
         for (uint32_t idx = tid; idx < nb * cap_s; idx += 256) {
             const uint32_t bkt = idx / cap_s, i = idx - bkt * cap_s;
             if (i < min(s_cnt[bkt], cap_s) && s_base[bkt] != 0xFFFFFFFFu)
-                R.rec[(uint64_t)bkt * capb + s_base[bkt] + i] = stage[idx];
+                R.rec[(uint64_t)bkt * capb + s_base[bkt] + i] = make_uint4(st_h0[idx], st_h1[idx], st_pos[idx], 0u);
         }
         __syncthreads();
         if (tid < nb)
@@ -1402,11 +1408,14 @@ __global__ __launch_bounds__(256) void ckc_scatter(AArgs a, CensusArgs c, CkcArg
     }
 }
 
-// A workgroup per (pair, bucket): the bucket's distinct k-mers.
+// A workgroup per (pair, bucket): the bucket's distinct k-mers.  Three passes: the records into the
+// LDS set (their slot goes back into the record); the set's k-mers counted per counter group, a range
+// of each group reserved with one atomic; the set's k-mers once more, their (counter, k-mer) entries
+// written straight into those ranges.  (First version: entries staged per group in 40 KB of LDS -- two
+// workgroups per CU, 20.6 ms per 1000 contigs; the counters are cheap to work out twice.)
 __global__ __launch_bounds__(256) void ckc_group(AArgs a, CensusArgs c, CkcArgs g, uint32_t span)
 {
     __shared__ unsigned long long keys[kCkcSlots];
-    __shared__ unsigned long long stage[kCkcStageE];
     __shared__ uint32_t s_cnt[kCkcMaxGroups], s_base[kCkcMaxGroups], s_ndist;
     const uint32_t pair = blockIdx.x / span, bkt = blockIdx.x % span, tid = threadIdx.x; // (a 1-D grid: pairs x the most buckets a pair has)
     const uint32_t nb = g.pair_nb[pair];
@@ -1417,7 +1426,7 @@ __global__ __launch_bounds__(256) void ckc_group(AArgs a, CensusArgs c, CkcArgs 
         return;
     const uint32_t capb = g.pair_capb[pair], capg = g.pair_capg[pair];
     const uint32_t n = R.cur_b[bkt]; // (<= capb: a chunk that did not fit set the overflow word)
-    const uint32_t ng = g.n_groups, cap_s = kCkcStageE / ng, gmask = (1u << g.gshift) - 1u;
+    const uint32_t ng = g.n_groups, gmask = (1u << g.gshift) - 1u;
     const uint32_t k = a.kc[c.pair_ki[pair]].k;
     const unsigned long long EMPTY = ~0ull;
     for (uint32_t i = tid; i < kCkcSlots; i += 256)
@@ -1437,11 +1446,13 @@ __global__ __launch_bounds__(256) void ckc_group(AArgs a, CensusArgs c, CkcArgs 
             continue;
         }
         uint32_t sl = (uint32_t)(ckc_mix(key) >> 40) & (kCkcSlots - 1u);
-        bool fresh = false, placed = false;
+        bool placed = false;
         for (uint32_t probe = 0; probe < kCkcSlots; probe++, sl = (sl + 1u) & (kCkcSlots - 1u)) {
             const unsigned long long old = atomicCAS(&keys[sl], EMPTY, key);
             if (old == EMPTY) {
-                fresh = placed = true;
+                if (atomicAdd(&s_ndist, 1u) >= kCkcSlots / 8 * 7)
+                    bad = true;
+                placed = true;
                 break;
             }
             if (old == key) {
@@ -1454,84 +1465,107 @@ __global__ __launch_bounds__(256) void ckc_group(AArgs a, CensusArgs c, CkcArgs 
             continue;
         }
         rec[i].w = sl;
-        if (fresh) {
-            if (atomicAdd(&s_ndist, 1u) >= kCkcSlots / 8 * 7)
-                bad = true;
-            const uint32_t ref = (bkt << 11) | sl;
-            for (uint32_t h = 0; h < a.hash_num; h++) {
-                const uint32_t ix = (uint32_t)fastmod(h ? ext_hash(key, k, h) : key, a.cbf_mod);
-                const uint32_t grp = ix >> g.gshift;
-                const unsigned long long e = ((unsigned long long)(ix & gmask) << 32) | ref;
-                const uint32_t q = atomicAdd(&s_cnt[grp], 1u);
-                if (q < cap_s) {
-                    stage[grp * cap_s + q] = e;
-                } else {
-                    const uint32_t at = atomicAdd(&R.cur_g[grp], 1u);
-                    if (at < capg)
-                        R.ent[(uint64_t)grp * capg + at] = e;
-                    else
-                        bad = true;
-                }
-            }
+    }
+    __syncthreads();
+    // the set's k-mers per counter group
+    for (uint32_t sl = tid; sl < kCkcSlots; sl += 256) {
+        const unsigned long long key = keys[sl];
+        if (key == EMPTY)
+            continue;
+        for (uint32_t h = 0; h < a.hash_num; h++)
+            atomicAdd(&s_cnt[(uint32_t)fastmod(h ? ext_hash(key, k, h) : key, a.cbf_mod) >> g.gshift], 1u);
+    }
+    __syncthreads();
+    for (uint32_t grp = tid; grp < ng; grp += 256) {
+        const uint32_t m = s_cnt[grp];
+        uint32_t at = m ? atomicAdd(&R.cur_g[grp], m) : 0u;
+        if (at + m > capg) {
+            bad = true;
+            at = 0xFFFFFFFFu;
         }
+        s_base[grp] = at;
+        s_cnt[grp] = 0; // (the next pass hands out the places of the range)
     }
     if (bad)
         *R.over = 1u;
     __syncthreads();
-    for (uint32_t grp = tid; grp < ng; grp += 256) {
-        const uint32_t m = min(s_cnt[grp], cap_s);
-        uint32_t at = m ? atomicAdd(&R.cur_g[grp], m) : 0u;
-        if (at + m > capg) {
-            *R.over = 1u;
-            at = 0xFFFFFFFFu;
+    for (uint32_t sl = tid; sl < kCkcSlots; sl += 256) {
+        const unsigned long long key = keys[sl];
+        if (key == EMPTY)
+            continue;
+        const uint32_t ref = (bkt << 11) | sl;
+        for (uint32_t h = 0; h < a.hash_num; h++) {
+            const uint32_t ix = (uint32_t)fastmod(h ? ext_hash(key, k, h) : key, a.cbf_mod);
+            const uint32_t grp = ix >> g.gshift;
+            const uint32_t q = atomicAdd(&s_cnt[grp], 1u);
+            if (s_base[grp] != 0xFFFFFFFFu)
+                R.ent[(uint64_t)grp * capg + s_base[grp] + q] = ((unsigned long long)(ix & gmask) << 32) | ref;
         }
-        s_base[grp] = at;
-    }
-    __syncthreads();
-    for (uint32_t idx = tid; idx < ng * cap_s; idx += 256) {
-        const uint32_t grp = idx / cap_s, i = idx - grp * cap_s;
-        if (i < min(s_cnt[grp], cap_s) && s_base[grp] != 0xFFFFFFFFu)
-            R.ent[(uint64_t)grp * capg + s_base[grp] + i] = stage[idx];
     }
 }
 
-// A workgroup per (pair, counter group): which counters do two different candidate k-mers touch?
-__global__ __launch_bounds__(256) void ckc_share(CensusArgs c, CkcArgs g)
+// Which counters do two different candidate k-mers touch?  A unit = (pair, counter group): an exact LDS
+// table counter -> k-mer.  A persistent grid: a workgroup takes units one after the other and never clears
+// its table -- an entry carries the unit's epoch in its top bits, one of another epoch is an empty slot --
+// because a unit is a few hundred to a few thousand entries and clearing 64 KB for each of the 320 000
+// units of 1000 contigs was most of the kernel (11.4 ms per 1000 contigs with a workgroup per unit).
+// entry in memory: (counter within its group << 32) | (bucket << 11 | slot); in the table:
+// (epoch << 44) | (counter within its group << 20) | (bucket << 11 | slot)
+__global__ __launch_bounds__(256) void ckc_share(CensusArgs c, CkcArgs g, uint32_t n_pairs)
 {
     __shared__ unsigned long long tab[kCkcShareSlots];
-    const uint32_t pair = blockIdx.x / g.n_groups, grp = blockIdx.x % g.n_groups, tid = threadIdx.x;
-    if (!g.pair_nb[pair] || grp >= g.n_groups)
-        return;
-    const CkcRegion R = ckc_region(c, g, pair);
-    if (*R.over)
-        return;
-    const uint32_t capg = g.pair_capg[pair];
-    const uint32_t n = R.cur_g[grp];
-    if (n > kCkcShareSlots / 4 * 3) {
-        if (tid == 0)
-            *R.over = 1u;
-        return;
-    }
-    const unsigned long long EMPTY = ~0ull;
+    const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < kCkcShareSlots; i += 256)
-        tab[i] = EMPTY;
-    __syncthreads();
-    const unsigned long long* const ent = R.ent + (uint64_t)grp * capg;
-    for (uint32_t i = tid; i < n; i += 256) {
-        const unsigned long long e = ent[i];
-        const uint32_t key = (uint32_t)(e >> 32), ref = (uint32_t)e;
-        uint32_t sl = (key * 0x9E3779B1u) >> (32 - 13);
-        for (uint32_t probe = 0; probe < kCkcShareSlots; probe++, sl = (sl + 1u) & (kCkcShareSlots - 1u)) {
-            const unsigned long long old = atomicCAS(&tab[sl], EMPTY, e);
-            if (old == EMPTY)
-                break;
-            if ((uint32_t)(old >> 32) == key) {
-                const uint32_t other = (uint32_t)old;
-                if (other != ref) { // two k-mers on one counter: neither is private
-                    atomicOr(&R.flags[(ref >> 11) * (kCkcSlots / 32) + ((ref & 2047u) >> 5)], 1u << (ref & 31u));
-                    atomicOr(&R.flags[(other >> 11) * (kCkcSlots / 32) + ((other & 2047u) >> 5)], 1u << (other & 31u));
+        tab[i] = 0; // epoch 0: never a unit's
+    unsigned long long ep = 0;
+    const uint32_t n_units = n_pairs * g.n_groups;
+    for (uint32_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        __syncthreads(); // the unit before is done with the table
+        if (++ep == (1ull << 20)) { // (a million units per workgroup: the tags start over on a clean table; before any `continue`: the epoch is the workgroup's, not a thread's)
+            for (uint32_t i = tid; i < kCkcShareSlots; i += 256)
+                tab[i] = 0;
+            ep = 1;
+            __syncthreads();
+        }
+        const uint32_t pair = unit / g.n_groups, grp = unit % g.n_groups;
+        if (!g.pair_nb[pair])
+            continue;
+        const CkcRegion R = ckc_region(c, g, pair);
+        if (*R.over)
+            continue;
+        const uint32_t capg = g.pair_capg[pair];
+        const uint32_t n = R.cur_g[grp];
+        if (n > kCkcShareSlots / 4 * 3) {
+            if (tid == 0)
+                *R.over = 1u;
+            continue;
+        }
+        const unsigned long long* const ent = R.ent + (uint64_t)grp * capg;
+        for (uint32_t i = tid; i < n; i += 256) {
+            const unsigned long long e = ent[i];
+            const uint32_t key = (uint32_t)(e >> 32), ref = (uint32_t)e;
+            const unsigned long long mine = (ep << 44) | ((unsigned long long)key << 20) | ref;
+            uint32_t sl = (key * 0x9E3779B1u) >> (32 - 13);
+            unsigned long long old = tab[sl];
+            for (uint32_t probe = 0; probe < kCkcShareSlots;) {
+                if ((old >> 44) != ep) { // free for this unit
+                    const unsigned long long prev = atomicCAS(&tab[sl], old, mine);
+                    if (prev == old)
+                        break; // in
+                    old = prev; // somebody else took the slot meanwhile: look at what is there now
+                    continue;
                 }
-                break;
+                if (((uint32_t)(old >> 20) & 0xFFFFFFu) == key) { // (same epoch, same counter)
+                    const uint32_t other = (uint32_t)old & 0xFFFFFu;
+                    if (other != ref) { // two k-mers on one counter: neither is private
+                        atomicOr(&R.flags[(ref >> 11) * (kCkcSlots / 32) + ((ref & 2047u) >> 5)], 1u << (ref & 31u));
+                        atomicOr(&R.flags[(other >> 11) * (kCkcSlots / 32) + ((other & 2047u) >> 5)], 1u << (other & 31u));
+                    }
+                    break;
+                }
+                sl = (sl + 1u) & (kCkcShareSlots - 1u);
+                old = tab[sl];
+                probe++;
             }
         }
     }
@@ -1559,39 +1593,37 @@ __global__ __launch_bounds__(256) void ckc_apply(AArgs a, CensusArgs c, CkcArgs 
         s_private = 0;
     __syncthreads();
     const uint4* const rec = R.rec + (uint64_t)bkt * capb;
+    const uint64_t bit0 = c.pair_bit_off[pair];
     for (uint32_t i = tid; i < n; i += 256) {
         const uint4 r = rec[i];
-        if (atomicAdd(&cnt[r.w], 1u) == 0u) { // (every record of a slot carries the same hash)
+        if ((flg[r.w >> 5] >> (r.w & 31u)) & 1u) { // a copy of a k-mer that shares a counter: replayed
+            const uint64_t bit = bit0 + r.z;
+            atomicOr(&g.cand2[bit >> 6], 1ULL << (bit & 63));
+        } else if (atomicAdd(&cnt[r.w], 1u) == 0u) { // (every record of a slot carries the same hash)
             hlo[r.w] = r.x;
             hhi[r.w] = r.y;
         }
     }
     __syncthreads();
     unsigned long long mine = 0;
+    uint32_t* const bf = a.bf + (uint64_t)stream * a.bf_words;
     for (uint32_t sl = tid; sl < kCkcSlots; sl += 256) {
         const uint32_t m = cnt[sl];
-        if (!m || ((flg[sl >> 5] >> (sl & 31u)) & 1u))
+        if (!m)
             continue;
         mine += m;
         if (m >= need) {
+            // (no look at the word first, as bf_insert does: this is the k-mer's one insertion, and an
+            // atomic whose result nobody waits for costs the lane nothing)
             const uint64_t base = ((uint64_t)hhi[sl] << 32) | hlo[sl];
-            uint64_t hv[kMaxHash];
-            hv[0] = base;
-            for (uint32_t i = 1; i < a.hash_num; i++)
-                hv[i] = ext_hash(base, k, i);
-            bf_insert(a, stream, hv);
+            for (uint32_t i = 0; i < a.hash_num; i++) {
+                const uint64_t nbit = fastmod(i ? ext_hash(base, k, i) : base, a.bf_mod);
+                atomicOr(&bf[nbit >> 5], 1u << (uint32_t)(nbit & 31));
+            }
         }
     }
     if (mine)
         atomicAdd(&s_private, mine);
-    const uint64_t bit0 = c.pair_bit_off[pair];
-    for (uint32_t i = tid; i < n; i += 256) {
-        const uint4 r = rec[i];
-        if ((flg[r.w >> 5] >> (r.w & 31u)) & 1u) {
-            const uint64_t bit = bit0 + r.z;
-            atomicOr(&g.cand2[bit >> 6], 1ULL << (bit & 63));
-        }
-    }
     __syncthreads();
     if (tid == 0) {
         if (s_private)
@@ -2400,6 +2432,7 @@ int stage_a_run(gp_job* job)
     job->t_round.reset();
     job->t_local.reset();
     job->t_census.reset();
+    job->t_ckc.reset();
     job->counters.a_rounds = 0;
 
     // fresh filters + free reservation tables (the counting-filter arena is cleared slot by slot,
@@ -2472,8 +2505,12 @@ int stage_a_run(gp_job* job)
     // Arena slots of the grid-wide groups: a group is a run of consecutive entries of `order`,
     // batch i of the group holds slots [i * n_k, (i + 1) * n_k).  The grouping below depends on
     // nothing but these sizes, so the whole table is known now.
+    // (default: as many batches as keep the group's counting filters inside the 256 MB Infinity Cache --
+    // 4 batches x 4 k x 10 MiB; SURVEY 8d's 48 long contigs in one group of 192 filters = 2 GiB took 6.92 s
+    // per step for their filters, in groups of 4: 5.97 s, 8: 6.22 s, 16: 6.66 s, same bits)
+    const uint64_t group_fit = std::max<uint64_t>(1, (200ull << 20) / ((uint64_t)p.n_k * a.cbf_stride));
     const uint32_t group_cap = (uint32_t)std::max<uint64_t>(
-        1, std::min<uint64_t>({ std::max<uint64_t>(1, env_u64("GP_STAGE_A_GROUP", 2048)),
+        1, std::min<uint64_t>({ std::max<uint64_t>(1, env_u64("GP_STAGE_A_GROUP", group_fit)),
                                 std::max<uint64_t>(1, job->window / kTile),
                                 std::max<uint64_t>(1, job->cbf_slots / p.n_k) }));
     {
@@ -2543,13 +2580,18 @@ int stage_a_run(gp_job* job)
             // measured: 91.7 against 91.8 ms per 1000 contigs, the pack beside the next mark costs what it
             // saves.  =0: one set, one stream)
             const uint64_t overlap = env_u64("GP_STAGE_A_CENSUS_OVERLAP", 1);
-            const uint32_t n_sets = overlap == 0 ? 1u : overlap == 3 ? 3u : 2u;
+            // candidates by k-mer (GP_STAGE_A_CKC=0: every candidate is replayed, as before round 4)
+            const bool ckc_on = env_u64("GP_STAGE_A_CKC", 1) != 0 && p.hash_num <= 4 && p.cbf_bytes <= (1ull << 30); // (ckc_share's table holds 24 bits of a counter's place in its group)
+            // With the candidates-by-k-mer kernels behind every cohort's pack a set of buffers is busy for four
+            // kernels in a row (scatter, mark, pack, ckc_*): three sets and the ckc_* kernels on the third
+            // stream, so that a cohort's grouping runs beside the next one's mark and the scatter of the one
+            // after (GP_STAGE_A_CKC_STREAM=0: two sets, the ckc_* kernels behind the pack on its stream)
+            const bool ckc_stream = ckc_on && overlap == 1 && env_u64("GP_STAGE_A_CKC_STREAM", 1) != 0;
+            const uint32_t n_sets = overlap == 0 ? 1u : (overlap == 3 || ckc_stream) ? 3u : 2u;
             const uint64_t scatter_per_cu = env_u64("GP_STAGE_A_SCATTER_PER_CU", n_sets > 1 ? 2 : 0); // census_scatter workgroups per CU (0: no cap on its grid)
             const uint64_t rec_budget = (env_u64("GP_STAGE_A_CENSUS_MB", 16384) << 20) / 4 / n_sets; // (4-byte) record slots of a cohort
             h_pair_mode.assign(n_pairs, 0);
             h_pair_bit_off.assign(n_pairs, 0);
-            // candidates by k-mer (GP_STAGE_A_CKC=0: every candidate is replayed, as before round 4)
-            const bool ckc_on = env_u64("GP_STAGE_A_CKC", 1) != 0 && p.hash_num <= 4;
             std::vector<uint8_t> batch_uniform_thr(job->n_batches, 0);
             std::vector<uint32_t> batch_thr_seg(job->n_batches, 0); // a contig of the batch that has reads
             for (uint32_t bi = 0; bi < job->n_batches; bi++) {
@@ -2672,7 +2714,8 @@ int stage_a_run(gp_job* job)
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&census_mark<kCRunWide, kMarkBlockWide>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
                 hipStream_t sm = n_sets > 1 ? job->a_stream2 : s;  // mark
-                hipStream_t sp = n_sets > 2 ? job->a_stream3 : sm; // pack
+                hipStream_t sp = (n_sets > 2 && !ckc_stream) ? job->a_stream3 : sm; // pack
+                hipStream_t sc = ckc_stream ? job->a_stream3 : sp;                   // candidates by k-mer
                 for (size_t ci = 0; ci < cohorts.size(); ci++) {
                     Cohort& co = cohorts[ci];
                     const uint32_t set = (uint32_t)(ci % n_sets);
@@ -2778,15 +2821,25 @@ int stage_a_run(gp_job* job)
                         g.n_groups = ckc_groups;
                         g.cand2 = job->d_cand2.p;
                         const uint32_t span = co.ckc_max_nb;
-                        hipLaunchKernelGGL(ckc_init, dim3((unsigned)np), dim3(256), 0, sp, c, g, (uint32_t)np);
-                        hipLaunchKernelGGL(ckc_scatter, dim3((unsigned)nw), dim3(256), 0, sp, a, c, g);
-                        hipLaunchKernelGGL(ckc_group, dim3((unsigned)(np * span)), dim3(256), 0, sp, a, c, g, span);
-                        hipLaunchKernelGGL(ckc_share, dim3((unsigned)(np * ckc_groups)), dim3(256), 0, sp, c, g);
-                        hipLaunchKernelGGL(ckc_apply, dim3((unsigned)(np * span)), dim3(256), 0, sp, a, c, g, span);
+                        if (sc != sp) { // (ev_marked is free in this arrangement: mark and pack share a stream)
+                            GP_HIP(hipEventRecord(ev_marked, sp));
+                            GP_HIP(hipStreamWaitEvent(sc, ev_marked, 0));
+                        }
+                        if ((rcc = job->t_ckc.begin(sc, co.pair_batch.size())) != GP_OK)
+                            return rcc;
+                        hipLaunchKernelGGL(ckc_init, dim3((unsigned)np), dim3(256), 0, sc, c, g, (uint32_t)np);
+                        hipLaunchKernelGGL(ckc_scatter, dim3((unsigned)nw), dim3(256), 0, sc, a, c, g);
+                        hipLaunchKernelGGL(ckc_group, dim3((unsigned)(np * span)), dim3(256), 0, sc, a, c, g, span);
+                        hipLaunchKernelGGL(ckc_share, dim3((unsigned)std::min<uint64_t>(np * ckc_groups, 2ull * job->ctx->prop.multiProcessorCount)), dim3(256), 0, sc, c, g, (uint32_t)np);
+                        hipLaunchKernelGGL(ckc_apply, dim3((unsigned)(np * span)), dim3(256), 0, sc, a, c, g, span);
                         GP_HIP(hipGetLastError());
-                    }
-                    if (n_sets > 1)
+                        if ((rcc = job->t_ckc.end(sc)) != GP_OK)
+                            return rcc;
+                        if (n_sets > 1)
+                            GP_HIP(hipEventRecord(ev_packed, sc)); // the set is free when its grouping is done
+                    } else if (n_sets > 1) {
                         GP_HIP(hipEventRecord(ev_packed, sp));
+                    }
                 }
                 if (n_sets > 1) // everything has been packed before the replay starts
                     for (uint32_t set = 0; set < n_sets && set < cohorts.size(); set++)
@@ -3154,7 +3207,7 @@ int stage_a_run(gp_job* job)
     if (rc != GP_OK)
         return rc;
     if ((rc = job->t_round.collect()) != GP_OK || (rc = job->t_local.collect()) != GP_OK ||
-        (rc = job->t_census.collect()) != GP_OK)
+        (rc = job->t_census.collect()) != GP_OK || (rc = job->t_ckc.collect()) != GP_OK)
         return rc;
     job->filters_ready = true;
     return GP_OK;

@@ -310,9 +310,11 @@ int gp_job_get_sequences_device(gp_job* job, void* device_buf, uint64_t buf_byte
  * as it was before the call (a new one removed, an appended one cut back). */
 int gp_job_write_fasta(gp_job* job, const char* const* names, const char* path, int append);
 int gp_job_get_counters(gp_job* job, gp_counters* out);
-/* Average device time (ms) of the dominant stage-A kernel's launches since the
- * last gp_job_build_filters, measured with HIP events on the context stream,
- * and the number of launches and streamed positions it covered. */
+/* Device time (ms, HIP events on the stream the kernels run on) of a kernel family since the last
+ * gp_job_build_filters / gp_job_polish, the number of timed spans and the units they covered.
+ * kernel: "cbf_first_pass", "cbf_round" (grid-wide schedule), "cbf_census" (census_scatter / _mark /
+ * _pack and, inside the same span, "cbf_ckc": the candidates-by-k-mer kernels), "cbf_local",
+ * "ntedit_scan" (with ntedit_site_eval), "ntedit_walk", "mask", "sealer_bfs", "upper". */
 int gp_job_kernel_time(gp_job* job, const char* kernel, double* total_ms, uint64_t* launches,
                        uint64_t* units);
 

@@ -9,8 +9,13 @@ from goldpolish_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def test_stream_of_sets_equals_single_jobs_and_the_oracle(oracle):
+@pytest.mark.parametrize("overlap", ["1", "0", "2"])
+def test_stream_of_sets_equals_single_jobs_and_the_oracle(oracle, overlap, monkeypatch):
+    """overlap 1: four stages, the filter build of a set on 7 CUs in 8 beside the back half of the set
+    before on the eighth (the default); 0: build and back half in one thread on the whole chip (round 3);
+    2: four stages without CU masks"""
     from goldpolish_amd import core
+    monkeypatch.setenv("GP_PIPELINE_OVERLAP", overlap)
     p = core.default_params()
     shapes = [[9000, 4000, 12000], [300, 7000], [25000, 90, 6000, 5000], [15000], [8000, 8000]]
     ws = [synth.make_workload(l, 25, seed=70 + i) for i, l in enumerate(shapes)]

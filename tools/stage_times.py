@@ -9,7 +9,7 @@ n, L, cov = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
 w = synth.make_workload_chunked([L] * n, cov, seed=3, chunk=50)
 from goldpolish_amd import core
 p = core.default_params()
-names = ("cbf_census", "cbf_local", "cbf_first_pass", "cbf_round", "ntedit_scan", "ntedit_walk", "sealer_bfs", "mask")
+names = ("cbf_census", "cbf_ckc", "cbf_local", "cbf_first_pass", "cbf_round", "ntedit_scan", "ntedit_walk", "sealer_bfs", "mask")
 def run(tag):
     with core.Context(0) as ctx, core.Job.from_workload(ctx, p, w) as job:
         best = None
