@@ -1116,8 +1116,9 @@ try {
     }
     GP_HIP(hipStreamSynchronize(job->ctx->stream));
     const uint64_t words = job->prm.bf_bytes / 4;
-    GP_HIP(hipMemcpy(out, job->d_bf.p + ((uint64_t)batch * job->prm.n_k + k_index) * words,
-                     job->prm.bf_bytes, hipMemcpyDeviceToHost));
+    GP_HIP(hipMemcpyAsync(out, job->d_bf.p + ((uint64_t)batch * job->prm.n_k + k_index) * words,
+                          job->prm.bf_bytes, hipMemcpyDeviceToHost, job->ctx->stream));
+    GP_HIP(hipStreamSynchronize(job->ctx->stream));
     return GP_OK;
 } GP_CATCH("gp_job_get_filter")
 
@@ -1129,9 +1130,9 @@ try {
     if (int rcw = ensure_work(job, "gp_job_set_filters"))
         return rcw;
     GP_HIP(hipStreamSynchronize(job->ctx->stream));
-    GP_HIP(hipMemcpy(job->d_bf.p, filters,
-                     (uint64_t)job->n_batches * job->prm.n_k * job->prm.bf_bytes,
-                     hipMemcpyHostToDevice));
+    GP_HIP(hipMemcpyAsync(job->d_bf.p, filters, (uint64_t)job->n_batches * job->prm.n_k * job->prm.bf_bytes,
+                          hipMemcpyHostToDevice, job->ctx->stream));
+    GP_HIP(hipStreamSynchronize(job->ctx->stream));
     job->filters_ready = true;
     return GP_OK;
 } GP_CATCH("gp_job_set_filters")

@@ -2,25 +2,32 @@
 // memory (SURVEY.md 8d's timed region: reads + contigs resident in host memory -> polished bytes
 // in host memory).  Host C++ only; the device work is gp_job_create / gp_job_polish.
 //
-// Four stages run side by side, each in a thread of its own, connected by bounded queues:
-//   upload   gp_job_create of set i + 2 on the pipeline's upload context (pinned staging, DMA on
+// Three stages run side by side, each in a thread of its own, connected by bounded queues:
+//   upload   gp_job_create of set i + 1 on the pipeline's upload context (pinned staging, DMA on
 //            that context's stream) ...
-//   build    ... while the filters of set i + 1 are built on the build context, whose streams are
-//            restricted to 7 CUs in 8 (gp_ctx_create_masked): the filter build is streaming kernels that
-//            fill every wave slot they are given ...
-//   polish   ... while set i runs everything behind the filters (ntEdit cascade, mask, Sealer, upper) on
-//            the polishing context -- the eighth CU of every eight: latency-bound kernels of a few
-//            thousand small workgroups, 10 % slower there than on the whole chip -- its polished records
+//   polish   ... while set i runs the whole path on the polishing context; its polished records
 //            are packed into an HBM buffer, copied to pinned host memory, and the job is destroyed
 //            (its device blocks go to the pool and are what the next job's first use takes) ...
 //   collect  ... while the caller still reads the result of set i - 1.
-// GP_PIPELINE_OVERLAP=0: build and polish in one thread on one unmasked context (round 3's three
-// stages); 2: four stages, no CU masks.  Measured with two jobs of 1000 x 25 kbp (tools/overlap_cu_probe.py):
-// one after the other 601 ms, two unmasked streams 598 ms, build on 224 CUs | back half on 32: 561 ms
-// (192 | 64 as contiguous ranges: 1139 ms -- a range of CU bits is a few shader engines, not a share of each).
 // Results come back in submission order -- the ordered append of scripts/goldpolish-reaper:51-73.
 // The reference overlaps the same things with processes: its filter server builds the next
 // batches' filters while polishing workers run (scripts/goldpolish:496-514).
+//
+// GP_PIPELINE_OVERLAP=1 splits `polish` in two (round 4, the review's overlap experiment): a BUILD thread
+// builds the filters of set i + 1 on a context whose streams are restricted to 7 CUs in 8
+// (gp_ctx_create_masked) while the polishing thread runs everything behind the filters of set i on the
+// eighth CU of every eight; =2: the same without CU masks.  Measured on BASELINE configs[2] (4000 x 25 kbp,
+// 40x), ms per step: three stages 920; four stages, masked 909 (the filter build's kernels take 862 ms
+// beside the back half instead of 664 alone, the back half 313 instead of 263); four stages, unmasked 906;
+// device memory 62 -> 90 GiB (two sets of filters and of stage B/C buffers).  The two halves do run side by
+// side (kernel trace) and the sum does not move: the filter build's streaming kernels fill every wave slot
+// they are given, and what the back half takes it takes from them.  So three stages stay the default.
+// (With CU-masked streams nothing in a job's path may touch the null stream: masked streams are created
+// BLOCKING, and a synchronous hipMemcpy / hipMemset waits for every blocking stream of the device -- the
+// first version of this ran the two halves strictly one after the other for that reason.  And a mask must
+// be interleaved: build on CUs [0, 192) | back half on [192, 256) took 1139 ms for two jobs of 1000 contigs
+// against 561 for 7-in-8 | 1-in-8 and 601 for one job after the other -- a range of CU bits is whole
+// shader engines, and workgroups are still dealt to all of them.)
 #include "gp_internal.h"
 
 #include <chrono>
@@ -274,7 +281,7 @@ try {
     int rc;
     if ((rc = gp_ctx_create(device, &p->up_ctx)) != GP_OK)
         return rc;
-    const uint64_t overlap = env_u64("GP_PIPELINE_OVERLAP", 1);
+    const uint64_t overlap = env_u64("GP_PIPELINE_OVERLAP", 0);
     if (overlap == 0) {
         if ((rc = gp_ctx_create(device, &p->run_ctx)) != GP_OK)
             return rc;

@@ -2288,14 +2288,18 @@ int stage_a_prepare(gp_job* job)
             }
             tm[bi] = run;
         }
+        // (on the context's stream, never the null stream: a null-stream copy waits for every BLOCKING stream
+        // of the device -- CU-masked streams are created blocking -- i.e. for another job's kernels)
+        hipStream_t s = job->ctx->stream;
         if (job->n_batches)
-            GP_HIP(hipMemcpy(job->d_batch_thr_max.p, tm.data(), tm.size() * sizeof(uint32_t),
-                             hipMemcpyHostToDevice));
+            GP_HIP(hipMemcpyAsync(job->d_batch_thr_max.p, tm.data(), tm.size() * sizeof(uint32_t),
+                                  hipMemcpyHostToDevice, s));
         if ((rc = job->d_seg_smax.alloc(smax.size())) != GP_OK || (rc = job->d_batch_seg.alloc(job->n_batches + 1)) != GP_OK)
             return rc;
-        GP_HIP(hipMemcpy(job->d_batch_seg.p, job->h_batch_contig_begin.data(), (job->n_batches + 1) * sizeof(uint32_t),
-                         hipMemcpyHostToDevice));
-        GP_HIP(hipMemcpy(job->d_seg_smax.p, smax.data(), smax.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        GP_HIP(hipMemcpyAsync(job->d_batch_seg.p, job->h_batch_contig_begin.data(), (job->n_batches + 1) * sizeof(uint32_t),
+                              hipMemcpyHostToDevice, s));
+        GP_HIP(hipMemcpyAsync(job->d_seg_smax.p, smax.data(), smax.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        GP_HIP(hipStreamSynchronize(s)); // tm and smax are locals
     }
     GP_HIP(hipHostMalloc((void**)&job->h_count_pinned, 4 * kRing * sizeof(uint32_t)));
     for (uint32_t i = 0; i < kRing; i++) {

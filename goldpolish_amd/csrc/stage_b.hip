@@ -3182,6 +3182,9 @@ int stage_bc_prepare(gp_job* job)
              ? GP_OK : (rc = b->site_rec.alloc(off + 64))) != GP_OK ||
         (rc = b->tile_first.alloc((size_t)n + 1)) != GP_OK || (rc = b->flags.alloc(n)) != GP_OK)
         return rc;
+    // (copies and clears on the context's stream, never the null stream: that one waits for every blocking
+    // stream of the device -- CU-masked streams are -- i.e. for another job's kernels)
+    hipStream_t sq = job->ctx->stream;
     {
         std::vector<uint32_t> tf((size_t)n + 1), tc;
         for (uint32_t c = 0; c < n; c++) {
@@ -3195,27 +3198,22 @@ int stage_bc_prepare(gp_job* job)
         if ((rc = b->tile_contig.alloc(tc.size())) != GP_OK)
             return rc;
         if (!tc.empty())
-            GP_HIP(hipMemcpy(b->tile_contig.p, tc.data(), tc.size() * sizeof(uint32_t),
-                             hipMemcpyHostToDevice));
-        GP_HIP(hipMemcpy(b->tile_first.p, tf.data(), tf.size() * sizeof(uint32_t),
-                         hipMemcpyHostToDevice));
+            GP_HIP(hipMemcpyAsync(b->tile_contig.p, tc.data(), tc.size() * sizeof(uint32_t), hipMemcpyHostToDevice, sq));
+        GP_HIP(hipMemcpyAsync(b->tile_first.p, tf.data(), tf.size() * sizeof(uint32_t), hipMemcpyHostToDevice, sq));
     }
-    GP_HIP(hipMemcpy(b->off.p, b->h_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-    GP_HIP(hipMemcpy(b->node_off.p, b->h_node_off.data(), (n + 1) * sizeof(uint64_t),
-                     hipMemcpyHostToDevice));
+    GP_HIP(hipMemcpyAsync(b->off.p, b->h_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, sq));
+    GP_HIP(hipMemcpyAsync(b->node_off.p, b->h_node_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, sq));
     if (n) {
-        GP_HIP(hipMemcpy(b->contig_batch.p, job->h_contig_batch.data(), n * sizeof(uint32_t),
-                         hipMemcpyHostToDevice));
-        GP_HIP(hipMemcpy(b->name_len.p, job->h_contig_name_len.data(), n * sizeof(uint32_t),
-                         hipMemcpyHostToDevice));
-        GP_HIP(hipMemcpy(b->in_len.p, in_len.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        GP_HIP(hipMemcpyAsync(b->contig_batch.p, job->h_contig_batch.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, sq));
+        GP_HIP(hipMemcpyAsync(b->name_len.p, job->h_contig_name_len.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, sq));
+        GP_HIP(hipMemcpyAsync(b->in_len.p, in_len.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, sq));
     }
-    GP_HIP(hipMemcpy(b->in_off.p, job->h_contig_off.data(), (n + 1) * sizeof(uint64_t),
-                     hipMemcpyHostToDevice));
-    GP_HIP(hipMemcpy(b->batch_begin.p, job->h_batch_contig_begin.data(),
-                     (job->n_batches + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
-    GP_HIP(hipMemset(b->err.p, 0, 4 * sizeof(uint32_t)));
-    GP_HIP(hipMemset(b->stats.p, 0, 16 * sizeof(unsigned long long)));
+    GP_HIP(hipMemcpyAsync(b->in_off.p, job->h_contig_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, sq));
+    GP_HIP(hipMemcpyAsync(b->batch_begin.p, job->h_batch_contig_begin.data(),
+                     (job->n_batches + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, sq));
+    GP_HIP(hipMemsetAsync(b->err.p, 0, 4 * sizeof(uint32_t), sq));
+    GP_HIP(hipMemsetAsync(b->stats.p, 0, 16 * sizeof(unsigned long long), sq));
+    GP_HIP(hipStreamSynchronize(sq)); // (in_len is a local)
     return stage_c_prepare(job);
 }
 
@@ -3864,8 +3862,9 @@ int stage_lengths(gp_job* job, uint64_t* lengths, uint8_t* dropped, uint64_t* to
     std::vector<uint32_t> len(n ? n : 1);
     std::vector<uint8_t> dr(n ? n : 1);
     if (n) {
-        GP_HIP(hipMemcpy(len.data(), b->len[b->cur].p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        GP_HIP(hipMemcpy(dr.data(), b->dropped.p, n, hipMemcpyDeviceToHost));
+        GP_HIP(hipMemcpyAsync(len.data(), b->len[b->cur].p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, job->ctx->stream));
+        GP_HIP(hipMemcpyAsync(dr.data(), b->dropped.p, n, hipMemcpyDeviceToHost, job->ctx->stream));
+        GP_HIP(hipStreamSynchronize(job->ctx->stream));
     }
     uint64_t t = 0;
     for (uint32_t c = 0; c < n; c++) {
@@ -3948,7 +3947,8 @@ int stage_sequences(gp_job* job, uint8_t* buf, uint64_t buf_bytes)
         return rc;
     if ((rc = pack_to_device(job, b->pack_buf.p, total, "gp_job_get_sequences")) != GP_OK)
         return rc;
-    GP_HIP(hipMemcpy(buf, b->pack_buf.p, total, hipMemcpyDeviceToHost));
+    GP_HIP(hipMemcpyAsync(buf, b->pack_buf.p, total, hipMemcpyDeviceToHost, job->ctx->stream));
+    GP_HIP(hipStreamSynchronize(job->ctx->stream));
     return GP_OK;
 }
 

@@ -1827,12 +1827,14 @@ int stage_c_prepare(gp_job* job)
                           (3ull * (kNwMax + 1) * (kNwMax + 1) + 2 * (2 * kNwMax + 64) / 4 + 64))) != GP_OK ||
         (rc = c->epoch.alloc(n_big)) != GP_OK)
         return rc;
-    GP_HIP(hipMemcpy(c->gap_off.p, c->h_gap_off.data(), (n + 1) * sizeof(uint32_t),
-                     hipMemcpyHostToDevice));
-    GP_HIP(hipMemset(c->slots.p, 0, n_big * kSlots * sizeof(uint32_t)));
-    GP_HIP(hipMemset(c->epoch.p, 0, n_big * sizeof(uint32_t)));
-    GP_HIP(hipMemset(c->m_slots.p, 0, (n_med << kMedSlotBits) * sizeof(uint32_t)));
-    GP_HIP(hipMemset(c->m_epoch.p, 0, n_med * sizeof(uint32_t)));
+    // (on the context's stream, not the null stream: see stage_bc_prepare)
+    hipStream_t sq = job->ctx->stream;
+    GP_HIP(hipMemcpyAsync(c->gap_off.p, c->h_gap_off.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, sq));
+    GP_HIP(hipMemsetAsync(c->slots.p, 0, n_big * kSlots * sizeof(uint32_t), sq));
+    GP_HIP(hipMemsetAsync(c->epoch.p, 0, n_big * sizeof(uint32_t), sq));
+    GP_HIP(hipMemsetAsync(c->m_slots.p, 0, (n_med << kMedSlotBits) * sizeof(uint32_t), sq));
+    GP_HIP(hipMemsetAsync(c->m_epoch.p, 0, n_med * sizeof(uint32_t), sq));
+    GP_HIP(hipStreamSynchronize(sq));
     return GP_OK;
 }
 

@@ -9,11 +9,11 @@ from goldpolish_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("overlap", ["1", "0", "2"])
+@pytest.mark.parametrize("overlap", ["0", "1", "2"])
 def test_stream_of_sets_equals_single_jobs_and_the_oracle(oracle, overlap, monkeypatch):
-    """overlap 1: four stages, the filter build of a set on 7 CUs in 8 beside the back half of the set
-    before on the eighth (the default); 0: build and back half in one thread on the whole chip (round 3);
-    2: four stages without CU masks"""
+    """overlap 0: build and back half in one thread on the whole chip (the default); 1: four stages, the
+    filter build of a set on 7 CUs in 8 beside the back half of the set before on the eighth; 2: four stages
+    without CU masks"""
     from goldpolish_amd import core
     monkeypatch.setenv("GP_PIPELINE_OVERLAP", overlap)
     p = core.default_params()
