@@ -817,7 +817,7 @@ def main():
         if seen > line["cpu_baseline"]["threads_used"] and w_main.n_contigs > 4:
             # once more on every hardware thread the process may use: the whole node's CPU figure, so that
             # the 8-GPU ratio needs no extrapolation from a 16-thread share
-            n_all = min(w_main.n_contigs, 12 * seen)
+            n_all = min(w_main.n_contigs, 2 * seen)   # (3072 batches took 256 threads 131 s: 0.59 Mbp/s, less than 16 threads' 1.32)
             line["cpu_baseline_all_cores"] = cpu_baseline(w_main, ks_main, desc_main, main_res.get("polished"),
                                                           sample=list(range(n_all)), threads=seen,
                                                           label="every hardware thread the process may use")

@@ -119,6 +119,7 @@ struct CState {
     DevBuf<uint32_t> epoch;        // per worker
     std::vector<uint32_t> h_gap_off;
     uint32_t gap_cap = 0, table_bits = 0, multi_cap = 0;
+    uint32_t lanes = 32;           // lanes of a sealer_connect_lanes wave that take a gap (the small arenas are allocated for that many)
     uint32_t n_big = 0;            // workers with full arenas (all of them where long contigs are polished, else kBigWorkers)
     uint32_t n_workers = 0;        // sealer_connect's grid: 1024 took 0.15 s per configs[2] step, 2048 0.10 s, 3072 (three waves per SIMD) 0.08 s, 4096 (four: the kernel fits 128 registers without a spill) 12 ms less
     uint64_t pool_cap = 0;
@@ -1263,7 +1264,7 @@ __global__ __launch_bounds__(64, 4) void sealer_connect_lanes(CArgs a, SmallAren
 {
     const uint32_t lane = threadIdx.x;
     const uint32_t n_work = a.queue[0];
-    SmallArena* mine = arenas + (uint64_t)blockIdx.x * kSimtLanes + (lane % kSimtLanes);
+    SmallArena* mine = arenas + (uint64_t)blockIdx.x * a.simt_lanes + (lane % a.simt_lanes);
     Search S;
     uint8_t r1[64], r2[64];
     for (;;) {
@@ -1757,6 +1758,9 @@ __global__ __launch_bounds__(kApplyThreads) void apply_fills(CArgs a)
 // ------------------------------------------------------------------ host side
 static CState* cstate(gp_job* job) { return (CState*)job->bc->c_state; }
 
+// lanes of a sealer_connect_lanes wave that take a gap, each with a small arena of its own (read once, when the job's arenas are allocated)
+static uint32_t sealer_lanes() { return (uint32_t)std::min<uint64_t>(kSimtLanes, std::max<uint64_t>(1, env_u64("GP_SEALER_LANES", 32))); }
+
 int stage_c_prepare(gp_job* job)
 {
     if (!job->prm.run_sealer)
@@ -1814,7 +1818,7 @@ int stage_c_prepare(gp_job* job)
         (rc = c->fill_len.alloc(g)) != GP_OK || (rc = c->table_left.alloc(1ull << tb)) != GP_OK ||
         (rc = c->table_pair.alloc(1ull << tb)) != GP_OK || (rc = c->work.alloc(g)) != GP_OK ||
         (rc = c->defer.alloc(g)) != GP_OK ||
-        (rc = c->small.alloc((uint64_t)kSimtWaves * kSimtLanes * sizeof(SmallArena))) != GP_OK ||
+        (rc = c->small.alloc((uint64_t)kSimtWaves * (c->lanes = sealer_lanes()) * sizeof(SmallArena))) != GP_OK ||
         (rc = c->queue.alloc(8)) != GP_OK || (rc = c->pool.alloc(c->pool_cap)) != GP_OK ||
         (rc = c->pool_head.alloc(1)) != GP_OK || (rc = c->multi.alloc(c->multi_cap)) != GP_OK ||
         (rc = c->slots.alloc(n_big * kSlots)) != GP_OK || (rc = c->verts.alloc(n_big * kVertCap)) != GP_OK ||
@@ -1906,7 +1910,7 @@ int stage_c_run(gp_job* job)
     a.err = b->err.p;
     a.stats = b->stats.p;
     a.flags = b->flags.p;
-    a.simt_lanes = (uint32_t)std::min<uint64_t>(kSimtLanes, std::max<uint64_t>(1, env_u64("GP_SEALER_LANES", 32)));
+    a.simt_lanes = c->lanes;
 
     GP_HIP(hipMemsetAsync(c->queue.p, 0, 8 * sizeof(uint32_t), s));
     GP_HIP(hipMemsetAsync(c->pool_head.p, 0, sizeof(unsigned long long), s));
