@@ -484,8 +484,9 @@ def main():
         whole workload: one upload, the path, one download (and at N > 1 the gather)."""
         params = core.default_params(k_values=ks)
         bs, keep = core.batch_set_of_workload(w)
-        # sets in the pipeline: one uploading, one being polished (GP_PIPELINE_OVERLAP=1 / 2: one more, in the filter build)
-        DEPTH = 3 if os.environ.get("GP_PIPELINE_OVERLAP", "0") != "0" else 2
+        # sets in the pipeline: one uploading, one being polished and -- for the sets gp_pipeline splits (those with
+        # long contigs) -- one more in the filter build
+        DEPTH = 2 if os.environ.get("GP_PIPELINE_OVERLAP") == "0" else 3
         pipe = core.Pipeline(device_index, params, depth=DEPTH)
         sums, times = [], {"upload_ms": [], "polish_ms": [], "download_ms": []}
         last = {}

@@ -13,15 +13,19 @@
 // The reference overlaps the same things with processes: its filter server builds the next
 // batches' filters while polishing workers run (scripts/goldpolish:496-514).
 //
-// GP_PIPELINE_OVERLAP=1 splits `polish` in two (round 4, the review's overlap experiment): a BUILD thread
-// builds the filters of set i + 1 on a context whose streams are restricted to 7 CUs in 8
-// (gp_ctx_create_masked) while the polishing thread runs everything behind the filters of set i on the
-// eighth CU of every eight; =2: the same without CU masks.  Measured on BASELINE configs[2] (4000 x 25 kbp,
-// 40x), ms per step: three stages 920; four stages, masked 909 (the filter build's kernels take 862 ms
-// beside the back half instead of 664 alone, the back half 313 instead of 263); four stages, unmasked 906;
-// device memory 62 -> 90 GiB (two sets of filters and of stage B/C buffers).  The two halves do run side by
-// side (kernel trace) and the sum does not move: the filter build's streaming kernels fill every wave slot
-// they are given, and what the back half takes it takes from them.  So three stages stay the default.
+// A set that holds a LONG contig (GP_PIPELINE_SPLIT_FROM bases, default 200 000) is split (round 4): a BUILD
+// thread builds its filters on a context whose streams are restricted to 6 CUs in 8 (gp_ctx_create_masked)
+// while the polishing thread runs everything behind the filters of the set before on the other two of every
+// eight.  GP_PIPELINE_OVERLAP: 3 (default) as said; 0 never; 1 every set (back half on GP_PIPELINE_BACK_SHARE
+// = 1 CU in 8); 2 every set, no masks.  Measured, ms per step:
+//   BASELINE configs[2] (4000 x 25 kbp, 40x): three stages 920; every set split, masked 7 | 1: 909 (the filter
+//   build's kernels take 862 ms beside the back half instead of 664 alone, the back half 313 instead of 263);
+//   unmasked 906; device memory 62 -> 90 GiB.  The two halves do run side by side (kernel trace) and the sum
+//   does not move: the build's streaming kernels fill every wave slot they are given, and what the back half
+//   takes it takes from them.  So read-length sets stay whole.
+//   SURVEY 8d config 3's own shape (48 contigs of 0.3-12 Mbp): whole 11 310; split 7 | 1: 9 906 -- the walk of
+//   6 100 segment workgroups takes 7.2 s on 32 CUs instead of 2.2 s on 256, the build 7.5 instead of 6.6;
+//   split 6 | 2 (the default for such sets): see DESIGN section 5.
 // (With CU-masked streams nothing in a job's path may touch the null stream: masked streams are created
 // BLOCKING, and a synchronous hipMemcpy / hipMemset waits for every blocking stream of the device -- the
 // first version of this ran the two halves strictly one after the other for that reason.  And a mask must
@@ -30,6 +34,7 @@
 // shader engines, and workgroups are still dealt to all of them.)
 #include "gp_internal.h"
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -71,6 +76,7 @@ struct Item {
     int rc = GP_OK;
     std::string msg;
     double upload_ms = 0, build_ms = 0;
+    bool split = false; // filter build and back half in two threads on two CU-masked contexts
 };
 
 double now_ms()
@@ -82,8 +88,10 @@ double now_ms()
 
 struct gp_pipeline {
     gp_ctx* up_ctx = nullptr;
-    gp_ctx* front_ctx = nullptr; // the filter build's (null: build and back half both on run_ctx, in the polishing thread)
-    gp_ctx* run_ctx = nullptr;
+    gp_ctx* front_ctx = nullptr; // the filter build's, for sets that are split (null: never; build and back half both on run_ctx, in the polishing thread)
+    gp_ctx* back_ctx = nullptr;  // the back half's of a split set
+    gp_ctx* run_ctx = nullptr;   // the whole path of a set that is not split
+    uint64_t split_from = 0;     // sets with a contig of this many bases or more are split (0 with front_ctx: every set)
     gp_params prm{};
     uint32_t depth = 2;
     std::mutex mu;
@@ -142,7 +150,7 @@ static void build_loop(gp_pipeline* p)
             p->uploaded.pop_front();
         }
         p->cv.notify_all(); // the upload thread may start on the next set
-        if (it.rc == GP_OK) {
+        if (it.rc == GP_OK && it.split) {
             const double t0 = now_ms();
             try {
                 it.job->ctx = p->front_ctx; // the upload is complete (gp_job_create waits for it)
@@ -169,9 +177,10 @@ static void build_loop(gp_pipeline* p)
 static int polish_one(gp_pipeline* p, Item& it, Slot& s)
 {
     gp_job* job = it.job;
-    job->ctx = p->run_ctx; // from here on the polishing context's stream
+    gp_ctx* const ctx = it.split ? p->back_ctx : p->run_ctx;
+    job->ctx = ctx; // from here on the polishing context's stream
     double t0 = now_ms();
-    int rc = p->front_ctx ? job_polish_back(job) : gp_job_polish(job, 1);
+    int rc = it.split ? job_polish_back(job) : gp_job_polish(job, 1);
     if (rc != GP_OK)
         return rc;
     s.polish_ms = now_ms() - t0 + it.build_ms;
@@ -198,8 +207,8 @@ static int polish_one(gp_pipeline* p, Item& it, Slot& s)
     if (s.total) {
         if ((rc = gp_job_get_sequences_device(job, s.d_bytes.p, s.total)) != GP_OK)
             return rc;
-        GP_HIP(hipMemcpyAsync(s.h_bytes, s.d_bytes.p, s.total, hipMemcpyDeviceToHost, p->run_ctx->stream));
-        GP_HIP(hipStreamSynchronize(p->run_ctx->stream));
+        GP_HIP(hipMemcpyAsync(s.h_bytes, s.d_bytes.p, s.total, hipMemcpyDeviceToHost, ctx->stream));
+        GP_HIP(hipStreamSynchronize(ctx->stream));
     }
     s.download_ms = now_ms() - t0;
     s.counters = job->counters;
@@ -247,7 +256,7 @@ static void polish_loop(gp_pipeline* p)
             }
         }
         if (it.job) {
-            it.job->ctx = p->run_ctx;
+            it.job->ctx = it.split ? p->back_ctx : p->run_ctx;
             gp_job_destroy(it.job); // its blocks go to the pool: the next job's work buffers
         }
         {
@@ -281,24 +290,30 @@ try {
     int rc;
     if ((rc = gp_ctx_create(device, &p->up_ctx)) != GP_OK)
         return rc;
-    const uint64_t overlap = env_u64("GP_PIPELINE_OVERLAP", 0);
-    if (overlap == 0) {
-        if ((rc = gp_ctx_create(device, &p->run_ctx)) != GP_OK)
-            return rc;
-    } else {
-        // the back half on every eighth CU, the filter build on the other seven (bit i of the mask = CU i;
-        // interleaved, so that each gets its share of every shader engine)
+    // GP_PIPELINE_OVERLAP: 0 never split a set; 1 split every set (CU-masked contexts); 2 split every set,
+    // no masks; 3 (default) split the sets that hold a long contig (GP_PIPELINE_SPLIT_FROM bases, default
+    // 200 000): there the back half -- segments of long contigs walked by thousands of workgroups, searches
+    // that branch -- is as long as the filter build and the two overlap for real (SURVEY 8d config 3's shape:
+    // 11.3 -> ... s per step), where for read-length contigs the sum does not move (header of this file).
+    const uint64_t overlap = env_u64("GP_PIPELINE_OVERLAP", 3);
+    if ((rc = gp_ctx_create(device, &p->run_ctx)) != GP_OK)
+        return rc;
+    if (overlap != 0) {
+        // the back half on `share` CUs of every eight (bit i of the mask = CU i; interleaved, so that each half
+        // gets its share of every shader engine), the filter build on the others
         const uint32_t n_cu = (uint32_t)p->up_ctx->prop.multiProcessorCount;
+        const uint32_t share = (uint32_t)std::min<uint64_t>(7, std::max<uint64_t>(1, env_u64("GP_PIPELINE_BACK_SHARE", overlap == 3 ? 2 : 1)));
         std::vector<uint32_t> front((n_cu + 31) / 32, 0), back((n_cu + 31) / 32, 0);
         for (uint32_t cu = 0; cu < n_cu; cu++)
-            (cu % 8 == 7 ? back : front)[cu / 32] |= 1u << (cu % 32);
-        if (overlap == 1 && n_cu >= 16) {
+            (cu % 8 >= 8 - share ? back : front)[cu / 32] |= 1u << (cu % 32);
+        if (overlap != 2 && n_cu >= 16) {
             if ((rc = gp_ctx_create_masked(device, front.data(), (uint32_t)front.size(), &p->front_ctx)) != GP_OK ||
-                (rc = gp_ctx_create_masked(device, back.data(), (uint32_t)back.size(), &p->run_ctx)) != GP_OK)
+                (rc = gp_ctx_create_masked(device, back.data(), (uint32_t)back.size(), &p->back_ctx)) != GP_OK)
                 return rc;
-        } else if ((rc = gp_ctx_create(device, &p->front_ctx)) != GP_OK || (rc = gp_ctx_create(device, &p->run_ctx)) != GP_OK) {
+        } else if ((rc = gp_ctx_create(device, &p->front_ctx)) != GP_OK || (rc = gp_ctx_create(device, &p->back_ctx)) != GP_OK) {
             return rc;
         }
+        p->split_from = overlap == 3 ? env_u64("GP_PIPELINE_SPLIT_FROM", 200000) : 0;
     }
     p->prm = *params;
     p->depth = depth < 1 ? 1 : depth > 8 ? 8 : depth;
@@ -322,6 +337,13 @@ try {
     Item it;
     it.set = *set;
     it.tag = tag;
+    if (p->front_ctx) {
+        uint64_t longest = 0;
+        if (p->split_from && set->contig_off)
+            for (uint32_t c = 0; c < set->n_contigs; c++)
+                longest = std::max<uint64_t>(longest, set->contig_off[c + 1] - set->contig_off[c]);
+        it.split = p->split_from == 0 || longest >= p->split_from;
+    }
     {
         std::unique_lock<std::mutex> g(p->mu);
         if (p->in_flight >= p->depth) {
@@ -436,6 +458,7 @@ void gp_pipeline_destroy(gp_pipeline* p)
         }
         gp_ctx_destroy(p->up_ctx);
         gp_ctx_destroy(p->front_ctx);
+        gp_ctx_destroy(p->back_ctx);
         gp_ctx_destroy(p->run_ctx);
         delete p;
     } catch (...) {

@@ -9,11 +9,12 @@ from goldpolish_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("overlap", ["0", "1", "2"])
+@pytest.mark.parametrize("overlap", ["3", "0", "1", "2"])
 def test_stream_of_sets_equals_single_jobs_and_the_oracle(oracle, overlap, monkeypatch):
-    """overlap 0: build and back half in one thread on the whole chip (the default); 1: four stages, the
-    filter build of a set on 7 CUs in 8 beside the back half of the set before on the eighth; 2: four stages
-    without CU masks"""
+    """overlap 3 (the default): sets with a long contig are split -- their filter build on 6 CUs in 8 beside
+    the back half of the set before on the other two -- the rest runs whole (here: the set with the 25 kbp
+    contig is split, GP_PIPELINE_SPLIT_FROM lowered); 0: never; 1: every set, 7 | 1; 2: every set, no masks"""
+    monkeypatch.setenv("GP_PIPELINE_SPLIT_FROM", "20000")
     from goldpolish_amd import core
     monkeypatch.setenv("GP_PIPELINE_OVERLAP", overlap)
     p = core.default_params()

@@ -9,12 +9,12 @@ import pathlib
 import shutil
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
 # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports exactly half the bytes of a WIDE COALESCED
 # STREAMING read; random 1-byte loads are reported at their 64-byte line (calibrated with
 # tools/probes/random_rmw_probe: profiles/r02_probe_pmc_traffic.json).  These kernels stream their
 # input (records, bitmaps, sequence tiles): their FETCH_SIZE is doubled in "FETCH_SIZE_corrected".
-STREAMING = ("gp::census_mark", "gp::census_pack", "gp::ntedit_scan", "gp::materialize_kernel", "gp::mask_kernel",
+STREAMING = ("gp::census_mark", "gp::census_pack", "gp::ckc_scatter", "gp::ckc_group", "gp::ckc_share", "gp::ckc_apply", "gp::ntedit_scan", "gp::materialize_kernel", "gp::mask_kernel",
              "gp::upper_kernel", "gp::copy_contigs", "gp::copy_flagged", "gp::pack_kernel", "gp::classify_kernel")
 raw = pathlib.Path("gpurun_out/profiles_raw")
 out = pathlib.Path("profiles")
