@@ -26,6 +26,8 @@
 //   SURVEY 8d config 3's own shape (48 contigs of 0.3-12 Mbp): whole 11 310; split 7 | 1: 9 906 -- the walk of
 //   6 100 segment workgroups takes 7.2 s on 32 CUs instead of 2.2 s on 256, the build 7.5 instead of 6.6;
 //   split 6 | 2 (the default for such sets): see DESIGN section 5.
+// A split set of fewer than GP_PIPELINE_MASK_FROM contigs (default 4) runs its halves on contexts WITHOUT masks
+// (the build on front_plain, the back half on run_ctx): see gp_pipeline_create.
 // (With CU-masked streams nothing in a job's path may touch the null stream: masked streams are created
 // BLOCKING, and a synchronous hipMemcpy / hipMemset waits for every blocking stream of the device -- the
 // first version of this ran the two halves strictly one after the other for that reason.  And a mask must
@@ -76,7 +78,8 @@ struct Item {
     int rc = GP_OK;
     std::string msg;
     double upload_ms = 0, build_ms = 0;
-    bool split = false; // filter build and back half in two threads on two CU-masked contexts
+    bool split = false; // filter build and back half in two threads on two contexts ...
+    bool masked = false; // ... CU-masked ones
 };
 
 double now_ms()
@@ -92,6 +95,8 @@ struct gp_pipeline {
     gp_ctx* back_ctx = nullptr;  // the back half's of a split set
     gp_ctx* run_ctx = nullptr;   // the whole path of a set that is not split
     uint64_t split_from = 0;     // sets with a contig of this many bases or more are split (0 with front_ctx: every set)
+    gp_ctx* front_plain = nullptr; // the filter build's for split sets of fewer than mask_from contigs: no CU mask (their back half: run_ctx)
+    uint32_t mask_from = 0;
     gp_params prm{};
     uint32_t depth = 2;
     std::mutex mu;
@@ -153,7 +158,7 @@ static void build_loop(gp_pipeline* p)
         if (it.rc == GP_OK && it.split) {
             const double t0 = now_ms();
             try {
-                it.job->ctx = p->front_ctx; // the upload is complete (gp_job_create waits for it)
+                it.job->ctx = it.masked ? p->front_ctx : p->front_plain; // the upload is complete (gp_job_create waits for it)
                 it.rc = job_polish_front(it.job);
                 if (it.rc != GP_OK)
                     it.msg = gp_last_error();
@@ -177,7 +182,7 @@ static void build_loop(gp_pipeline* p)
 static int polish_one(gp_pipeline* p, Item& it, Slot& s)
 {
     gp_job* job = it.job;
-    gp_ctx* const ctx = it.split ? p->back_ctx : p->run_ctx;
+    gp_ctx* const ctx = (it.split && it.masked) ? p->back_ctx : p->run_ctx;
     job->ctx = ctx; // from here on the polishing context's stream
     double t0 = now_ms();
     int rc = it.split ? job_polish_back(job) : gp_job_polish(job, 1);
@@ -256,7 +261,7 @@ static void polish_loop(gp_pipeline* p)
             }
         }
         if (it.job) {
-            it.job->ctx = it.split ? p->back_ctx : p->run_ctx;
+            it.job->ctx = (it.split && it.masked) ? p->back_ctx : p->run_ctx;
             gp_job_destroy(it.job); // its blocks go to the pool: the next job's work buffers
         }
         {
@@ -314,6 +319,14 @@ try {
             return rc;
         }
         p->split_from = overlap == 3 ? env_u64("GP_PIPELINE_SPLIT_FROM", 200000) : 0;
+        // A split set of FEWER than GP_PIPELINE_MASK_FROM contigs (default 4; 0: masks always) takes contexts
+        // without masks: its filter build is the grid-wide schedule on a handful of filters -- thousands of
+        // small launches steered by host feedback -- and on CU-masked streams the gaps between those launches
+        // grow (BASELINE configs[1], one 10 Mbp contig: 53 ms per step whole, 88 split with masks, 48 split
+        // without; SURVEY 8d config 3's 48 contigs: 8.2 s whole, 6.9 split without masks, 6.5 with).
+        p->mask_from = overlap == 3 ? (uint32_t)env_u64("GP_PIPELINE_MASK_FROM", 4) : 0;
+        if (p->mask_from && (rc = gp_ctx_create(device, &p->front_plain)) != GP_OK)
+            return rc;
     }
     p->prm = *params;
     p->depth = depth < 1 ? 1 : depth > 8 ? 8 : depth;
@@ -343,6 +356,7 @@ try {
             for (uint32_t c = 0; c < set->n_contigs; c++)
                 longest = std::max<uint64_t>(longest, set->contig_off[c + 1] - set->contig_off[c]);
         it.split = p->split_from == 0 || longest >= p->split_from;
+        it.masked = it.split && set->n_contigs >= p->mask_from;
     }
     {
         std::unique_lock<std::mutex> g(p->mu);
@@ -458,6 +472,7 @@ void gp_pipeline_destroy(gp_pipeline* p)
         }
         gp_ctx_destroy(p->up_ctx);
         gp_ctx_destroy(p->front_ctx);
+        gp_ctx_destroy(p->front_plain);
         gp_ctx_destroy(p->back_ctx);
         gp_ctx_destroy(p->run_ctx);
         delete p;

@@ -803,6 +803,26 @@ constexpr uint32_t kCMaxShift = 14;       // counters per range: 14 bits of a re
 constexpr uint32_t kCBucketsWide = 1024, kCRunWide = 128, kCRingWide = 16;
 static_assert(kCBuckets * kCRun == kCBucketsWide * kCRunWide, "the record buffers are sized alike");
 
+// Where the run of (range `bucket`, stretch `stretch`) of a pair of `nst` stretches starts in the pair's
+// record space, in runs.  Stretches come in SEGMENTS of 128: [segment][range][stretch in the segment], so
+// that the ranges' runs of one stretch -- which census_scatter writes and census_pack reads side by side --
+// lie at most 128 runs (64 KB) apart however long the pair is.  With one flat [range][stretch] table a pair
+// of 100 M positions (12 000 stretches: the census level by level on a 2.5 Mbp contig) put them 6 MB
+// apart -- 640 pages per stretch -- and the level-by-level census took 17 s where the model said 2.  A pair
+// of up to 128 stretches has one segment: the layout it always had.
+constexpr uint32_t kCSeg = 128;
+__host__ __device__ inline uint64_t census_run_index(uint32_t nst, uint32_t n_buckets, uint32_t bucket, uint32_t stretch)
+{
+    const uint32_t stride = nst < kCSeg ? nst : kCSeg;
+    return ((uint64_t)(stretch / kCSeg) * n_buckets + bucket) * stride + stretch % kCSeg;
+}
+// runs in a pair's record space
+__host__ __device__ inline uint64_t census_runs(uint32_t nst, uint32_t n_buckets)
+{
+    const uint32_t stride = nst < kCSeg ? nst : kCSeg;
+    return (uint64_t)((nst + kCSeg - 1) / kCSeg) * n_buckets * stride;
+}
+
 struct CensusArgs {
     const uint32_t* wg_pair;       // [workgroups] pair (cohort-local) of a stretch
     const uint64_t* wg_pos0;       // [workgroups] its first read position
@@ -822,6 +842,11 @@ struct CensusArgs {
     uint32_t bucket_shift;         // a range holds 1 << bucket_shift counters
     uint32_t n_buckets;            // ranges per pair
     uint32_t seed_rows;            // census_scatter: rows of its table of rotated seeds (the largest k)
+    // the census repeated level by level (long batches whose filters stay unsaturated: stage_a_levels)
+    const unsigned long long* members; // only the operations whose bit is set take part (null: all of them)
+    const uint32_t* pair_need;     // [pairs] census passes the pair takes (null: one); a pair is skipped from pass pair_need on
+    uint32_t level;                // the pass (0: positions and operations are counted)
+    unsigned long long* level_count; // census_pack: operations with every touch marked, over the launch (or null)
 };
 
 // ---- census 1: every counter touch of an 8192-position stretch into the bucket of its counter
@@ -895,6 +920,25 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
     const int t0 = threadIdx.x * SPAN;
     const uint32_t shift = c.bucket_shift, lmask = (1u << shift) - 1u, mod5_s = a.cbf_mod.s;
     bool over = false;
+    // the census level by level: a pair that has had its passes, or that overflowed, is left alone; a
+    // stretch without a member leaves empty runs
+    const unsigned long long* const members =
+        c.members ? c.members + ((c.pair_bit_off[pair] + (pos0 - b_start)) >> 6) : nullptr;
+    if (c.pair_need) {
+        if (c.level >= c.pair_need[pair] || c.overflow[pair])
+            continue; // (uniform: one pair per workgroup turn)
+        if (members) {
+            int any = 0;
+            if (threadIdx.x < kCStretch / 64 && pos0 + (uint64_t)threadIdx.x * 64 < stretch_end)
+                any = members[threadIdx.x] != 0ull;
+            if (!__syncthreads_or(any)) {
+                uint8_t* const cnt0 = c.cnt + c.pair_cnt_off[pair];
+                for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock)
+                    cnt0[(uint64_t)i * nst + stretch] = 0;
+                continue;
+            }
+        }
+    }
     for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock)
         hist[i] = 0;
     if (threadIdx.x < 8) {
@@ -934,6 +978,17 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
         if (tile0 >= stretch_end)
             break; // uniform
         const uint64_t tile_end = min(stretch_end, tile0 + (uint64_t)TILE);
+        if (members) {
+            // a tile without a member of this level: nothing to hash (the next tile's bases are still fetched)
+            int any = 0;
+            if (threadIdx.x < TILE / 64 && tile0 + (uint64_t)threadIdx.x * 64 < stretch_end)
+                any = members[((tile0 - pos0) >> 6) + threadIdx.x] != 0ull;
+            if (!__syncthreads_or(any)) {
+                if (tile0 + (uint64_t)TILE < stretch_end)
+                    fetch(tile0 + (uint64_t)TILE);
+                continue;
+            }
+        }
         __syncthreads(); // codes and ring free (and the counters cleared before the first use)
         {
             const int sh = (int)(tile0 & 3ull);
@@ -958,6 +1013,10 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
         // cbf_local only visits the candidates of a census pair: the counters of positions
         // streamed and of operations (valid k-mers) are kept here
         n_positions += lane_on ? (uint32_t)min((uint64_t)SPAN, tile_end - lane_pos0) : 0u;
+        // (the lane's SPAN positions start on a multiple of SPAN bits: one word holds their member bits)
+        const uint32_t mbits = (members && lane_on)
+                                   ? (uint32_t)(members[(lane_pos0 - pos0) >> 6] >> ((lane_pos0 - pos0) & 63)) & ((1u << SPAN) - 1u)
+                                   : 0xFFFFFFFFu;
         for (int rd = 0; rd < ROUNDS; rd++) {
             if (rd > 0)
                 __syncthreads(); // the round before has been flushed
@@ -978,6 +1037,8 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
                 if (!(last_bad < jj && pos + k <= a.n_pos))
                     continue;
                 n_ops++;
+                if (!((mbits >> jj) & 1u))
+                    continue; // not a member of this level
                 const uint64_t base = fh + rh;
                 const uint32_t off = (uint32_t)(st * TILE + t0 + jj); // position in the stretch
                 // the operation's touches side by side: their indices, then their LDS atomics in flight
@@ -1021,7 +1082,7 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
                         ring[in_win ? bucket * RING + (rank & (RING - 1u)) : spare] = r;
                         if (__builtin_expect(__ballot(!in_win && rank < RUN) != 0ull, 0))
                             if (!in_win && rank < RUN)
-                                rec[((uint64_t)bucket * nst + stretch) * RUN + rank] = r;
+                                rec[census_run_index(nst, c.n_buckets, bucket, stretch) * RUN + rank] = r;
                     }
                 }
             }
@@ -1039,7 +1100,7 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
                     ng = cnt > G * g0 ? (cnt - G * g0) / G : 0u; // (after such a round the window starts past the records)
                     g_next = g0 + ng;
                 }
-                uint4* const dst = reinterpret_cast<uint4*>(rec + ((uint64_t)i * nst + stretch) * RUN);
+                uint4* const dst = reinterpret_cast<uint4*>(rec + census_run_index(nst, c.n_buckets, i, stretch) * RUN);
                 const uint4* const src = reinterpret_cast<const uint4*>(ring + i * RING);
                 for (uint32_t g = g0; g < g0 + ng; g++)
                     dst[g * Q + part] = src[(g & 1u) * Q + part];
@@ -1055,7 +1116,7 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
         cnt[(uint64_t)i * nst + stretch] = (uint8_t)n;
         // what is left in the ring: less than a group
         for (uint32_t r = G * (hist[i] >> 16); r < n; r++)
-            rec[((uint64_t)i * nst + stretch) * RUN + r] = ring[i * RING + (r & (RING - 1u))];
+            rec[census_run_index(nst, c.n_buckets, i, stretch) * RUN + r] = ring[i * RING + (r & (RING - 1u))];
     }
     if (over)
         c.overflow[pair] = 1u; // many copies of one k-mer within the stretch: this pair is replayed whole
@@ -1065,7 +1126,7 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
         n_positions += (uint32_t)__shfl_down((int)n_positions, o);
         n_ops += (uint32_t)__shfl_down((int)n_ops, o);
     }
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0 && c.level == 0) { // (later passes stream the same positions again)
         atomicAdd(&a.stats[0], (unsigned long long)n_positions);
         atomicAdd(&a.stats[1], (unsigned long long)n_ops);
     }
@@ -1088,7 +1149,8 @@ __global__ __launch_bounds__(BLOCK, 8) void census_mark(CensusArgs c)
     if (c.overflow[pair])
         return;
     const uint32_t nst = c.pair_nst[pair];
-    uint32_t* const rec = c.rec + c.pair_rec_off[pair] + (uint64_t)bucket * nst * RUN;
+    uint32_t* const rec0 = c.rec + c.pair_rec_off[pair];
+    auto run_of = [&](uint32_t st) -> uint32_t* { return rec0 + census_run_index(nst, c.n_buckets, bucket, st) * RUN; };
     const uint8_t* cnt = c.cnt + c.pair_cnt_off[pair] + (uint64_t)bucket * nst;
     uint8_t* const s_cnt = reinterpret_cast<uint8_t*>(first_t + bucket_w);
     constexpr int kKeep = 128 / kMarkWaves; // 128 runs: a pair of a million positions
@@ -1099,7 +1161,7 @@ __global__ __launch_bounds__(BLOCK, 8) void census_mark(CensusArgs c)
 #pragma unroll
     for (int q = 0; q < kKeep; q++) {
         const uint32_t st = wave + (uint32_t)kMarkWaves * (uint32_t)q;
-        keep[q][0] = st < nst ? rec[(uint64_t)st * RUN + lane] : 0xFFFFFFFFu;
+        keep[q][0] = st < nst ? run_of(st)[lane] : 0xFFFFFFFFu;
     }
     for (uint32_t i = threadIdx.x; i < nst; i += BLOCK)
         s_cnt[i] = cnt[i];
@@ -1114,7 +1176,7 @@ __global__ __launch_bounds__(BLOCK, 8) void census_mark(CensusArgs c)
             keep[q][0] = 0xFFFFFFFFu;
 #pragma unroll
         for (int e = 1; e < PER; e++)
-            keep[q][e] = lane + 64u * e < n ? rec[(uint64_t)st * RUN + lane + 64u * e] : 0xFFFFFFFFu;
+            keep[q][e] = lane + 64u * e < n ? run_of(st)[lane + 64u * e] : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int q = 0; q < kKeep; q++)
@@ -1128,7 +1190,7 @@ __global__ __launch_bounds__(BLOCK, 8) void census_mark(CensusArgs c)
 #pragma unroll
         for (int e = 0; e < PER; e++)
             if (lane + 64u * e < s_cnt[st]) {
-                const uint32_t r = rec[(uint64_t)st * RUN + lane + 64u * e];
+                const uint32_t r = run_of(st)[lane + 64u * e];
                 atomicMin(&first_t[(r >> 2) & 0x3FFFu], st * kCStretch + (r >> 16));
             }
     __syncthreads();
@@ -1139,7 +1201,7 @@ __global__ __launch_bounds__(BLOCK, 8) void census_mark(CensusArgs c)
     // a run up to the first record without the bit; a run whose touches are all marked gets a zero
     // behind them (what lies past a run's records is left over from an earlier cohort).
     auto mark = [&](const uint32_t (&r)[PER], uint32_t st) { // every lane of the wave; r[e] == 0xFFFFFFFF: no record
-        uint32_t* const run = rec + (uint64_t)st * RUN;
+        uint32_t* const run = run_of(st);
         uint32_t n = 0;
 #pragma unroll
         for (int e = 0; e < PER; e++) {
@@ -1163,8 +1225,123 @@ __global__ __launch_bounds__(BLOCK, 8) void census_mark(CensusArgs c)
         uint32_t r[PER];
 #pragma unroll
         for (int e = 0; e < PER; e++)
-            r[e] = lane + 64u * e < s_cnt[st] ? rec[(uint64_t)st * RUN + lane + 64u * e] : 0xFFFFFFFFu;
+            r[e] = lane + 64u * e < s_cnt[st] ? run_of(st)[lane + 64u * e] : 0xFFFFFFFFu;
         mark(r, st);
+    }
+}
+
+// ---- census 2 for the census LEVEL BY LEVEL (stage_a_levels): the same marks, a pair of any length taken a
+// segment of 128 runs at a time, and from the second pass on fed by the pass before.
+template <uint32_t RUN, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 8) void census_mark_seg(CensusArgs c)
+{
+    constexpr int kMarkWaves = BLOCK / 64;
+    constexpr int PER = RUN / 64;         // records of a run per lane
+    extern __shared__ uint32_t first_t[]; // a word per counter of the range (32 KB at GoldPolish's 10 MiB; 64 KB for wide ranges), then the run lengths
+    const uint32_t pair = blockIdx.x / c.n_buckets, bucket = blockIdx.x % c.n_buckets;
+    const uint32_t bucket_w = 1u << c.bucket_shift;
+    if (c.overflow[pair] || (c.pair_need && c.level >= c.pair_need[pair]))
+        return;
+    const uint32_t nst = c.pair_nst[pair];
+    uint32_t* const rec0 = c.rec + c.pair_rec_off[pair];
+    auto run_of = [&](uint32_t st) -> uint32_t* { return rec0 + census_run_index(nst, c.n_buckets, bucket, st) * RUN; };
+    uint8_t* const cnt = c.cnt + c.pair_cnt_off[pair] + (uint64_t)bucket * nst;
+    // Level by level (stage_a_levels), from the second pass on: NOTHING is scattered again.  The records of
+    // the operations of L(j + 1) are already here -- an operation is in L(j + 1) iff all its touches were
+    // marked in pass j, and the marked records lie packed at the head of their runs -- so a pass's input is
+    // the previous pass's marked records whose operation made it into the set (one bit per record, from the
+    // bitmap census_pack has just written), and the run lengths are rewritten to what this pass marks.
+    const unsigned long long* const members =
+        (c.level > 0 && c.members) ? c.members + (c.pair_bit_off[pair] >> 6) : nullptr;
+    auto take = [&](uint32_t r, uint32_t st) -> uint32_t { // a record of the pass before -> this pass's (or none)
+        if (!members || r == 0xFFFFFFFFu)
+            return r;
+        const uint64_t pos = (uint64_t)st * kCStretch + ((r >> 16) & (kCStretch - 1u));
+        return ((members[pos >> 6] >> (pos & 63)) & 1ull) ? (r & 0x7FFFFFFFu) : 0xFFFFFFFFu;
+    };
+    uint8_t* const s_cnt = reinterpret_cast<uint8_t*>(first_t + bucket_w);
+    constexpr int kKeep = 128 / kMarkWaves; // a segment of 128 runs (a million positions): a run per wave and turn, kept in registers
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t i = threadIdx.x; i < nst; i += BLOCK)
+        s_cnt[i] = cnt[i];
+    for (uint32_t i = threadIdx.x; i < bucket_w; i += BLOCK)
+        first_t[i] = 0xFFFFFFFFu;
+    // A pair longer than a segment (the census level by level on a long contig: thousands of stretches) is
+    // taken a segment at a time, the table carried along: positions only grow from segment to segment, so
+    // after a segment's minima are in, the table is final for every counter that segment touches -- a touch
+    // is its counter's first iff the table holds its own position -- and the next segment can only fill
+    // entries nobody has touched yet.  (First version: one pass over ALL the pair's runs for the minima,
+    // a second for the marks, both re-reading the records: 17 s for the level-by-level census of SURVEY
+    // 8d's long contigs where the grid-wide schedule took 6.6.)
+    for (uint32_t seg0 = 0; seg0 < nst; seg0 += 128) {
+        uint32_t keep[kKeep][PER];
+        // The first 64 slots of a run are fetched beside the run lengths, not behind them (a run of
+        // 51 records on average spans those four lines anyway); what a length rules out is dropped below.
+        // (from the second pass of the level-by-level census on most runs are empty: there nothing is fetched
+        // before the length is known -- fetching the heads of all runs again in every pass was 320 GB a pass
+        // on SURVEY 8d's long contigs)
+#pragma unroll
+        for (int q = 0; q < kKeep; q++) {
+            const uint32_t st = seg0 + wave + (uint32_t)kMarkWaves * (uint32_t)q;
+            keep[q][0] = (st < nst && !members) ? run_of(st)[lane] : 0xFFFFFFFFu;
+        }
+        if (seg0 == 0)
+            __syncthreads(); // the run lengths and the empty table are there
+#pragma unroll
+        for (int q = 0; q < kKeep; q++) {
+            const uint32_t st = seg0 + wave + (uint32_t)kMarkWaves * (uint32_t)q;
+            const uint32_t n = st < nst ? s_cnt[st] : 0u;
+            if (members && lane < n)
+                keep[q][0] = run_of(st)[lane];
+            if (lane >= n)
+                keep[q][0] = 0xFFFFFFFFu;
+#pragma unroll
+            for (int e = 1; e < PER; e++)
+                keep[q][e] = lane + 64u * e < n ? run_of(st)[lane + 64u * e] : 0xFFFFFFFFu;
+            if (members) {
+#pragma unroll
+                for (int e = 0; e < PER; e++)
+                    keep[q][e] = take(keep[q][e], st);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kKeep; q++)
+#pragma unroll
+            for (int e = 0; e < PER; e++)
+                if (keep[q][e] != 0xFFFFFFFFu)
+                    atomicMin(&first_t[(keep[q][e] >> 2) & 0x3FFFu],
+                              (seg0 + wave + (uint32_t)kMarkWaves * (uint32_t)q) * kCStretch + (keep[q][e] >> 16));
+        __syncthreads();
+        // The touches that are not their counter's first go back into the head of their own run, bit 31
+        // set, packed (the records are in registers, the run is this wave's alone): a sector or two per
+        // run, next to each other, instead of a flag byte per touch scattered over the pair's positions
+        // (19 G bytes per configs[2] step that left L2 as 0.64 TB of partial sectors).  census_pack reads
+        // a run up to the first record without the bit; a run whose touches are all marked gets a zero
+        // behind them (what lies past a run's records is left over from an earlier cohort).
+#pragma unroll
+        for (int q = 0; q < kKeep; q++) {
+            const uint32_t st = seg0 + wave + (uint32_t)kMarkWaves * (uint32_t)q;
+            if (st >= nst)
+                continue;
+            uint32_t* const run = run_of(st);
+            uint32_t n = 0;
+#pragma unroll
+            for (int e = 0; e < PER; e++) {
+                const uint32_t r = keep[q][e];
+                const uint32_t t = st * kCStretch + ((r >> 16) & (kCStretch - 1u));
+                const bool later = r != 0xFFFFFFFFu && first_t[(r >> 2) & 0x3FFFu] != t; // (a counter hit twice by one operation: both touches are its first)
+                const unsigned long long m = __ballot(later);
+                if (later)
+                    run[n + __popcll(m & ((1ull << lane) - 1ull))] = r | 0x80000000u;
+                n += (uint32_t)__popcll(m);
+            }
+            // (behind a pass's marked records: an unmarked original at the first pass unless every touch was
+            // marked; from the second pass on whatever the pass before left there)
+            if (lane == 0 && (members || n == s_cnt[st]) && n < RUN)
+                run[n] = 0;
+            if (lane == 0 && c.pair_need)
+                cnt[st] = (uint8_t)n; // the next pass's input: this pass's marked records
+        }
     }
 }
 
@@ -1175,24 +1352,44 @@ template <uint32_t RUN>
 __global__ __launch_bounds__(256) void census_pack(AArgs a, CensusArgs c)
 {
     __shared__ uint32_t s_touch[kCStretch / 4];
+    __shared__ uint32_t s_ncand;
     const uint32_t pair = c.wg_pair[blockIdx.x];
+    if (threadIdx.x == 0)
+        s_ncand = 0;
     if (c.overflow[pair]) {
         if (threadIdx.x == 0)
             c.pair_mode[c.pair_queue[pair]] = 2u; // the plain replay for this pair (its operations are counted already)
         return;
     }
+    if (c.pair_need && c.level >= c.pair_need[pair])
+        return;
     const uint32_t b = c.pair_batch[pair];
     const uint64_t b_start = a.batch_pos[b], b_end = a.batch_pos[b + 1];
     const uint64_t pos0 = c.wg_pos0[blockIdx.x];
     const uint64_t stretch_end = min(b_end, pos0 + (uint64_t)kCStretch);
     const uint32_t nst = c.pair_nst[pair], stretch = (uint32_t)((pos0 - b_start) / kCStretch);
+    if (c.members) {
+        // a stretch without a member of this level has nobody in the next one either: zeros, no run is read
+        const unsigned long long* const mem = c.members + ((c.pair_bit_off[pair] + (pos0 - b_start)) >> 6);
+        int any = 0;
+        if (threadIdx.x < kCStretch / 64 && pos0 + (uint64_t)threadIdx.x * 64 < stretch_end)
+            any = mem[threadIdx.x] != 0ull;
+        if (!__syncthreads_or(any)) {
+            if (threadIdx.x < kCStretch / 64 && pos0 + (uint64_t)threadIdx.x * 64 < stretch_end)
+                c.cand[((c.pair_bit_off[pair] + (pos0 - b_start)) >> 6) + threadIdx.x] = 0ull;
+            return;
+        }
+    }
+    const uint8_t* const cnt = c.cnt + c.pair_cnt_off[pair];
     for (uint32_t i = threadIdx.x; i < kCStretch / 4; i += 256)
         s_touch[i] = 0;
     __syncthreads();
     const uint32_t* const rec = c.rec + c.pair_rec_off[pair];
     for (uint32_t bu = threadIdx.x; bu < c.n_buckets; bu += 256) {
+        if (c.members && cnt[(uint64_t)bu * nst + stretch] == 0)
+            continue; // (deeper levels: most runs are empty; a byte says so before a line is fetched)
         // a 64-byte line of the run at a time (four loads in flight instead of one behind the other)
-        const uint4* run = reinterpret_cast<const uint4*>(rec + ((uint64_t)bu * nst + stretch) * RUN);
+        const uint4* run = reinterpret_cast<const uint4*>(rec + census_run_index(nst, c.n_buckets, bu, stretch) * RUN);
         for (uint32_t q = 0; q < RUN / 16; q++) {
             const uint4 v0 = run[4 * q], v1 = run[4 * q + 1], v2 = run[4 * q + 2], v3 = run[4 * q + 3];
             const uint32_t w[16] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w,
@@ -1212,13 +1409,25 @@ __global__ __launch_bounds__(256) void census_pack(AArgs a, CensusArgs c)
         }
     }
     __syncthreads();
+    uint32_t n_cand = 0;
     for (uint64_t p0 = pos0; p0 < stretch_end; p0 += 256) {
         const uint64_t p = p0 + threadIdx.x;
         const uint32_t rel = (uint32_t)(p - pos0);
         const bool is_cand = p < stretch_end && ((s_touch[rel >> 2] >> (8u * (rel & 3u))) & 255u) == a.hash_num;
         const unsigned long long m = __ballot(is_cand);
-        if ((threadIdx.x & 63) == 0 && p < stretch_end)
+        if ((threadIdx.x & 63) == 0 && p < stretch_end) {
             c.cand[(c.pair_bit_off[pair] + (p - b_start)) >> 6] = m; // stretches and batches start on multiples of 64 bits
+            n_cand += (uint32_t)__popcll(m);
+        }
+    }
+    // (one atomic per workgroup that found any: an atomic per 64 positions on the one word was 73 ms of
+    // a 75 ms launch -- 1.5 M of them in a row -- in the first version of the level-by-level census)
+    if (c.level_count) {
+        if ((threadIdx.x & 63) == 0 && n_cand)
+            atomicAdd(&s_ncand, n_cand);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_ncand)
+            atomicAdd(c.level_count, (unsigned long long)s_ncand);
     }
 }
 
@@ -1630,6 +1839,68 @@ __global__ __launch_bounds__(256) void ckc_apply(AArgs a, CensusArgs c, CkcArgs 
             atomicAdd(&a.stats[7], s_private); // candidate operations settled by their k-mer's count
         if (bkt == 0)
             c.pair_mode[c.pair_queue[pair]] = 3u; // cbf_local replays the second bitmap's candidates
+    }
+}
+
+// ---- the census level by level (stage_a_levels): the operations that are in the set after a pair's last
+// pass go into its filter.  A workgroup per stretch, a quarter of it at a time, hashing as ckc_scatter does.
+__global__ __launch_bounds__(256) void level_insert(AArgs a, CensusArgs c, const unsigned long long* bits)
+{
+    __shared__ uint8_t codes[kCkcQuarter + kHalo];
+    __shared__ uint64_t seed_t[kSeedTableWords];
+    __shared__ ulonglong2 roll_in[8], roll_out[8];
+    const uint32_t pair = c.wg_pair[blockIdx.x];
+    if (c.overflow[pair] || c.pair_need[pair] != c.level + 1)
+        return; // (only the pairs whose last pass this was)
+    const uint32_t b = c.pair_batch[pair], ki = c.pair_ki[pair], tid = threadIdx.x;
+    const KConsts& kc = a.kc[ki];
+    const uint32_t k = kc.k;
+    const uint64_t b_start = a.batch_pos[b], b_end = a.batch_pos[b + 1];
+    const uint64_t pos0 = c.wg_pos0[blockIdx.x];
+    const uint64_t stretch_end = min(b_end, pos0 + (uint64_t)kCStretch);
+    const uint8_t* const mem = reinterpret_cast<const uint8_t*>(bits + ((c.pair_bit_off[pair] + (pos0 - b_start)) >> 6));
+    uint32_t* const bf = a.bf + ((uint64_t)b * a.n_k + ki) * a.bf_words;
+    fill_seed_table(seed_t);
+    if (tid < 8) {
+        roll_in[tid] = tid < 4 ? make_ulonglong2(seed_of_code(tid), kc.in_rev[tid]) : make_ulonglong2(0, 0);
+        roll_out[tid] = tid < 4 ? make_ulonglong2(kc.out_fwd[tid], seed_of_code(tid ^ 2)) : make_ulonglong2(0, 0);
+    }
+    for (uint32_t q = 0; q < 4; q++) {
+        const uint64_t q0 = pos0 + (uint64_t)q * kCkcQuarter;
+        if (q0 >= stretch_end)
+            break; // uniform
+        const uint64_t lane_pos0 = q0 + (uint64_t)tid * kCkcPerLane;
+        uint32_t mb = lane_pos0 < stretch_end ? mem[q * (kCkcQuarter / 8) + tid] : 0u;
+        if (lane_pos0 < stretch_end && stretch_end - lane_pos0 < 8)
+            mb &= (1u << (stretch_end - lane_pos0)) - 1u;
+        if (!__syncthreads_or((int)mb))
+            continue; // nobody of this quarter is in the set (and the barrier the staging below needs)
+        for (uint32_t i = tid; i < kCkcQuarter + kHalo; i += 256) {
+            const uint64_t p = q0 + i;
+            codes[i] = base_code(p < a.n_pos ? a.reads[p] : (uint8_t)'\n');
+        }
+        __syncthreads();
+        if (mb) {
+            const uint32_t t0 = tid * kCkcPerLane;
+            const uint32_t j0 = (uint32_t)__ffs((int)mb) - 1u;
+            uint64_t fh = 0, rh = 0;
+            int no_bad = -1;
+            kmer_hash_from_table(seed_t, codes + t0 + j0, k, fh, rh, no_bad);
+            for (uint32_t j = j0; j < kCkcPerLane; j++) {
+                if (j > j0) {
+                    const ulonglong2 ri = roll_in[codes[t0 + j + k - 1]], ro = roll_out[codes[t0 + j - 1]];
+                    fh = srol1(fh) ^ ri.x ^ ro.x;
+                    rh = sror1(rh ^ ri.y ^ ro.y);
+                }
+                if (!((mb >> j) & 1u))
+                    continue;
+                const uint64_t base = fh + rh;
+                for (uint32_t i = 0; i < a.hash_num; i++) {
+                    const uint64_t nbit = fastmod(i ? ext_hash(base, k, i) : base, a.bf_mod);
+                    atomicOr(&bf[nbit >> 5], 1u << (uint32_t)(nbit & 31));
+                }
+            }
+        }
     }
 }
 
@@ -2470,7 +2741,15 @@ int stage_a_run(gp_job* job)
     // and none of them is long; a long contig's batch needs the whole chip on its one filter.
     // GP_STAGE_A_LOCAL: 0 never, 1 every batch, default by size.
     std::vector<uint32_t> order;
-    uint32_t n_big = job->n_batches;
+    uint32_t n_big = job->n_batches, n_lvl = 0;
+    std::vector<uint32_t> lvl_batches, lvl_thr; // batches of the level-by-level census (in `order` behind the grid-wide ones) and their thresholds
+    // the census's geometry (counter ranges a power of two wide), as the local schedule's census takes it
+    const bool lv_wide = env_u64("GP_STAGE_A_CENSUS_WIDE", 1) != 0;
+    uint32_t lv_shift = 2;
+    while (((p.cbf_bytes + (1ull << lv_shift) - 1) >> lv_shift) > (lv_wide ? kCBucketsWide : kCBuckets))
+        lv_shift++;
+    const uint32_t lv_buckets = (uint32_t)((p.cbf_bytes + (1ull << lv_shift) - 1) >> lv_shift);
+    const uint64_t lv_budget = (env_u64("GP_STAGE_A_CENSUS_MB", 16384) << 20) / 4; // record slots of a cohort (one buffer set)
     {
         // A workgroup replays its pair at about 15 us per 512-position tile when it has the memory
         // system to itself; all of them together are bound by random line traffic, about 4.5 G
@@ -2496,7 +2775,46 @@ int stage_a_run(gp_job* job)
             for (uint32_t bi = 0; bi < job->n_batches; bi++)
                 order.push_back(bi);
         }
+        // Long batches whose filters stay UNSATURATED take the census level by level (stage A's third
+        // schedule, below): one threshold per filter (a batch of one contig always has), every pair's
+        // records inside a cohort's budget, and no more than GP_STAGE_A_LEVELS_LOAD counter touches per
+        // counter (default 45: a contig of about 2.9 Mbp at 40x on GoldPolish's 10 MiB; beyond that the
+        // filter saturates, the grid-wide schedule settles nearly everything in its first pass and the
+        // levels would take their twelve passes for nothing).  GP_STAGE_A_LEVELS=0: never.
+        {
+            const bool levels_on = env_u64("GP_STAGE_A_LEVELS", 1) != 0 && p.hash_num <= 4 && lv_shift <= kCMaxShift;
+            const double max_load = (double)env_u64("GP_STAGE_A_LEVELS_LOAD", 45);
+            std::vector<uint32_t> grid;
+            for (uint32_t bi : order) {
+                const uint64_t len = batch_pos[bi + 1] - batch_pos[bi];
+                bool uniform = true, any = false;
+                uint32_t thr0 = 0;
+                for (uint32_t cc = job->h_batch_contig_begin[bi]; cc < job->h_batch_contig_begin[bi + 1]; cc++) {
+                    if (job->h_seg_start[cc + 1] == job->h_seg_start[cc])
+                        continue;
+                    if (!any) {
+                        any = true;
+                        thr0 = job->h_contig_thr[cc];
+                    } else if (job->h_contig_thr[cc] != thr0) {
+                        uniform = false;
+                    }
+                }
+                const uint64_t nst = (len + kCStretch - 1) / kCStretch;
+                const uint64_t recs = census_runs((uint32_t)nst, lv_buckets) * (lv_wide ? kCRunWide : kCRun);
+                const bool ok = levels_on && any && uniform && len > 0 && nst <= env_u64("GP_STAGE_A_LEVELS_NST", 20000) &&
+                                (double)len * p.hash_num <= max_load * (double)p.cbf_bytes && recs <= lv_budget;
+                if (ok) {
+                    lvl_batches.push_back(bi);
+                    lvl_thr.push_back(thr0);
+                } else {
+                    grid.push_back(bi);
+                }
+            }
+            order.swap(grid);
+        }
         n_big = (uint32_t)order.size();
+        n_lvl = (uint32_t)lvl_batches.size();
+        order.insert(order.end(), lvl_batches.begin(), lvl_batches.end());
         // the queue of cbf_local hands out the longest batches first: the last workgroups to
         // finish then work on short ones
         std::stable_sort(small.begin(), small.end(), [&](uint32_t x, uint32_t y) {
@@ -2526,7 +2844,7 @@ int stage_a_run(gp_job* job)
         GP_HIP(hipStreamSynchronize(s)); // batch_pos, order and slot are locals
     }
     a.batch_order = job->d_batch_order.p;
-    const uint32_t n_local = job->n_batches - n_big;
+    const uint32_t n_local = job->n_batches - n_big - n_lvl, first_local = n_big + n_lvl;
     // census tables: host copies stay alive until the stream has been synchronised at the end
     struct Cohort {
         std::vector<uint32_t> wg_pair, pair_batch, pair_ki, pair_nst, pair_queue, tab32;
@@ -2539,7 +2857,7 @@ int stage_a_run(gp_job* job)
     std::vector<uint64_t> h_pair_bit_off;
     if (n_local) {
         uint64_t units = 0;
-        for (uint32_t i = n_big; i < job->n_batches; i++)
+        for (uint32_t i = first_local; i < job->n_batches; i++)
             units += (batch_pos[order[i] + 1] - batch_pos[order[i]]) * p.n_k;
         int rc0 = GP_OK;
         // as many workgroups as the chip holds at once (each owns one arena slot), never more than
@@ -2631,14 +2949,14 @@ int stage_a_run(gp_job* job)
                 cur_rec = cur_cnt = 0;
             };
             for (uint32_t i = 0; i < n_local; i++) {
-                const uint32_t b = order[n_big + i];
+                const uint32_t b = order[first_local + i];
                 const uint64_t pos = batch_pos[b + 1] - batch_pos[b];
                 // every operation in a first touch when the filter is nearly empty, hardly any once
                 // it has seen a few times its size: the census pays up to about two touches per counter
                 if (pos < min_pos || pos >= (1ull << 32) || pos * p.hash_num > 2 * p.cbf_bytes)
                     continue;
                 const uint32_t nst = (uint32_t)((pos + kCStretch - 1) / kCStretch);
-                const uint64_t recs = (uint64_t)n_buckets * nst * (wide ? kCRunWide : kCRun); // a run of slots per bucket and stretch
+                const uint64_t recs = census_runs(nst, n_buckets) * (wide ? kCRunWide : kCRun); // a run of slots per bucket and stretch
                 if (recs * p.n_k > rec_budget)
                     continue; // a batch that would not fit a cohort by itself
                 if (cur_rec + recs * p.n_k > rec_budget)
@@ -2871,10 +3189,196 @@ int stage_a_run(gp_job* job)
         }
         if ((rc0 = job->t_local.begin(s, units)) != GP_OK)
             return rc0;
-        hipLaunchKernelGGL(cbf_local, dim3(grid), dim3(kLBlock), 0, s, a, n_big, (uint32_t)n_pairs);
+        hipLaunchKernelGGL(cbf_local, dim3(grid), dim3(kLBlock), 0, s, a, first_local, (uint32_t)n_pairs);
         GP_HIP(hipGetLastError());
         if ((rc0 = job->t_local.end(s)) != GP_OK)
             return rc0;
+    }
+
+    // ---- The census LEVEL BY LEVEL: long batches whose filters stay unsaturated.
+    // Let m(o) be the minimum an operation finds among its counters.  A counter is >= j + 1 exactly from
+    // its first touch by an operation with m >= j on (that operation lifts it there, or found it there), so
+    //     m(o) >= j + 1  <=>  every counter of o has an EARLIER touch by an operation with m >= j:
+    // the set L(j + 1) = { m >= j + 1 } is "the candidates" of a census over the operations of L(j) alone --
+    // L(0) is everybody, L(1) the census's candidates as the local schedule knows them -- and an operation
+    // puts its k-mer into the filter iff m >= thr - 1, i.e. iff it is in L(thr - 1).  thr - 1 passes of
+    // census_scatter (members only) / census_mark / census_pack, the last one's set into the filter
+    // (level_insert): streaming kernels, no counting filter at all, no order to keep.  The sets shrink: on
+    // a 1 Mbp contig at 40x (15 touches per counter) the passes' sizes sum to 4.0 times the operations, at
+    // 30 touches to 7.3 times (tools: the model in DESIGN section 4), against 5.4 reservation atomics plus
+    // two rounds of random counter traffic per ordered operation in the grid-wide schedule.  A pass in which
+    // nobody is left ends a cohort early.  Exact for one threshold per filter (for j + 1 <= thr an operation
+    // that does not update found its counters at thr already).
+    std::vector<uint32_t> lvl_fallback;
+    if (n_lvl) {
+        GP_HIP(hipStreamSynchronize(s)); // (the buffers below may be the local schedule's, about to be resized)
+        const uint32_t RUNW = lv_wide ? kCRunWide : kCRun;
+        struct LCohort {
+            std::vector<uint32_t> wg_pair, pair_batch, pair_ki, pair_nst, pair_queue, pair_need, tab32;
+            std::vector<uint64_t> wg_pos0, pair_rec_off, pair_cnt_off, pair_bit_off, tab64;
+            uint64_t recs = 0, cnts = 0, bits = 0;
+            uint32_t max_need = 0, max_nst = 0;
+        };
+        std::vector<LCohort> lco;
+        {
+            LCohort cur;
+            for (uint32_t i = 0; i < n_lvl; i++) {
+                const uint32_t b = lvl_batches[i];
+                const uint64_t pos = batch_pos[b + 1] - batch_pos[b];
+                const uint32_t nst = (uint32_t)((pos + kCStretch - 1) / kCStretch);
+                const uint64_t recs = census_runs(nst, lv_buckets) * RUNW;
+                for (uint32_t ki = 0; ki < p.n_k; ki++) {
+                    if (!cur.pair_batch.empty() && cur.recs + recs > lv_budget) {
+                        lco.push_back(std::move(cur));
+                        cur = LCohort();
+                    }
+                    const uint32_t lp = (uint32_t)cur.pair_batch.size();
+                    cur.pair_batch.push_back(b);
+                    cur.pair_ki.push_back(ki);
+                    cur.pair_nst.push_back(nst);
+                    cur.pair_queue.push_back(lp);
+                    cur.pair_need.push_back(lvl_thr[i] - 2 + ki - 1); // thr - 1 passes (thr >= 2: at least one)
+                    cur.pair_rec_off.push_back(cur.recs);
+                    cur.pair_cnt_off.push_back(cur.cnts);
+                    cur.pair_bit_off.push_back(cur.bits);
+                    cur.max_need = std::max(cur.max_need, cur.pair_need.back());
+                    cur.max_nst = std::max(cur.max_nst, nst);
+                    cur.recs += recs;
+                    cur.cnts += (uint64_t)lv_buckets * nst;
+                    cur.bits += (uint64_t)nst * kCStretch; // whole stretches: a pass reads a stretch's 128 words
+                    for (uint64_t p0 = 0; p0 < pos; p0 += kCStretch) {
+                        cur.wg_pair.push_back(lp);
+                        cur.wg_pos0.push_back(batch_pos[b] + p0);
+                    }
+                }
+            }
+            if (!cur.pair_batch.empty())
+                lco.push_back(std::move(cur));
+        }
+        uint64_t m_rec = 0, m_cnt = 0, m_bits = 0, m_np = 0, m_wg = 0;
+        for (const LCohort& co : lco) {
+            m_rec = std::max(m_rec, co.recs);
+            m_cnt = std::max(m_cnt, co.cnts);
+            m_bits = std::max(m_bits, co.bits);
+            m_np = std::max<uint64_t>(m_np, co.pair_batch.size());
+            m_wg = std::max<uint64_t>(m_wg, co.wg_pair.size());
+        }
+        int rcl;
+        DevBuf<unsigned long long> d_bits[2], d_count;
+        DevBuf<uint32_t> d_mode;
+        const uint64_t t32 = (m_wg + 5 * m_np + 3) / 4 * 4, t64 = m_wg + 3 * m_np;
+        if ((rcl = job->d_census_rec.ensure(m_rec + 64)) != GP_OK || (rcl = job->d_census_cnt.ensure(m_cnt + 64)) != GP_OK ||
+            (rcl = job->d_census_over.ensure(m_np)) != GP_OK || (rcl = job->d_census_tab32.ensure(t32)) != GP_OK ||
+            (rcl = job->d_census_tab64.ensure(t64)) != GP_OK || (rcl = d_bits[0].alloc(m_bits / 64 + 64)) != GP_OK ||
+            (rcl = d_bits[1].alloc(m_bits / 64 + 64)) != GP_OK || (rcl = d_count.alloc(16)) != GP_OK ||
+            (rcl = d_mode.alloc(m_np)) != GP_OK)
+            return rcl;
+        uint64_t lv_units = 0;
+        for (uint32_t b : lvl_batches)
+            lv_units += (batch_pos[b + 1] - batch_pos[b]) * p.n_k;
+        if ((rcl = job->t_census.begin(s, lv_units)) != GP_OK)
+            return rcl;
+        uint32_t k_max = 1;
+        for (uint32_t ki = 0; ki < p.n_k; ki++)
+            k_max = std::max(k_max, p.k[ki]);
+        const size_t scatter_lds =
+            (((size_t)lv_buckets * ((lv_wide ? kCRingWide : 8u) + 1) + 2) & ~(size_t)1) * sizeof(uint32_t) + (size_t)k_max * 8 * sizeof(uint64_t);
+        if (lv_wide)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&census_mark_seg<kCRunWide, kMarkBlockWide>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        const uint64_t span = std::max<uint64_t>(1, env_u64("GP_STAGE_A_SCATTER_SPAN", 4));
+        const bool mod5 = a.cbf_mod.fast && a.cbf_mod.c == 5 && a.cbf_mod.s < 32 && a.hash_num == 4;
+        unsigned long long* const h_count = job->h_readback + 16; // (pinned; words 0..8 are stage A's statistics)
+        uint64_t passes = 0;
+        for (LCohort& co : lco) {
+            const size_t np = co.pair_batch.size(), nw = co.wg_pair.size();
+            co.tab32.reserve(nw + 5 * np);
+            co.tab32.insert(co.tab32.end(), co.wg_pair.begin(), co.wg_pair.end());
+            co.tab32.insert(co.tab32.end(), co.pair_batch.begin(), co.pair_batch.end());
+            co.tab32.insert(co.tab32.end(), co.pair_ki.begin(), co.pair_ki.end());
+            co.tab32.insert(co.tab32.end(), co.pair_nst.begin(), co.pair_nst.end());
+            co.tab32.insert(co.tab32.end(), co.pair_queue.begin(), co.pair_queue.end());
+            co.tab32.insert(co.tab32.end(), co.pair_need.begin(), co.pair_need.end());
+            co.tab64.reserve(nw + 3 * np);
+            co.tab64.insert(co.tab64.end(), co.wg_pos0.begin(), co.wg_pos0.end());
+            co.tab64.insert(co.tab64.end(), co.pair_rec_off.begin(), co.pair_rec_off.end());
+            co.tab64.insert(co.tab64.end(), co.pair_cnt_off.begin(), co.pair_cnt_off.end());
+            co.tab64.insert(co.tab64.end(), co.pair_bit_off.begin(), co.pair_bit_off.end());
+            GP_HIP(hipMemcpyAsync(job->d_census_tab32.p, co.tab32.data(), co.tab32.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            GP_HIP(hipMemcpyAsync(job->d_census_tab64.p, co.tab64.data(), co.tab64.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+            GP_HIP(hipMemsetAsync(job->d_census_over.p, 0, np * sizeof(uint32_t), s));
+            CensusArgs c{};
+            c.wg_pair = job->d_census_tab32.p;
+            c.pair_batch = c.wg_pair + nw;
+            c.pair_ki = c.pair_batch + np;
+            c.pair_nst = c.pair_ki + np;
+            c.pair_queue = c.pair_nst + np;
+            c.pair_need = c.pair_queue + np;
+            c.wg_pos0 = job->d_census_tab64.p;
+            c.pair_rec_off = c.wg_pos0 + nw;
+            c.pair_cnt_off = c.pair_rec_off + np;
+            c.pair_bit_off = c.pair_cnt_off + np;
+            c.n_wg = (uint32_t)nw;
+            c.rec = job->d_census_rec.p;
+            c.cnt = job->d_census_cnt.p;
+            c.overflow = job->d_census_over.p;
+            c.pair_mode = d_mode.p;
+            c.bucket_shift = lv_shift;
+            c.n_buckets = lv_buckets;
+            c.seed_rows = k_max;
+            c.level_count = d_count.p;
+            for (uint32_t level = 0; level < co.max_need; level++) {
+                c.level = level;
+                c.members = level ? d_bits[(level - 1) & 1].p : nullptr;
+                c.cand = d_bits[level & 1].p;
+                GP_HIP(hipMemsetAsync(d_count.p, 0, sizeof(unsigned long long), s));
+                if (level == 0) { // (later passes take the marked records of the pass before: census_mark)
+                    uint64_t n_g = (nw + span - 1) / span;
+                    n_g = std::min<uint64_t>(n_g, 3ull * (uint64_t)job->ctx->prop.multiProcessorCount);
+                    const dim3 g((unsigned)n_g), bl(kBlock);
+                    if (lv_wide && mod5)
+                        hipLaunchKernelGGL((census_scatter<kCRunWide, kCRingWide, 1, true>), g, bl, scatter_lds, s, a, c);
+                    else if (lv_wide)
+                        hipLaunchKernelGGL((census_scatter<kCRunWide, kCRingWide, 1, false>), g, bl, scatter_lds, s, a, c);
+                    else
+                        hipLaunchKernelGGL((census_scatter<kCRun, 8u, 1, false>), g, bl, scatter_lds, s, a, c);
+                }
+                {
+                    const size_t lds = ((size_t)sizeof(uint32_t) << lv_shift) + (co.max_nst + 3) / 4 * 4;
+                    if (lv_wide)
+                        hipLaunchKernelGGL((census_mark_seg<kCRunWide, kMarkBlockWide>), dim3((unsigned)(np * lv_buckets)),
+                                           dim3(kMarkBlockWide), lds, s, c);
+                    else
+                        hipLaunchKernelGGL((census_mark_seg<kCRun, kMarkBlock>), dim3((unsigned)(np * lv_buckets)), dim3(kMarkBlock), lds, s, c);
+                }
+                if (lv_wide)
+                    hipLaunchKernelGGL((census_pack<kCRunWide>), dim3((unsigned)nw), dim3(256), 0, s, a, c);
+                else
+                    hipLaunchKernelGGL((census_pack<kCRun>), dim3((unsigned)nw), dim3(256), 0, s, a, c);
+                bool any_final = false;
+                for (uint32_t need : co.pair_need)
+                    any_final |= need == level + 1;
+                if (any_final)
+                    hipLaunchKernelGGL(level_insert, dim3((unsigned)nw), dim3(256), 0, s, a, c, (const unsigned long long*)d_bits[level & 1].p);
+                GP_HIP(hipGetLastError());
+                passes++;
+                GP_HIP(hipMemcpyAsync(h_count, d_count.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                GP_HIP(hipStreamSynchronize(s));
+                if (*h_count == 0)
+                    break; // nobody is left in any pair's set: the later sets are empty too
+            }
+            std::vector<uint32_t> h_over(np);
+            GP_HIP(hipMemcpyAsync(h_over.data(), job->d_census_over.p, np * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            GP_HIP(hipStreamSynchronize(s));
+            for (size_t q = 0; q < np; q++)
+                if (h_over[q] && (lvl_fallback.empty() || lvl_fallback.back() != co.pair_batch[q]))
+                    lvl_fallback.push_back(co.pair_batch[q]);
+        }
+        job->counters.a_rounds += passes;
+        if ((rcl = job->t_census.end(s)) != GP_OK)
+            return rcl;
+        std::sort(lvl_fallback.begin(), lvl_fallback.end());
+        lvl_fallback.erase(std::unique(lvl_fallback.begin(), lvl_fallback.end()), lvl_fallback.end());
     }
 
     // Slice = the read positions of one batch a step's first pass hashes.  What makes the
@@ -2884,7 +3388,7 @@ int stage_a_run(gp_job* job)
     // in the first pass; the slice then grows (feedback on the waiting fraction).
     const uint64_t load_div = std::max<uint64_t>(1, env_u64("GP_STAGE_A_LOAD_DIV", 6));
     const uint64_t lim0 = std::max<uint64_t>(kTile, p.cbf_bytes / (load_div * p.hash_num));
-    const double wait_cap = (double)env_u64("GP_STAGE_A_WAITCAP", 3000000); // operations expected to wait, per step
+    const double wait_cap = (double)env_u64("GP_STAGE_A_WAITCAP", 2000000); // operations expected to wait, per step
     const double slot_mul = (double)env_u64("GP_STAGE_A_SLOTS_PER_RESV", 8);
     const bool allow_skip = env_u64("GP_STAGE_A_SKIP_LOOKUP", 1) != 0;
     const uint64_t max_pending = job->window * p.n_k; // list capacity, operations
@@ -2997,10 +3501,14 @@ int stage_a_run(gp_job* job)
     // every batch of the group.  Many small batches therefore advance in lockstep: each filter
     // sees only a sliver of its reads per step, yet a step still holds enough operations to
     // fill the chip.  A group of one batch degenerates to consecutive slices of that batch.
-    if (n_big)
+    bool grid_used = false;
+    auto grid_range = [&](uint32_t g_lo, uint32_t g_hi) -> int { // the grid-wide schedule over order[g_lo .. g_hi)
+    if (g_lo < g_hi && !grid_used) {
         GP_HIP(hipStreamWaitEvent(s2, job->a_ev_init, 0)); // behind the memsets above
-    for (uint32_t g_first = 0; g_first < n_big;) {
-        const uint32_t g_n = std::min<uint32_t>(group_cap, n_big - g_first);
+        grid_used = true;
+    }
+    for (uint32_t g_first = g_lo; g_first < g_hi;) {
+        const uint32_t g_n = std::min<uint32_t>(group_cap, g_hi - g_first);
         // the group's counting filters start from zero; stream `s` is behind the previous
         // group's tail (and behind cbf_local) here, and every later step waits for `s`
         GP_HIP(hipMemsetAsync(job->d_cbf.p, 0, (uint64_t)g_n * p.n_k * a.cbf_stride, s));
@@ -3170,6 +3678,31 @@ int stage_a_run(gp_job* job)
         }
         g_first += g_n;
     }
+    return GP_OK;
+    };
+    {
+        int rcg = grid_range(0, n_big);
+        if (rcg != GP_OK)
+            return rcg;
+    }
+    if (!lvl_fallback.empty()) {
+        // pairs of the level-by-level census that overflowed a run (many copies of one k-mer within a
+        // stretch): their batches take the grid-wide schedule after all -- whole batches, every k: setting
+        // the bits of a filter the levels have already finished a second time changes nothing
+        GP_HIP(hipStreamSynchronize(s));
+        GP_HIP(hipStreamSynchronize(s2));
+        for (size_t i = 0; i < lvl_fallback.size(); i++)
+            order[n_big + i] = lvl_fallback[i];
+        std::vector<uint32_t> slot(job->n_batches, 0);
+        for (uint32_t i = 0; i < (uint32_t)lvl_fallback.size(); i++)
+            slot[lvl_fallback[i]] = (i % group_cap) * p.n_k;
+        GP_HIP(hipMemcpyAsync(job->d_batch_order.p, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        GP_HIP(hipMemcpyAsync(job->d_batch_slot.p, slot.data(), slot.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        GP_HIP(hipStreamSynchronize(s));
+        int rcg = grid_range(n_big, n_big + (uint32_t)lvl_fallback.size());
+        if (rcg != GP_OK)
+            return rcg;
+    }
     if (span_open) {
         int rc = job->t_round.end(s2);
         if (rc != GP_OK)
@@ -3185,7 +3718,7 @@ int stage_a_run(gp_job* job)
                 (unsigned long long)n_first_pass, host_ms, all_ms);
     }
     // the rest of the pipeline (stream `s`) continues behind the last tail
-    if (n_big) {
+    if (grid_used) {
         GP_HIP(hipEventRecord(job->a_ev_init, s2));
         GP_HIP(hipStreamWaitEvent(s, job->a_ev_init, 0));
     }

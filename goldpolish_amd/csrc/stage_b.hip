@@ -3508,8 +3508,16 @@ int stage_b_pass(gp_job* job, uint32_t ki)
     // many for the same registers.  (A site's window must fit the workgroup: k <= 56.)
     const unsigned walk_threads =
         (unsigned)env_u64("GP_WALK_THREADS", (walk_waves >= 4 && a.k <= 56) ? 128 : kWalkThreads) == 128 && a.k <= 56 ? 128u : (unsigned)kWalkThreads;
+    // The segments of long contigs are thousands of workgroups as well (SURVEY 8d config 3's shape: 6 100 per k),
+    // but twice as many of them resident (GP_WALK_SEG_WAVES=4: 128 threads each, eight per CU instead of four)
+    // buys nothing there -- walk 2.33 s per step against 2.22: a launch lasts as long as its slowest segments
+    // and the contigs walked whole after a failed repair, not as long as the queue of the others
+    const bool seg_tight = h_segs.size() > 3 * 256 && env_u64("GP_WALK_SEG_WAVES", 1) >= 4;
+    const unsigned walk_threads_seg = (env_u64("GP_WALK_SEG_THREADS", 128) == 128 && a.k <= 56) ? 128u : (unsigned)kWalkThreads;
     auto launch_walk = [&](unsigned grid, bool seg) {
-        if (seg)
+        if (seg && seg_tight)
+            hipLaunchKernelGGL((ntedit_walk<4, true>), dim3(grid), dim3(walk_threads_seg), 0, s, a);
+        else if (seg)
             hipLaunchKernelGGL((ntedit_walk<1, true>), dim3(grid), dim3(kWalkThreads), 0, s, a);
         else if (walk_waves >= 6)
             hipLaunchKernelGGL((ntedit_walk<6, false>), dim3(grid), dim3(walk_threads), 0, s, a);

@@ -865,6 +865,10 @@ __device__ int bidi_search(Search& S)
         // base leaving the k-mer: first (forward extension) or last (backward extension)
         const uint32_t first = (uint32_t)(pk >> (2 * (k - 1))) & 3;
         const uint32_t last = (uint32_t)pk & 3;
+        // (measured, round 4: issuing the four neighbours' filter look-ups together ahead of this loop made the
+        // long searches of SURVEY 8d config 3's shape SLOWER, 1.71 s against 1.53 per step -- a search is one
+        // lane's instruction stream, not a chain of load latencies, and the look-ups of neighbours a search
+        // never reaches are instructions too)
         for (uint32_t b = 0; b < 4 && !aborted; b++) {
             uint64_t km[2], fh, rh;
             if (dir == FWD) {

@@ -11,16 +11,19 @@ from goldpolish_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["grid", "local", "census", "census_all"], autouse=True)
+@pytest.fixture(params=["grid", "levels", "local", "census", "census_all"], autouse=True)
 def stage_a_path(request, monkeypatch):
     """every case runs through the stage-A schedules: grid-wide reservation rounds
-    (GP_STAGE_A_LOCAL=0), one workgroup per (batch, k) pair replaying every operation
+    (GP_STAGE_A_LOCAL=0), the census level by level (long batches with one threshold per filter: batches with
+    several take the grid-wide schedule there too), one workgroup per (batch, k) pair replaying every operation
     (GP_STAGE_A_LOCAL=1, census off), the same behind the census of first touches (forced
     for batches of any length; pairs it does not apply to or whose buckets overflow fall back) with
     the candidates of private k-mers settled by their count (ckc_*: the default), and the census with
     every candidate replayed (GP_STAGE_A_CKC=0: rounds 2-3's path, which pairs the count does not apply
     to still take)"""
-    monkeypatch.setenv("GP_STAGE_A_LOCAL", "0" if request.param == "grid" else "1")
+    monkeypatch.setenv("GP_STAGE_A_LOCAL", "0" if request.param in ("grid", "levels") else "1")
+    monkeypatch.setenv("GP_STAGE_A_LEVELS", "1" if request.param == "levels" else "0")
+    monkeypatch.setenv("GP_STAGE_A_LEVELS_LOAD", "1000000")   # (filters of any load: the tiny ones of these tests saturate)
     monkeypatch.setenv("GP_STAGE_A_CENSUS", "1" if request.param.startswith("census") else "0")
     monkeypatch.setenv("GP_STAGE_A_CENSUS_MIN", "1")
     monkeypatch.setenv("GP_STAGE_A_CKC", "0" if request.param == "census_all" else "1")
@@ -96,10 +99,12 @@ def test_filters_match_oracle_default_sizes(gp, oracle, stage_a_path):
     core, ctx = gp
     w = synth.make_workload([25000, 9000, 14000], 30, seed=11)
     c = run_and_compare(core, ctx, oracle, w, core.default_params())
-    assert c["a_ops"] > 0 and c["a_ordered_ops"] > 0
+    assert c["a_ops"] > 0 and (c["a_ordered_ops"] > 0 or stage_a_path == "levels")   # (the levels order nothing)
     # the schedule the fixture asked for is the one that ran (a silent fall-back would still match the oracle)
     if stage_a_path == "grid":
         assert c["a_reservations"] > 0 and c["a_replayed"] == 0
+    elif stage_a_path == "levels":
+        assert c["a_reservations"] == 0 and c["a_replayed"] == 0 and c["a_ordered_ops"] == 0
     elif stage_a_path == "local":
         assert c["a_reservations"] == 0 and c["a_replayed"] == c["a_ops"]
     else:
