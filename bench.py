@@ -457,6 +457,7 @@ def main():
     if args.prepare_only:
         return
 
+    from goldpolish_amd import core   # before torch brings the HIP runtime up: core asks it for eight hardware queues
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the polishing core has no CPU fallback")

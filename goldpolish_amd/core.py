@@ -13,6 +13,11 @@ import sys
 
 import numpy as np
 
+# (the library asks the HIP runtime for eight hardware queues instead of four when it is loaded -- api.hip,
+# gp_runtime_defaults -- which only counts if the runtime has not been initialised yet; a host that brings
+# the runtime up first -- torch does, on its first CUDA call -- gets the same by importing this module first)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libgpcore.so"
 

@@ -16,6 +16,18 @@
 #include <thread>
 #include <vector>
 
+// Hardware queues.  The filter build keeps three streams busy (census_scatter | census_mark + census_pack |
+// the ckc_* kernels), gp_pipeline adds an upload stream and the streams of its other contexts, and the HIP
+// runtime deals its streams onto FOUR hardware queues by default: two streams on one queue run one after the
+// other.  Seen in the kernel trace of BASELINE configs[2]: the mark/pack stream and the ckc stream on the same
+// queue in every job, 966 ms per step against 926 with eight queues.  The runtime reads GPU_MAX_HW_QUEUES
+// when it initialises, so the library asks for eight when it is loaded -- unless the host has set the variable
+// itself; a host that has initialised HIP before loading this library sets it itself.
+__attribute__((constructor)) static void gp_runtime_defaults()
+{
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+
 namespace gp {
 
 static thread_local std::string g_err;

@@ -3376,8 +3376,14 @@ int stage_b_pass(gp_job* job, uint32_t ki)
         }
     } walk_timer{ job->t_walk, s, true };
     // 2a. contigs of several segment lengths are cut into segments, each walked by a workgroup of
-    // its own (SegDesc above).  GP_WALK_SEG: k-mer starts per segment (0: never cut), default 16384 (walk 1.4 s per step with 16384, 2.5 s with 32768, 4.2 s with 65536, 37 s uncut).
-    const uint64_t seg_len = env_u64("GP_WALK_SEG", 16384);
+    // its own (SegDesc above).  GP_WALK_SEG: k-mer starts per segment (0: never cut), default 4096.  SURVEY 8d
+    // config 3's shape, walk per step: 37 s uncut, 4.2 s with 65536, 2.5 s with 32768, 2.33 s with 16384 (the
+    // default up to round 4), 2.02 s with 8192, 1.93 s with 4096, 1.77 s with 2048 (there 44 segments of 48 000 fail
+    // and are repaired, 12 of 24 000 at 4096).  The gain is small because a launch lasts as long as its slowest
+    // segment, and the slowest are stretches edited every other base where no cut is found at any spacing
+    // (9 000 sites in 18 000 starts at 22-30 us each: 0.55 s at 16384, 0.42 s at 4096), plus one contig per
+    // pass walked whole after a refused insertion (0.8 s at k = 20, whatever the spacing).
+    const uint64_t seg_len = env_u64("GP_WALK_SEG", 4096);
     std::vector<SegDesc> h_segs;
     std::vector<SegContig> h_segc;
     std::vector<uint32_t> h_len; // the contigs' lengths going into this pass (filled when a contig is cut)

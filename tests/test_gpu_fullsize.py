@@ -138,31 +138,35 @@ def test_device_export_matches_host_export(gp):
 
 
 def test_mixed_job_long_and_many_short_batches(gp, oracle, monkeypatch):
-    """One job holding a long contig's batch (grid-wide reservation rounds) and a few hundred
-    short ones (one workgroup per filter pair, chosen by size): every filter equals the one
-    the forced single-schedule runs give, and a sample of them equals the serial oracle."""
+    """One job holding a long contig's batch and a few hundred short ones.  By itself the filter build
+    gives the long batch (filters that stay unsaturated) the census level by level and the short ones
+    one workgroup per filter pair; with GP_STAGE_A_LEVELS=0 the long batch takes the grid-wide reservation
+    rounds instead; with GP_STAGE_A_LOCAL=0 every batch does.  Every filter is the same in all three, and a
+    sample of them equals the serial oracle's."""
     core, ctx = gp
     lens = [2_500_000] + [6000] * 150 + [9000] * 60
     w = synth.make_workload(lens, 20, seed=91)
     p = core.default_params(k_values=[32, 24])
 
-    def filters(mode):
-        if mode is None:
-            monkeypatch.delenv("GP_STAGE_A_LOCAL", raising=False)
-        else:
-            monkeypatch.setenv("GP_STAGE_A_LOCAL", mode)
+    def filters(**env):
+        for name in ("GP_STAGE_A_LOCAL", "GP_STAGE_A_LEVELS"):
+            monkeypatch.delenv(name, raising=False)
+        for name, value in env.items():
+            monkeypatch.setenv(name, value)
         with core.Job.from_workload(ctx, p, w) as job:
             job.build_filters()
-            local_ms, local_launches, _ = job.kernel_time("cbf_local")
-            fp_ms, fp_launches, _ = job.kernel_time("cbf_first_pass")
+            launches = {name: job.kernel_time(name)[1] for name in ("cbf_local", "cbf_first_pass", "cbf_census")}
+            rounds = job.counters()["a_rounds"]
             return ([[sha(job.get_filter(b, ki).tobytes()) for ki in range(p.n_k)]
                      for b in range(job.n_batches)],
-                    [job.get_filter(b, 1) for b in (0, 1, 77, 210)], local_launches, fp_launches)
+                    [job.get_filter(b, 1) for b in (0, 1, 77, 210)], launches, rounds)
 
-    auto, sample, n_local, n_fp = filters(None)
-    assert n_local == 1 and n_fp > 0          # both schedules ran
-    grid, _, n_local_g, _ = filters("0")
-    assert n_local_g == 0 and grid == auto
+    auto, sample, n, _ = filters()
+    assert n["cbf_local"] == 1 and n["cbf_first_pass"] == 0 and n["cbf_census"] >= 1   # levels + workgroup-local
+    mixed, _, n, _ = filters(GP_STAGE_A_LEVELS="0")
+    assert n["cbf_local"] == 1 and n["cbf_first_pass"] > 0 and mixed == auto            # grid-wide + workgroup-local
+    grid, _, n, _ = filters(GP_STAGE_A_LOCAL="0", GP_STAGE_A_LEVELS="0")
+    assert n["cbf_local"] == 0 and n["cbf_first_pass"] > 0 and grid == auto             # grid-wide alone
     for i, b in enumerate((0, 1, 77, 210)):
         _, bfs = oracle.fill_bfs(w.reads_of(b), [32, 24], int(w.kmer_threshold[b]), p.cbf_bytes,
                                  p.bf_bytes)

@@ -25,9 +25,12 @@ def newest(pattern):
     return files[-1:]
 
 
-for name in ("config3", "config2", "probe"):
+for name in ("config3", "config2", "survey3", "probe"):
     for f in newest(str(raw / f"{name}_trace" / "*" / "*kernel_stats.csv")):
         shutil.copy(f, out / f"{rnd}_{name}_kernel_stats.csv")
+b3 = raw / "survey3_bench.json"
+if b3.exists():
+    shutil.copy(b3, out / f"{rnd}_survey3_bench_line.json")
 for name in ("config3", "config2", "probe"):
     traffic = {}
     for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):

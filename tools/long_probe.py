@@ -2,7 +2,7 @@
 """development aid: the filter build (stage A) of SURVEY 8d config 3's long-contig shape under a list of
 environment settings, one job per setting -- wall time, the stage-A timers, reservation atomics, and a
 hash of every filter (all settings must give the same bits).
-usage: long_probe.py TOTAL_MBP "VAR=a,b" ["VAR2=x VAR3=y" ...]   (a spec with spaces sets several variables at once)"""
+usage: long_probe.py TOTAL_MBP|config3 "VAR=a,b" ["VAR2=x VAR3=y" ...]   (a spec with spaces sets several variables at once)"""
 import hashlib
 import os
 import pathlib
@@ -14,14 +14,17 @@ sys.path.insert(0, str(ROOT))
 import bench
 from goldpolish_amd import synth
 
-total = int(float(sys.argv[1]) * 1e6)
-lens = bench.survey_lengths(total, 2_000_000, 3)
 t = time.time()
-w = synth.make_workload_chunked(lens, 40, seed=2, chunk=1)
-print(f"workload: {len(lens)} contigs, {sum(lens)} bp, generated in {time.time() - t:.0f} s", flush=True)
+if sys.argv[1] == "config3":   # BASELINE configs[2] (bench.py's headline workload) instead of the long contigs
+    w = bench.make_workload("config3", seed=2)[0]
+else:
+    total = int(float(sys.argv[1]) * 1e6)
+    lens = bench.survey_lengths(total, 2_000_000, 3)
+    w = synth.make_workload_chunked(lens, 40, seed=2, chunk=1)
+print(f"workload: {w.n_contigs} contigs, {w.total_bp} bp, generated in {time.time() - t:.0f} s", flush=True)
 from goldpolish_amd import core
 p = core.default_params()
-names = ("cbf_census", "cbf_local", "cbf_first_pass", "cbf_round")
+names = ("cbf_census", "cbf_ckc", "cbf_local", "cbf_first_pass", "cbf_round")
 
 
 def run(tag):
