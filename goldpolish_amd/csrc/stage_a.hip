@@ -3202,11 +3202,12 @@ int stage_a_run(gp_job* job)
     // the set L(j + 1) = { m >= j + 1 } is "the candidates" of a census over the operations of L(j) alone --
     // L(0) is everybody, L(1) the census's candidates as the local schedule knows them -- and an operation
     // puts its k-mer into the filter iff m >= thr - 1, i.e. iff it is in L(thr - 1).  thr - 1 passes of
-    // census_scatter (members only) / census_mark / census_pack, the last one's set into the filter
-    // (level_insert): streaming kernels, no counting filter at all, no order to keep.  The sets shrink: on
-    // a 1 Mbp contig at 40x (15 touches per counter) the passes' sizes sum to 4.0 times the operations, at
-    // 30 touches to 7.3 times (tools: the model in DESIGN section 4), against 5.4 reservation atomics plus
-    // two rounds of random counter traffic per ordered operation in the grid-wide schedule.  A pass in which
+    // census_scatter (once) / census_mark_seg / census_pack, the last one's set into the filter
+    // (level_insert): streaming kernels, no counting filter at all, no order to keep.  The sets shrink: in
+    // the CPU model of this schedule (tests/test_levels_model.py, which also checks the claim against the
+    // serial filter) the passes' sizes sum to 5.4 times the operations at 15 touches per counter and a
+    // threshold of 13, to 7.9 times at 30 touches, against 5.4 reservation atomics plus two rounds of random
+    // counter traffic per ordered operation in the grid-wide schedule.  A pass in which
     // nobody is left ends a cohort early.  Exact for one threshold per filter (for j + 1 <= thr an operation
     // that does not update found its counters at thr already).
     std::vector<uint32_t> lvl_fallback;
