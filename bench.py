@@ -353,7 +353,7 @@ def read_selection_cost(w):
 def dry_run(world):
     """Per rank of `bench.py --gpus world`: contigs, bases, and the bytes it will hold -- host pageable
     (the generated workload), host pinned (staging chunks, result buffers, rank 0's gather buffers) and
-    device (two sets of inputs in flight, one set of work buffers) -- from the assembly's lengths alone:
+    device (up to four sets of inputs in flight, one set of work buffers) -- from the assembly's lengths alone:
     no GPU, no reads generated.  The device model is checked against what one rank's share measured
     on one MI355X (137 GiB for 375 Mbp in 15000 batches at 30x: DESIGN 6)."""
     from goldpolish_amd import core
@@ -370,13 +370,13 @@ def dry_run(world):
         bp, nb = int(mine.sum()), int(mine.size)
         reads = bp * cov + bp * cov // 15000            # + one separator per read of about 15 kb
         inputs = reads + bp
-        dev = (2 * inputs                                # two sets in flight (upload beside polish)
+        dev = (4 * inputs                                # up to four sets' inputs on the device (run_stream's DEPTH: uploading, uploaded, built, polishing)
                + nb * n_k * (512 << 10)                  # Bloom filters, results of stage A
                + min(nb * n_k, 512) * (10 << 20)         # counting-filter arena
                + (16 << 30) + (1 << 30)                  # census record slots, settled tables
                + 150 * bp                                # stage B/C per-base state (two sequence slots of 1.5 x, node lists, bitmaps, 16-byte site records, Sealer's gap tables): fitted to 59 GiB for configs[2]
                + int(7.3 * 2**30))                       # Sealer arenas (read-length contigs)
-        pinned = 2 * 2 * (64 << 20) + 2 * int(bp * 1.02) + (int(1.1 * bp * (world - 1)) if r == 0 and world > 1 else 0)
+        pinned = 2 * 2 * (64 << 20) + 4 * int(bp * 1.02) + (int(1.1 * bp * (world - 1)) if r == 0 and world > 1 else 0)
         ranks.append({"rank": r, "batches": nb, "contig_bp": bp, "host_pageable_bytes": inputs + 16 * (reads // 15000 + nb),
                       "host_pinned_bytes": pinned, "device_bytes": dev})
     return {"dry_run": True, "n_gpus": world, "assembly_bp": int(lens.sum()), "batches": int(lens.size),
@@ -405,8 +405,8 @@ def main():
     ap.add_argument("--jobs-per-gpu", type=int, default=1,
                     help="HBM-resident extra only: jobs the batches are cut into and kept in flight (gp_jobs_polish)")
     ap.add_argument("--no-aux", action="store_true")
-    ap.add_argument("--aux-steps", type=int, default=2,
-                    help="timed steps of the long-contig block (aux_survey3: SURVEY 8d config 3's own shape, about 10 s a step)")
+    ap.add_argument("--aux-steps", type=int, default=3,
+                    help="timed steps of the long-contig block (aux_survey3: SURVEY 8d config 3's own shape, about 6 s a step; 0: skip it)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU, no generation of reads: print what every rank of --gpus N would hold in host "
                          "(pageable + pinned) and device memory, then exit")
@@ -486,8 +486,8 @@ def main():
         params = core.default_params(k_values=ks)
         bs, keep = core.batch_set_of_workload(w)
         # sets in the pipeline: one uploading, one being polished and -- for the sets gp_pipeline splits (those with
-        # long contigs) -- one more in the filter build
-        DEPTH = 2 if os.environ.get("GP_PIPELINE_OVERLAP") == "0" else 3
+        # long contigs) -- one more in the filter build and a second one in its back half
+        DEPTH = 2 if os.environ.get("GP_PIPELINE_OVERLAP") == "0" else int(os.environ.get("GP_BENCH_DEPTH", "4"))
         pipe = core.Pipeline(device_index, params, depth=DEPTH)
         sums, times = [], {"upload_ms": [], "polish_ms": [], "download_ms": []}
         last = {}
@@ -779,14 +779,14 @@ def main():
                     "records left packed in HBM: no PCIe in the timed region",
             "same_output_bytes": rs["output_checksum"]["bytes"] == main_res["output_checksum"]["bytes"],
         }
-    def aux_block(w_aux, ks_aux, desc_aux, name, steps, cpu_sample, note=""):
+    def aux_block(w_aux, ks_aux, desc_aux, name, steps, cpu_sample, note="", warmup=1):
         """one more workload through the same timed region, with a roofline and a CPU sample of its own"""
         core.device_pool_trim()   # the blocks of the workload before are of another shape
-        aux = run_stream(w_aux, ks_aux, steps, 1)
+        aux = run_stream(w_aux, ks_aux, steps, warmup)
         blk = {
             "workload": desc_aux + note,
             "value": round(aux["bp_per_rank"] * aux["steps"] / aux["dt"] / 1e6, 3),
-            "unit": "Mbp/s", "ms_per_step": round(aux["dt"] / aux["steps"] * 1e3, 2), "steps": aux["steps"],
+            "unit": "Mbp/s", "ms_per_step": round(aux["dt"] / aux["steps"] * 1e3, 2), "steps": aux["steps"], "warmup": warmup,
             "stream": aux["stream"], "roofline": roofline(aux, name), "counters": aux["counters"],
             "device_GiB_in_use": round(aux["device_bytes"] / 2**30, 1),
         }
@@ -811,7 +811,10 @@ def main():
             line["aux_survey3"] = aux_block(w_aux, ks_aux, desc_aux, "survey3", args.aux_steps,
                                             cpu_sample_by_cost(w_aux, threads, 28.0, 25.0),
                                             " -- the regime SURVEY 8d describes for configs 3 and 4; the fixed 10 MiB / "
-                                            "512 KiB filters (src/goldpolish_targeted_bfs.cpp:270-272) saturate on such contigs")
+                                            "512 KiB filters (src/goldpolish_targeted_bfs.cpp:270-272) saturate on such contigs",
+                                            # gp_pipeline keeps four such sets going (upload | filter build | two back
+                                            # halves) and the first one allocates 137 GiB: timed from the third collect on
+                                            warmup=3)
             del w_aux, aux_survey_in
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(w_main, ks_main, desc_main, main_res.get("polished"))

@@ -394,6 +394,7 @@ void gp_ctx_destroy(gp_ctx* ctx)
         if (ctx->stage_ev[i])
             (void)hipEventDestroy(ctx->stage_ev[i]);
     }
+    stage_a_ctx_release(ctx);
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     pool_context_gone(ctx->device); // the last context on a device takes its pool along

@@ -114,6 +114,17 @@ struct gp_ctx {
     uint8_t* stage[2] = { nullptr, nullptr };
     hipEvent_t stage_ev[2] = { nullptr, nullptr };
     size_t stage_bytes = 0;
+    // What the filter build needs beside the context's stream -- two more streams, the events that join them,
+    // the pinned feedback ring -- made by the first build on the context (stage_a_prepare) and kept for the
+    // context's life: a job borrows them.  (Up to round 4 every job made and destroyed its own: 30 creations
+    // and as many destructions per job, and hipHostFree / hipStreamDestroy wait for the DEVICE -- in
+    // gp_pipeline that made the filter build of one set end when the back half of the set before did.)
+    struct StageA {
+        hipStream_t stream2 = nullptr, stream3 = nullptr;
+        hipEvent_t ev[16] = {}, ev_b[16] = {}, ev_init = nullptr, ev_census[9] = {};
+        uint32_t* h_count_pinned = nullptr;
+        bool ready = false;
+    } a;
 };
 
 // Per-k constants of the rolling hash, prepared on the host.
@@ -201,6 +212,7 @@ int job_polish_back(gp_job* job);
 int stage_a_prepare(gp_job* job);            // allocate work buffers
 int stage_a_run(gp_job* job);                // enqueue + drive the filter build
 void stage_a_release(gp_job* job);
+void stage_a_ctx_release(gp_ctx* ctx);      // what stage_a_prepare keeps in the context (gp_ctx::StageA)
 int stage_bc_prepare(gp_job* job);
 void stage_bc_release(gp_job* job);
 int stage_b_reset(gp_job* job);              // current sequences := inputs

@@ -14,18 +14,24 @@
 // batches' filters while polishing workers run (scripts/goldpolish:496-514).
 //
 // A set that holds a LONG contig (GP_PIPELINE_SPLIT_FROM bases, default 200 000) is split (round 4): a BUILD
-// thread builds its filters on a context whose streams are restricted to 6 CUs in 8 (gp_ctx_create_masked)
-// while the polishing thread runs everything behind the filters of the set before on the other two of every
-// eight.  GP_PIPELINE_OVERLAP: 3 (default) as said; 0 never; 1 every set (back half on GP_PIPELINE_BACK_SHARE
-// = 1 CU in 8); 2 every set, no masks.  Measured, ms per step:
+// thread builds its filters on a context whose streams are restricted to 7 CUs in 8 (gp_ctx_create_masked)
+// while TWO polishing threads run everything behind the filters of the two sets before it on the eighth
+// (a masked context each).  GP_PIPELINE_OVERLAP: 3 (default) as said; 0 never; 1 every set; 2 every set, no
+// masks; GP_PIPELINE_BACK_SHARE: CUs in 8 for the back halves (default 1); GP_PIPELINE_BACK_THREADS (2).
+// Measured, ms per step:
 //   BASELINE configs[2] (4000 x 25 kbp, 40x): three stages 920; every set split, masked 7 | 1: 909 (the filter
 //   build's kernels take 862 ms beside the back half instead of 664 alone, the back half 313 instead of 263);
 //   unmasked 906; device memory 62 -> 90 GiB.  The two halves do run side by side (kernel trace) and the sum
 //   does not move: the build's streaming kernels fill every wave slot they are given, and what the back half
 //   takes it takes from them.  So read-length sets stay whole.
-//   SURVEY 8d config 3's own shape (48 contigs of 0.3-12 Mbp): whole 11 310; split 7 | 1: 9 906 -- the walk of
-//   6 100 segment workgroups takes 7.2 s on 32 CUs instead of 2.2 s on 256, the build 7.5 instead of 6.6;
-//   split 6 | 2 (the default for such sets): see DESIGN section 5.
+//   SURVEY 8d config 3's own shape (48 contigs of 0.3-12 Mbp), on the round's last filter build (3.4 s alone):
+//   whole 8 160; split without masks 6 930; split 6 | 2, one polishing thread 6 500 (2, 3 or 4 CUs in 8 for
+//   the back half: the same -- it waits for its slowest segments and searches); two
+//   polishing threads 5 780; and 7 | 1: 5 450.  GP_PIPELINE_TRACE=1 prints every stage of every set.
+//   What the trace showed first: build and back half ENDING TOGETHER, set after set, 6.3 s each -- every job
+//   made and destroyed its filter build's streams, events and pinned ring, hipHostFree / hipStreamDestroy
+//   wait for the whole device, and the back half never leaves it idle.  Those are the context's now
+//   (gp_ctx::StageA), made once.
 // A split set of fewer than GP_PIPELINE_MASK_FROM contigs (default 4) runs its halves on contexts WITHOUT masks
 // (the build on front_plain, the back half on run_ctx): see gp_pipeline_create.
 // (With CU-masked streams nothing in a job's path may touch the null stream: masked streams are created
@@ -56,6 +62,7 @@ constexpr int kTimers = 10;
 
 struct Slot { // one finished set
     uint64_t tag = 0;
+    uint64_t seq = 0; // its place in the order of submission
     int rc = GP_OK;
     std::string msg;
     std::vector<uint64_t> lengths;
@@ -78,6 +85,7 @@ struct Item {
     int rc = GP_OK;
     std::string msg;
     double upload_ms = 0, build_ms = 0;
+    uint64_t seq = 0;   // order of submission = order of collection
     bool split = false; // filter build and back half in two threads on two contexts ...
     bool masked = false; // ... CU-masked ones
 };
@@ -85,6 +93,15 @@ struct Item {
 double now_ms()
 {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// development aid (GP_PIPELINE_TRACE=1): one line per stage of every set on stderr, wall-clock ms
+void trace(const char* what, uint64_t seq, double t0)
+{
+    static const bool on = getenv("GP_PIPELINE_TRACE") != nullptr;
+    static const double origin = now_ms();
+    if (on)
+        fprintf(stderr, "PIPE set %llu %-8s %10.1f .. %10.1f ms (%.1f)\n", (unsigned long long)seq, what, t0 - origin, now_ms() - origin, now_ms() - t0);
 }
 
 } // namespace
@@ -104,13 +121,15 @@ struct gp_pipeline {
     std::deque<Item> submitted; // waiting for the upload thread
     std::deque<Item> uploaded;  // on the device, waiting for the build thread (one at most)
     std::deque<Item> built;     // filters built, waiting for the polishing thread (one at most)
-    std::deque<int> done;       // slots ready for collect, oldest first
+    std::deque<int> done;       // slots ready for collect (in the order they finished; collect takes them by seq)
     std::vector<int> free_slots;
-    Slot slots[3];
+    Slot slots[4];
+    uint64_t next_seq = 0, next_out = 0; // submitted so far / the set the next collect returns
+    gp_ctx* back_ctx2 = nullptr; // the second polishing thread's (split, masked sets only)
     int held = -1;              // slot the caller is reading (released by the next collect)
     uint32_t in_flight = 0;     // submitted and not yet collected
     bool stop = false;
-    std::thread uploader, builder, polisher;
+    std::thread uploader, builder, polisher, polisher2;
 };
 
 static void upload_loop(gp_pipeline* p)
@@ -134,6 +153,7 @@ static void upload_loop(gp_pipeline* p)
             it.rc = on_exception("gp_pipeline (upload)");
         }
         it.upload_ms = now_ms() - t0;
+        trace("upload", it.seq, t0);
         {
             std::lock_guard<std::mutex> g(p->mu);
             p->uploaded.push_back(std::move(it));
@@ -170,6 +190,7 @@ static void build_loop(gp_pipeline* p)
                 }
             }
             it.build_ms = now_ms() - t0;
+            trace("build", it.seq, t0);
         }
         {
             std::lock_guard<std::mutex> g(p->mu);
@@ -179,10 +200,10 @@ static void build_loop(gp_pipeline* p)
     }
 }
 
-static int polish_one(gp_pipeline* p, Item& it, Slot& s)
+static int polish_one(gp_pipeline* p, Item& it, Slot& s, gp_ctx* back)
 {
     gp_job* job = it.job;
-    gp_ctx* const ctx = (it.split && it.masked) ? p->back_ctx : p->run_ctx;
+    gp_ctx* const ctx = (it.split && it.masked) ? back : p->run_ctx;
     job->ctx = ctx; // from here on the polishing context's stream
     double t0 = now_ms();
     int rc = it.split ? job_polish_back(job) : gp_job_polish(job, 1);
@@ -223,15 +244,24 @@ static int polish_one(gp_pipeline* p, Item& it, Slot& s)
     return GP_OK;
 }
 
-static void polish_loop(gp_pipeline* p)
+// `second`: the second polishing thread.  The back half of a set with long contigs is as long as its slowest
+// members -- a walk segment edited every other base, a contig walked whole after a refused insertion, the
+// longest one-lane Sealer searches -- and leaves most of the chip idle while it waits for them (the same
+// 6.5 s on 2, 3 or 4 CUs in 8: section 10 of DESIGN.md), so two such back halves run side by side, each on
+// a masked context of its own.  The second thread takes nothing else: sets that run whole, and split sets
+// without masks, use run_ctx, which is the first thread's.
+static void polish_loop(gp_pipeline* p, bool second)
 {
+    gp_ctx* const back = second ? p->back_ctx2 : p->back_ctx;
     for (;;) {
         Item it;
         int si;
         {
             std::unique_lock<std::mutex> g(p->mu);
             std::deque<Item>& from = p->front_ctx ? p->built : p->uploaded;
-            p->cv.wait(g, [&] { return p->stop || (!from.empty() && !p->free_slots.empty()); });
+            p->cv.wait(g, [&] {
+                return p->stop || (!from.empty() && !p->free_slots.empty() && (!second || (from.front().split && from.front().masked)));
+            });
             if (p->stop)
                 return;
             it = std::move(from.front());
@@ -242,14 +272,17 @@ static void polish_loop(gp_pipeline* p)
         p->cv.notify_all(); // the stage before may start on the next set
         Slot& s = p->slots[si];
         s.tag = it.tag;
+        s.seq = it.seq;
         s.rc = it.rc;
         s.msg = it.msg;
         s.upload_ms = it.upload_ms;
         s.total = 0;
         if (it.rc == GP_OK) {
+            const double t_back = now_ms();
             try {
                 (void)hipSetDevice(p->run_ctx->device);
-                s.rc = polish_one(p, it, s);
+                s.rc = polish_one(p, it, s, back);
+                trace(second ? "back/2" : (it.split ? "back/1" : "whole"), it.seq, t_back);
                 if (s.rc != GP_OK)
                     s.msg = gp_last_error();
             } catch (...) {
@@ -261,7 +294,7 @@ static void polish_loop(gp_pipeline* p)
             }
         }
         if (it.job) {
-            it.job->ctx = (it.split && it.masked) ? p->back_ctx : p->run_ctx;
+            it.job->ctx = (it.split && it.masked) ? back : p->run_ctx;
             gp_job_destroy(it.job); // its blocks go to the pool: the next job's work buffers
         }
         {
@@ -307,7 +340,7 @@ try {
         // the back half on `share` CUs of every eight (bit i of the mask = CU i; interleaved, so that each half
         // gets its share of every shader engine), the filter build on the others
         const uint32_t n_cu = (uint32_t)p->up_ctx->prop.multiProcessorCount;
-        const uint32_t share = (uint32_t)std::min<uint64_t>(7, std::max<uint64_t>(1, env_u64("GP_PIPELINE_BACK_SHARE", overlap == 3 ? 2 : 1)));
+        const uint32_t share = (uint32_t)std::min<uint64_t>(7, std::max<uint64_t>(1, env_u64("GP_PIPELINE_BACK_SHARE", 1)));
         std::vector<uint32_t> front((n_cu + 31) / 32, 0), back((n_cu + 31) / 32, 0);
         for (uint32_t cu = 0; cu < n_cu; cu++)
             (cu % 8 >= 8 - share ? back : front)[cu / 32] |= 1u << (cu % 32);
@@ -327,15 +360,21 @@ try {
         p->mask_from = overlap == 3 ? (uint32_t)env_u64("GP_PIPELINE_MASK_FROM", 4) : 0;
         if (p->mask_from && (rc = gp_ctx_create(device, &p->front_plain)) != GP_OK)
             return rc;
+        // two back halves of split, masked sets at once (polish_loop; GP_PIPELINE_BACK_THREADS=1: one)
+        if (overlap == 3 && n_cu >= 16 && env_u64("GP_PIPELINE_BACK_THREADS", 2) >= 2 &&
+            (rc = gp_ctx_create_masked(device, back.data(), (uint32_t)back.size(), &p->back_ctx2)) != GP_OK)
+            return rc;
     }
     p->prm = *params;
     p->depth = depth < 1 ? 1 : depth > 8 ? 8 : depth;
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < 4; i++)
         p->free_slots.push_back(i);
     p->uploader = std::thread(upload_loop, p);
     if (p->front_ctx)
         p->builder = std::thread(build_loop, p);
-    p->polisher = std::thread(polish_loop, p);
+    p->polisher = std::thread(polish_loop, p, false);
+    if (p->back_ctx2)
+        p->polisher2 = std::thread(polish_loop, p, true);
     owner.p = nullptr;
     *out = p;
     return GP_OK;
@@ -366,6 +405,7 @@ try {
             return GP_ERR_STATE;
         }
         p->in_flight++;
+        it.seq = p->next_seq++;
         p->submitted.push_back(std::move(it));
     }
     p->cv.notify_all();
@@ -391,9 +431,18 @@ try {
             set_error("gp_pipeline_collect: nothing has been submitted");
             return GP_ERR_STATE;
         }
-        p->cv.wait(g, [&] { return !p->done.empty(); });
-        si = p->done.front();
-        p->done.pop_front();
+        // results come back in submission order, whichever polishing thread finished first
+        auto ready = [&] {
+            for (auto d = p->done.begin(); d != p->done.end(); ++d)
+                if (p->slots[*d].seq == p->next_out)
+                    return d;
+            return p->done.end();
+        };
+        p->cv.wait(g, [&] { return ready() != p->done.end(); });
+        auto d = ready();
+        si = *d;
+        p->done.erase(d);
+        p->next_out++;
         p->held = si;
         p->in_flight--;
     }
@@ -457,6 +506,8 @@ void gp_pipeline_destroy(gp_pipeline* p)
             p->builder.join();
         if (p->polisher.joinable())
             p->polisher.join();
+        if (p->polisher2.joinable())
+            p->polisher2.join();
         for (Item& it : p->uploaded)
             if (it.job)
                 gp_job_destroy(it.job);
@@ -474,6 +525,7 @@ void gp_pipeline_destroy(gp_pipeline* p)
         gp_ctx_destroy(p->front_ctx);
         gp_ctx_destroy(p->front_plain);
         gp_ctx_destroy(p->back_ctx);
+        gp_ctx_destroy(p->back_ctx2);
         gp_ctx_destroy(p->run_ctx);
         delete p;
     } catch (...) {

@@ -2572,43 +2572,79 @@ int stage_a_prepare(gp_job* job)
         GP_HIP(hipMemcpyAsync(job->d_seg_smax.p, smax.data(), smax.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         GP_HIP(hipStreamSynchronize(s)); // tm and smax are locals
     }
-    GP_HIP(hipHostMalloc((void**)&job->h_count_pinned, 4 * kRing * sizeof(uint32_t)));
-    for (uint32_t i = 0; i < kRing; i++) {
-        GP_HIP(hipEventCreateWithFlags(&job->a_ev[i], hipEventDisableTiming));
-        GP_HIP(hipEventCreateWithFlags(&job->a_ev_b[i], hipEventDisableTiming));
+    // streams, events and the pinned ring are the CONTEXT's (gp_ctx::StageA): made once, borrowed by every job
+    gp_ctx::StageA& r = job->ctx->a;
+    if (!r.ready) {
+        static_assert(kRing <= 16, "gp_ctx::StageA holds 16 events per ring");
+        if (!r.h_count_pinned)
+            GP_HIP(hipHostMalloc((void**)&r.h_count_pinned, 4 * kRing * sizeof(uint32_t)));
+        for (uint32_t i = 0; i < kRing; i++) {
+            if (!r.ev[i])
+                GP_HIP(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming));
+            if (!r.ev_b[i])
+                GP_HIP(hipEventCreateWithFlags(&r.ev_b[i], hipEventDisableTiming));
+        }
+        if (!r.ev_init)
+            GP_HIP(hipEventCreateWithFlags(&r.ev_init, hipEventDisableTiming));
+        int rcs;
+        if ((!r.stream2 && (rcs = ctx_stream_create(job->ctx, &r.stream2)) != GP_OK) ||
+            (!r.stream3 && (rcs = ctx_stream_create(job->ctx, &r.stream3)) != GP_OK))
+            return rcs;
+        for (hipEvent_t& e : r.ev_census)
+            if (!e)
+                GP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        r.ready = true;
     }
-    GP_HIP(hipEventCreateWithFlags(&job->a_ev_init, hipEventDisableTiming));
-    int rcs;
-    if ((rcs = ctx_stream_create(job->ctx, &job->a_stream2)) != GP_OK || (rcs = ctx_stream_create(job->ctx, &job->a_stream3)) != GP_OK)
-        return rcs;
-    for (hipEvent_t& e : job->a_ev_census)
-        GP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    job->h_count_pinned = r.h_count_pinned;
+    for (uint32_t i = 0; i < kRing; i++) {
+        job->a_ev[i] = r.ev[i];
+        job->a_ev_b[i] = r.ev_b[i];
+    }
+    job->a_ev_init = r.ev_init;
+    job->a_stream2 = r.stream2;
+    job->a_stream3 = r.stream3;
+    for (int i = 0; i < 9; i++)
+        job->a_ev_census[i] = r.ev_census[i];
     return GP_OK;
 }
 
-void stage_a_release(gp_job* job)
+void stage_a_ctx_release(gp_ctx* ctx)
 {
-    // Idempotent: every handle is null once it is gone, so ensure_work's failure path followed by
-    // gp_job_destroy (or by a second try) destroys nothing twice; the work buffers go back too.
-    if (job->h_count_pinned)
-        (void)hipHostFree(job->h_count_pinned);
-    job->h_count_pinned = nullptr;
+    gp_ctx::StageA& r = ctx->a;
+    if (r.h_count_pinned)
+        (void)hipHostFree(r.h_count_pinned);
     auto drop = [](hipEvent_t& e) {
         if (e)
             (void)hipEventDestroy(e);
         e = nullptr;
     };
+    for (hipEvent_t& e : r.ev)
+        drop(e);
+    for (hipEvent_t& e : r.ev_b)
+        drop(e);
+    drop(r.ev_init);
+    for (hipEvent_t& e : r.ev_census)
+        drop(e);
+    if (r.stream2)
+        (void)hipStreamDestroy(r.stream2);
+    if (r.stream3)
+        (void)hipStreamDestroy(r.stream3);
+    r = gp_ctx::StageA();
+}
+
+void stage_a_release(gp_job* job)
+{
+    // Idempotent: every handle is null once it is gone, so ensure_work's failure path followed by
+    // gp_job_destroy (or by a second try) gives nothing back twice; the work buffers go back to the pool.
+    // Streams, events and the pinned ring were borrowed from the context (stage_a_prepare): forgotten, not destroyed.
+    job->h_count_pinned = nullptr;
     for (hipEvent_t& e : job->a_ev)
-        drop(e);
+        e = nullptr;
     for (hipEvent_t& e : job->a_ev_b)
-        drop(e);
-    drop(job->a_ev_init);
+        e = nullptr;
+    job->a_ev_init = nullptr;
     for (hipEvent_t& e : job->a_ev_census)
-        drop(e);
-    if (job->a_stream2)
-        (void)hipStreamDestroy(job->a_stream2);
-    if (job->a_stream3)
-        (void)hipStreamDestroy(job->a_stream3);
+        e = nullptr;
     job->a_stream2 = job->a_stream3 = nullptr;
     job->d_resv.release();
     job->d_pending[0].release();

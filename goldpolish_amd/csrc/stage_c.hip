@@ -1803,6 +1803,17 @@ int stage_c_prepare(gp_job* job)
     // a worker per 4 kbp of contigs, 256 at least, kMaxWorkers from 12 Mbp on (3 GiB of medium arenas + 3.3 GiB of full ones)
     c->n_workers = (uint32_t)std::min<uint64_t>(
         kMaxWorkers, std::max<uint64_t>(256, env_u64("GP_SEALER_WORKERS", total_len / 4096)));
+    // (where long contigs are polished every worker gets a full arena, below: 13 MB each.  2048 of them are as
+    // fast as 4096 there -- a launch lasts as long as its longest chain of searches -- and leave room for the
+    // second back half gp_pipeline runs beside the first: SURVEY 8d config 3's shape 210 -> 137 GiB in use,
+    // 5.81 and 5.78 s per step; 1024: Sealer 2.3 -> 3.1 s)
+    {
+        uint64_t longest0 = 0;
+        for (uint32_t i = 0; i < n; i++)
+            longest0 = std::max<uint64_t>(longest0, job->h_contig_off[i + 1] - job->h_contig_off[i]);
+        if (longest0 >= env_u64("GP_SEALER_LONG", 200000) && !getenv("GP_SEALER_WORKERS"))
+            c->n_workers = std::min<uint32_t>(c->n_workers, 2048);
+    }
     // Full arenas for every worker where long contigs are polished: their near-saturated filters make
     // searches that neither find a path nor hit the branch limit explore tens of thousands of
     // vertices (160 000 such searches per step on SURVEY 8d's 100 Mbp of megabase contigs; with 256

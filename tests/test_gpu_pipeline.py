@@ -61,6 +61,39 @@ def test_stream_of_sets_equals_single_jobs_and_the_oracle(oracle, overlap, monke
         assert core.split_polished(got[2])[c] == outs[0]
 
 
+@pytest.mark.parametrize("threads", ["2", "1"])
+def test_two_back_halves_at_once_come_back_in_submission_order(threads, monkeypatch):
+    """split sets (every set here: GP_PIPELINE_SPLIT_FROM lowered, masks for any number of contigs) are taken by
+    two polishing threads; a short set behind a long one finishes first and must still be collected second"""
+    monkeypatch.setenv("GP_PIPELINE_SPLIT_FROM", "1000")
+    monkeypatch.setenv("GP_PIPELINE_MASK_FROM", "0")
+    monkeypatch.setenv("GP_PIPELINE_BACK_THREADS", threads)
+    from goldpolish_amd import core
+    p = core.default_params()
+    shapes = [[60000, 30000, 9000], [2000], [40000, 5000], [1500, 1200], [20000], [3000, 2500, 2000, 1800]]
+    ws = [synth.make_workload(l, 25, seed=170 + i) for i, l in enumerate(shapes)]
+    want = []
+    with core.Context(0) as ctx:
+        for w in ws:
+            with core.Job.from_workload(ctx, p, w) as job:
+                job.polish()
+                want.append(job.sequences())
+    sets = [core.batch_set_of_workload(w) for w in ws]
+    with core.Pipeline(0, p, depth=4) as pipe:
+        for rep in range(2):
+            nxt = 0
+            for nxt in range(4):
+                pipe.submit(*sets[nxt], tag=10 * rep + nxt)
+            nxt = 4
+            for i in range(len(ws)):
+                r = pipe.collect()
+                assert r["tag"] == 10 * rep + i
+                assert core.split_polished(r) == want[i], (rep, i)
+                if nxt < len(ws):
+                    pipe.submit(*sets[nxt], tag=10 * rep + nxt)
+                    nxt += 1
+
+
 def test_a_failing_set_is_reported_at_collect_and_the_stream_goes_on():
     from goldpolish_amd import core
     p = core.default_params(k_values=[32])
