@@ -25,11 +25,12 @@ timeout -k 10 300 $C2 > $OUT/config2_bench.json 2> $OUT/config2_bench.err || exi
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/config2_trace -- $C2 > $OUT/config2_trace.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/config2_fetch -- $C2 > $OUT/config2_fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/config2_write -- $C2 > $OUT/config2_write.log 2>&1 || exit 1
-# SURVEY 8d config 3's own shape (aux_survey3 in the bench line): kernel stats only, one timed step
+# SURVEY 8d config 3's own shape (aux_survey3 in the bench line): kernel stats only; the pipeline holds four such
+# sets, so three warm-up collects before the two timed steps (steady state)
 python3 bench.py --prepare-only --cache $CACHE --workload survey3 || exit 1
-S3="python3 bench.py --steps 1 --warmup 1 --no-aux --no-cpu-baseline --resident-steps 0 --workload survey3 --cache $CACHE"
-timeout -k 10 400 $S3 > $OUT/survey3_bench.json 2> $OUT/survey3_bench.err || exit 1
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/survey3_trace -- $S3 > $OUT/survey3_trace.log 2>&1 || exit 1
+S3="python3 bench.py --steps 2 --warmup 3 --no-aux --no-cpu-baseline --resident-steps 0 --workload survey3 --cache $CACHE"
+timeout -k 10 500 $S3 > $OUT/survey3_bench.json 2> $OUT/survey3_bench.err || exit 1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/survey3_trace -- $S3 > $OUT/survey3_trace.log 2>&1 || exit 1
 # what FETCH_SIZE / WRITE_SIZE report for THIS access pattern (random 1-byte loads / load+store
 # pairs over 16 GiB, 2^28 of them per launch): the calibration MI355X_MICROARCH.md asks for before
 # an absolute is trusted
