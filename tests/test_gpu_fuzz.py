@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 def test_random_jobs_match_the_oracle(oracle, monkeypatch):
     import fuzz_parity
     from goldpolish_amd import core
-    for name in ("GP_STAGE_A_LOCAL", "GP_STAGE_A_CENSUS", "GP_STAGE_A_CENSUS_MIN"):
+    for name in ("GP_STAGE_A_LOCAL", "GP_STAGE_A_CENSUS", "GP_STAGE_A_CENSUS_MIN", "GP_STAGE_A_LEVELS", "GP_STAGE_A_LEVELS_LOAD"):
         monkeypatch.setenv(name, "0")   # run_case sets them per schedule; put back when the test ends
     with core.Context(0) as ctx:
         # 1086: neighbouring gaps closer than two flanks, both closed (overlapping fills);
@@ -23,7 +23,7 @@ def test_random_jobs_match_the_oracle(oracle, monkeypatch):
         # follows the edited length, not the input's)
         # 400000+: several contigs per batch with different thresholds on small filters
         for seed in [1086, 20621, 20645, 300029] + list(range(7000, 7009)) + list(range(400000, 400012)):
-            for mode in ("0", "1", "2"):   # grid-wide, cbf_local plain, cbf_local behind the census
+            for mode in ("0", "1", "2", "3"):   # grid-wide, cbf_local plain, cbf_local behind the census, the census level by level
                 assert fuzz_parity.run_case(core, ctx, oracle, seed, mode) is None, (seed, mode)
 
 

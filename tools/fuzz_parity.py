@@ -97,10 +97,14 @@ def random_case(seed):
 
 def set_schedule(mode):
     """"0": grid-wide schedule; "1": cbf_local replaying every operation; "2": cbf_local behind the
-    census of first touches (forced for batches of any length)"""
-    os.environ["GP_STAGE_A_LOCAL"] = "0" if mode == "0" else "1"
+    census of first touches (forced for batches of any length); "3": the census level by level"""
+    os.environ["GP_STAGE_A_LOCAL"] = "0" if mode in ("0", "3") else "1"
     os.environ["GP_STAGE_A_CENSUS"] = "1" if mode == "2" else "0"
     os.environ["GP_STAGE_A_CENSUS_MIN"] = "1"
+    # "3": the census level by level for every batch that qualifies (one threshold, hash_num <= 4), whatever its
+    # load; the others of the job take the grid-wide schedule
+    os.environ["GP_STAGE_A_LEVELS"] = "1" if mode == "3" else "0"
+    os.environ["GP_STAGE_A_LEVELS_LOAD"] = "1000000"
 
 
 def run_case(core, ctx, O, seed, local_mode):
@@ -201,7 +205,7 @@ def main():
     t0 = time.time()
     with core.Context(0) as ctx:
         for seed in range(first, first + n):
-            for mode in ("0", "1", "2"):
+            for mode in ("0", "1", "2", "3"):
                 try:
                     err = run_case(core, ctx, O, seed, mode) or run_staged(core, ctx, O, seed, mode)
                 except Exception as e:  # noqa: BLE001 -- a fuzz loop reports and goes on
@@ -211,7 +215,7 @@ def main():
                     print(f"seed {seed} local={mode}: {err}", flush=True)
             if (seed - first) % 10 == 9:
                 print(f"... {seed - first + 1} cases, {bad} failures, {time.time() - t0:.0f} s", flush=True)
-    print(f"fuzz: {n} cases x 3 schedules, {bad} failures")
+    print(f"fuzz: {n} cases x 4 schedules, {bad} failures")
     return 1 if bad else 0
 
 
