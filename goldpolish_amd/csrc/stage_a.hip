@@ -846,6 +846,7 @@ struct CensusArgs {
     const unsigned long long* members; // only the operations whose bit is set take part (null: all of them)
     const uint32_t* pair_need;     // [pairs] census passes the pair takes (null: one); a pair is skipped from pass pair_need on
     uint32_t level;                // the pass (0: positions and operations are counted)
+    uint32_t mark_prefetch;        // census_mark: slots of every run fetched before its length is known
     unsigned long long* level_count; // census_pack: operations with every touch marked, over the launch (or null)
 };
 
@@ -1156,12 +1157,18 @@ __global__ __launch_bounds__(BLOCK, 8) void census_mark(CensusArgs c)
     constexpr int kKeep = 128 / kMarkWaves; // 128 runs: a pair of a million positions
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t keep[kKeep][PER];
-    // The first 64 slots of a run are fetched beside the run lengths, not behind them (a run of
-    // 51 records on average spans those four lines anyway); what a length rules out is dropped below.
+    // The first slots of a run are fetched beside the run lengths, not behind them; what a length rules out
+    // is dropped below, what it adds is fetched there.  How many: c.mark_prefetch, all 64 by default.  A wide
+    // range's run holds 38 records on average (three touches per position), more than 48 in one run in
+    // twenty, so the fourth 64-byte line is fetched for nothing nineteen times in twenty -- 80 GB per configs[2]
+    // step -- and NOT fetching it is slower: stage A 654.6 ms with 64, 661.4 with 48, 667.1 with 40, 668.8 with 32
+    // (GP_STAGE_A_MARK_PREFETCH).  The census is not short of bandwidth; the late fetch of the runs that do
+    // need the line is a second round trip in the one workgroup the others of its CU wait for.
+    const uint32_t pre = c.mark_prefetch;
 #pragma unroll
     for (int q = 0; q < kKeep; q++) {
         const uint32_t st = wave + (uint32_t)kMarkWaves * (uint32_t)q;
-        keep[q][0] = st < nst ? run_of(st)[lane] : 0xFFFFFFFFu;
+        keep[q][0] = (st < nst && lane < pre) ? run_of(st)[lane] : 0xFFFFFFFFu;
     }
     for (uint32_t i = threadIdx.x; i < nst; i += BLOCK)
         s_cnt[i] = cnt[i];
@@ -1172,6 +1179,8 @@ __global__ __launch_bounds__(BLOCK, 8) void census_mark(CensusArgs c)
     for (int q = 0; q < kKeep; q++) {
         const uint32_t st = wave + (uint32_t)kMarkWaves * (uint32_t)q;
         const uint32_t n = st < nst ? s_cnt[st] : 0u;
+        if (lane >= pre && lane < n)
+            keep[q][0] = run_of(st)[lane];
         if (lane >= n)
             keep[q][0] = 0xFFFFFFFFu;
 #pragma unroll
@@ -3125,6 +3134,7 @@ int stage_a_run(gp_job* job)
                     c.bucket_shift = bucket_shift;
                     c.n_buckets = n_buckets;
                     c.seed_rows = k_max;
+                    c.mark_prefetch = (uint32_t)std::min<uint64_t>(64, env_u64("GP_STAGE_A_MARK_PREFETCH", 64));
                     {
                         const bool mod5 = a.cbf_mod.fast && a.cbf_mod.c == 5 && a.cbf_mod.s < 32 && a.hash_num == 4;
                         // (beside census_mark -- two buffer sets -- the grid is two workgroups per CU, each

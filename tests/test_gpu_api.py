@@ -2,6 +2,7 @@
 gp_job_create refuses before it reads an array, empty jobs, and an output file that cannot be
 written whole (GoldPolish polishes in /dev/shm: disk full is the usual failure)."""
 import ctypes as C
+import hashlib
 import os
 import resource
 
@@ -9,6 +10,10 @@ import numpy as np
 import pytest
 
 from goldpolish_amd import synth
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
 
 pytestmark = pytest.mark.gpu
 
@@ -181,6 +186,40 @@ def test_a_failed_allocation_leaves_a_job_that_can_be_destroyed_or_tried_again(g
             job.close()
     finally:
         core.debug_fail_alloc(0)
+
+
+def test_jobs_taking_turns_on_one_context_share_its_filter_build_streams(gp, monkeypatch):
+    """The filter build's extra streams, events and pinned feedback ring belong to the CONTEXT (made by the
+    first build on it, borrowed by every job: gp_ctx::StageA).  Three jobs alive at once on one context --
+    one per schedule: grid-wide (host feedback through the pinned ring), level by level, workgroup-local
+    behind the census (three streams) -- built in turn, twice over, give what each gives alone."""
+    core, ctx = gp
+    p = core.default_params(k_values=[32, 20])
+    ws = [synth.make_workload([30000, 8000], 25, seed=301), synth.make_workload([120000], 20, seed=302),
+          synth.make_workload([9000] * 12, 25, seed=303)]
+    envs = [{"GP_STAGE_A_LOCAL": "0", "GP_STAGE_A_LEVELS": "0"}, {"GP_STAGE_A_LOCAL": "0", "GP_STAGE_A_LEVELS": "1"},
+            {"GP_STAGE_A_LOCAL": "1", "GP_STAGE_A_CENSUS_MIN": "1"}]
+
+    def build(job, env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        job.build_filters()
+        for k in env:
+            monkeypatch.delenv(k)
+        return [sha(job.get_filter(b, ki).tobytes()) for b in range(job.n_batches) for ki in range(p.n_k)]
+
+    alone = []
+    for w, env in zip(ws, envs):
+        with core.Context(0) as own, core.Job.from_workload(own, p, w) as job:
+            alone.append(build(job, env))
+    jobs = [core.Job.from_workload(ctx, p, w) for w in ws]
+    try:
+        for rep in range(2):
+            for i in (0, 1, 2, 1, 0, 2):
+                assert build(jobs[i], envs[i]) == alone[i], (rep, i)
+    finally:
+        for j in jobs:
+            j.close()
 
 
 def test_jobs_and_pipeline_on_a_second_device():
