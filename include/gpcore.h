@@ -256,7 +256,10 @@ int gp_sealer_consensus(gp_ctx* ctx, uint32_t n_sets, const uint32_t* set_seq_be
  * own stream) and the caller still reads the result of set i - 1.  Results come back in
  * submission order (the ordered collection of scripts/goldpolish-reaper:51-73).  The reference
  * overlaps the same steps with processes: its filter server works on the next batches while the
- * polishing workers run (scripts/goldpolish:496-514).
+ * polishing workers run (scripts/goldpolish:496-514).  A set that holds a long contig is taken in
+ * two halves -- its filter build, then everything behind it -- by threads of their own, so that the
+ * build of one such set runs beside the back halves of the two before it (a depth of 4 keeps all of
+ * them busy; INTEGRATION.md, GP_PIPELINE_*).
  *
  * gp_pipeline_submit never blocks: with `depth` sets submitted and not yet collected it returns
  * GP_ERR_STATE.  The arrays of a submitted gp_batch_set must stay valid and unchanged until the
