@@ -1943,6 +1943,8 @@ __global__ __launch_bounds__(kWalkThreads, kMinWaves) void ntedit_walk(WalkArgs 
                 }
             }
         }
+        if (a.prof && tid == 0)
+            S.prof_req = S.req[cur]; // (what a REQ_NEXT decision turned into -- sweep, scan, bit scan, refill -- is clocked as that)
         __syncthreads();
         // THE REQUEST PROTOCOL.  Thread 0 alone writes requests; every thread reads this trip's
         // exactly once, here, behind the barrier that makes thread 0's decision (and everything the
