@@ -2846,7 +2846,7 @@ int stage_a_run(gp_job* job)
                 }
                 const uint64_t nst = (len + kCStretch - 1) / kCStretch;
                 const uint64_t recs = census_runs((uint32_t)nst, lv_buckets) * (lv_wide ? kCRunWide : kCRun);
-                const bool ok = levels_on && any && uniform && len > 0 && nst <= env_u64("GP_STAGE_A_LEVELS_NST", 20000) &&
+                const bool ok = levels_on && any && uniform && len > 0 && nst <= std::min<uint64_t>(31000, env_u64("GP_STAGE_A_LEVELS_NST", 20000)) && // (census_mark_seg keeps a length byte per stretch in LDS beside its 64 KB table: 96 KB asked for below)
                                 (double)len * p.hash_num <= max_load * (double)p.cbf_bytes && recs <= lv_budget;
                 if (ok) {
                     lvl_batches.push_back(bi);
