@@ -921,25 +921,10 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
     const int t0 = threadIdx.x * SPAN;
     const uint32_t shift = c.bucket_shift, lmask = (1u << shift) - 1u, mod5_s = a.cbf_mod.s;
     bool over = false;
-    // the census level by level: a pair that has had its passes, or that overflowed, is left alone; a
-    // stretch without a member leaves empty runs
-    const unsigned long long* const members =
-        c.members ? c.members + ((c.pair_bit_off[pair] + (pos0 - b_start)) >> 6) : nullptr;
-    if (c.pair_need) {
-        if (c.level >= c.pair_need[pair] || c.overflow[pair])
-            continue; // (uniform: one pair per workgroup turn)
-        if (members) {
-            int any = 0;
-            if (threadIdx.x < kCStretch / 64 && pos0 + (uint64_t)threadIdx.x * 64 < stretch_end)
-                any = members[threadIdx.x] != 0ull;
-            if (!__syncthreads_or(any)) {
-                uint8_t* const cnt0 = c.cnt + c.pair_cnt_off[pair];
-                for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock)
-                    cnt0[(uint64_t)i * nst + stretch] = 0;
-                continue;
-            }
-        }
-    }
+    // (the census level by level scatters once, at level 0: its later passes take the records census_mark_seg
+    // left marked; a pair without a pass to run is left alone)
+    if (c.pair_need && (c.level >= c.pair_need[pair] || c.overflow[pair]))
+        continue; // (uniform: one pair per workgroup turn)
     for (uint32_t i = threadIdx.x; i < c.n_buckets; i += kBlock)
         hist[i] = 0;
     if (threadIdx.x < 8) {
@@ -979,17 +964,6 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
         if (tile0 >= stretch_end)
             break; // uniform
         const uint64_t tile_end = min(stretch_end, tile0 + (uint64_t)TILE);
-        if (members) {
-            // a tile without a member of this level: nothing to hash (the next tile's bases are still fetched)
-            int any = 0;
-            if (threadIdx.x < TILE / 64 && tile0 + (uint64_t)threadIdx.x * 64 < stretch_end)
-                any = members[((tile0 - pos0) >> 6) + threadIdx.x] != 0ull;
-            if (!__syncthreads_or(any)) {
-                if (tile0 + (uint64_t)TILE < stretch_end)
-                    fetch(tile0 + (uint64_t)TILE);
-                continue;
-            }
-        }
         __syncthreads(); // codes and ring free (and the counters cleared before the first use)
         {
             const int sh = (int)(tile0 & 3ull);
@@ -1014,10 +988,6 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
         // cbf_local only visits the candidates of a census pair: the counters of positions
         // streamed and of operations (valid k-mers) are kept here
         n_positions += lane_on ? (uint32_t)min((uint64_t)SPAN, tile_end - lane_pos0) : 0u;
-        // (the lane's SPAN positions start on a multiple of SPAN bits: one word holds their member bits)
-        const uint32_t mbits = (members && lane_on)
-                                   ? (uint32_t)(members[(lane_pos0 - pos0) >> 6] >> ((lane_pos0 - pos0) & 63)) & ((1u << SPAN) - 1u)
-                                   : 0xFFFFFFFFu;
         for (int rd = 0; rd < ROUNDS; rd++) {
             if (rd > 0)
                 __syncthreads(); // the round before has been flushed
@@ -1038,8 +1008,6 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
                 if (!(last_bad < jj && pos + k <= a.n_pos))
                     continue;
                 n_ops++;
-                if (!((mbits >> jj) & 1u))
-                    continue; // not a member of this level
                 const uint64_t base = fh + rh;
                 const uint32_t off = (uint32_t)(st * TILE + t0 + jj); // position in the stretch
                 // the operation's touches side by side: their indices, then their LDS atomics in flight
@@ -1127,7 +1095,7 @@ __global__ __launch_bounds__(kBlock) void census_scatter(AArgs a, CensusArgs c)
         n_positions += (uint32_t)__shfl_down((int)n_positions, o);
         n_ops += (uint32_t)__shfl_down((int)n_ops, o);
     }
-    if ((threadIdx.x & 63) == 0 && c.level == 0) { // (later passes stream the same positions again)
+    if ((threadIdx.x & 63) == 0) {
         atomicAdd(&a.stats[0], (unsigned long long)n_positions);
         atomicAdd(&a.stats[1], (unsigned long long)n_ops);
     }
