@@ -27,7 +27,11 @@
 //   SURVEY 8d config 3's own shape (48 contigs of 0.3-12 Mbp), on the round's last filter build (3.4 s alone):
 //   whole 8 160; split without masks 6 930; split 6 | 2, one polishing thread 6 500 (2, 3 or 4 CUs in 8 for
 //   the back half: the same -- it waits for its slowest segments and searches); two
-//   polishing threads 5 780; and 7 | 1: 5 450.  GP_PIPELINE_TRACE=1 prints every stage of every set.
+//   polishing threads 5 700 in steady state (7 | 1 and 6 | 2 alike; the "5 450" a first run gave was the start
+//   of the stream: time such a pipeline from its fourth set on).  GP_PIPELINE_TRACE=1 prints every stage of every set.
+//   With the waits described next gone, read-length sets were tried again: every set split 877 ms per
+//   configs[2] step against 916 whole (the census kernels 792 instead of 580 ms beside a back half, 88 instead
+//   of 65 GiB): 4 %, still not the default.
 //   What the trace showed first: build and back half ENDING TOGETHER, set after set, 6.3 s each -- every job
 //   made and destroyed its filter build's streams, events and pinned ring, hipHostFree / hipStreamDestroy
 //   wait for the whole device, and the back half never leaves it idle.  Those are the context's now
