@@ -61,12 +61,14 @@ def test_stream_of_sets_equals_single_jobs_and_the_oracle(oracle, overlap, monke
         assert core.split_polished(got[2])[c] == outs[0]
 
 
-@pytest.mark.parametrize("threads", ["2", "1"])
-def test_two_back_halves_at_once_come_back_in_submission_order(threads, monkeypatch):
-    """split sets (every set here: GP_PIPELINE_SPLIT_FROM lowered, masks for any number of contigs) are taken by
-    two polishing threads; a short set behind a long one finishes first and must still be collected second"""
+@pytest.mark.parametrize("threads,mask_from", [("2", "0"), ("1", "0"), ("2", "100"), ("2", "3")])
+def test_two_back_halves_at_once_come_back_in_submission_order(threads, mask_from, monkeypatch):
+    """split sets (every set here: GP_PIPELINE_SPLIT_FROM lowered) are taken by two polishing threads when they
+    run on CU-masked contexts (mask_from 0: every set; 3: the sets of three contigs and more); a short set behind
+    a long one finishes first and must still be collected second.  mask_from 100: every set split WITHOUT masks
+    (filter build on a plain context of its own, back half on the whole-path context, one polishing thread)."""
     monkeypatch.setenv("GP_PIPELINE_SPLIT_FROM", "1000")
-    monkeypatch.setenv("GP_PIPELINE_MASK_FROM", "0")
+    monkeypatch.setenv("GP_PIPELINE_MASK_FROM", mask_from)
     monkeypatch.setenv("GP_PIPELINE_BACK_THREADS", threads)
     from goldpolish_amd import core
     p = core.default_params()
