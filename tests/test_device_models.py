@@ -15,7 +15,12 @@ agree on random inputs -- the argument the kernel's comment makes, executed.
    modulo 5) and t / 5 = (t * 205) >> 10, against Python's %; and the extension hashes 1..3 from ONE
    multiply (census_scatter): base * (i ^ M) = base * M + d_i * base with d_i = ((M & 3) ^ i) - (M & 3).
 6. `census_scatter`'s range word: a record's rank (low half) and the range's window base (high half)
-   from one atomic add, against a counter and a base kept apart."""
+   from one atomic add, against a counter and a base kept apart.
+7. `census_run_index` (stage_a.hip): where the run of a (range, stretch) lies -- segments of 128 stretches,
+   ranges inside a segment, stretches inside a range (a pair of thousands of stretches keeps a segment's
+   runs of one range next to each other) -- is one-to-one onto [0, census_runs), and for pairs of up to 128
+   stretches the same as the plain range-major order; and `census_mark_seg`'s table carried from segment to
+   segment gives the same first touches as one table over all the stretches."""
 import json
 import pathlib
 
@@ -339,3 +344,59 @@ def test_rank_and_window_base_share_a_word():
                 word = (word & 0xFFFF) | (g_next << 16)
                 gbase = g_next
                 assert word & 0xFFFF == cnt and g_next <= (run + G - 1) // G + 1
+
+
+K_SEG = 128
+
+
+def census_run_index(nst, n_buckets, bucket, stretch):
+    stride = min(nst, K_SEG)
+    return ((stretch // K_SEG) * n_buckets + bucket) * stride + stretch % K_SEG
+
+
+def census_runs(nst, n_buckets):
+    return ((nst + K_SEG - 1) // K_SEG) * n_buckets * min(nst, K_SEG)
+
+
+def test_segmented_run_index_is_one_to_one_and_range_major_for_short_pairs():
+    for nst, n_buckets in [(1, 5), (7, 640), (123, 640), (128, 3), (129, 3), (300, 17), (4900, 4)]:
+        seen = set()
+        for b in range(n_buckets):
+            for st in range(nst):
+                i = census_run_index(nst, n_buckets, b, st)
+                assert 0 <= i < census_runs(nst, n_buckets) and i not in seen
+                seen.add(i)
+                if nst <= K_SEG:
+                    assert i == b * nst + st          # what the workgroup-local census has always used
+        assert len(seen) == nst * n_buckets
+        # a range's runs of one segment are neighbours (what census_mark_seg's waves read together)
+        for st in range(0, nst - 1):
+            if st // K_SEG == (st + 1) // K_SEG:
+                assert census_run_index(nst, n_buckets, 2 % n_buckets, st + 1) == census_run_index(nst, n_buckets, 2 % n_buckets, st) + 1
+
+
+def test_first_touches_with_the_table_carried_from_segment_to_segment():
+    """census_mark_seg: positions only grow from segment to segment, so after a segment's minima are in, the
+    table is final for every counter that segment touches; a touch is its counter's first iff the table
+    holds its own position when its segment is marked"""
+    rng = np.random.default_rng(5)
+    n_counters, per_stretch, nst, stretch_len = 257, 40, 700, 8192
+    touches = []                                            # (position, counter), stretch by stretch
+    for st in range(nst):
+        pos = np.sort(rng.integers(0, stretch_len, size=per_stretch)) + st * stretch_len
+        touches.append(list(zip(pos.tolist(), rng.integers(0, n_counters, size=per_stretch).tolist())))
+    first = {}
+    for run in touches:
+        for p, c in run:
+            first[c] = min(first.get(c, p), p)
+    want = [[first[c] != p for p, c in run] for run in touches]      # marked = not the counter's first
+    table = {}
+    got = []
+    for seg0 in range(0, nst, K_SEG):
+        seg = touches[seg0:seg0 + K_SEG]
+        for run in seg:                                      # the segment's atomicMin pass
+            for p, c in run:
+                table[c] = min(table.get(c, 1 << 62), p)
+        for run in seg:                                      # ... then its marks
+            got.append([table[c] != p for p, c in run])
+    assert got == want
