@@ -69,3 +69,37 @@ def test_levels_decide_what_the_serial_filter_inserts(load, thr, seed):
     if load >= 15 and thr == 13:
         # what the passes cost: the sum of their sizes in operations (DESIGN section 4 quotes these)
         print(f"load {load} touches per counter, thr {thr}: passes hold {sum(sizes) / n_ops:.1f} x the operations")
+
+
+def by_levels_on_records(idx, n_counters, thr):
+    """the device's way (census_mark_seg from the second pass on): NOTHING is scattered again -- a pass's input
+    is the records the pass before marked, filtered by one bit per operation (all of its touches marked)"""
+    n = len(idx)
+    records = [(t, int(x)) for t in range(n) for x in idx[t]]          # level 0: every touch
+    member = np.ones(n, dtype=bool)
+    for _ in range(thr - 1):
+        first = {}
+        for t, x in records:                                            # (records are in order of t)
+            first.setdefault(x, t)
+        marked = [(t, x) for t, x in records if first[x] != t]          # a touch that is not its counter's first
+        n_marked = np.zeros(n, dtype=np.int64)
+        for t, _x in marked:
+            n_marked[t] += 1
+        member = member & (n_marked == idx.shape[1])                    # census_pack: every touch marked
+        records = [(t, x) for t, x in marked if member[t]]              # take(): the next pass's input
+        if not records:
+            member[:] = False
+            break
+    return member
+
+
+@pytest.mark.parametrize("load,thr,seed", [(3, 4, 12), (15, 13, 13), (30, 6, 14), (8, 2, 15)])
+def test_passes_over_the_marked_records_equal_passes_over_the_members(load, thr, seed):
+    rng = np.random.default_rng(seed)
+    n_counters, h = 512, 3
+    n_ops = int(load * n_counters / h)
+    n_kmers = max(4, n_ops // max(2, thr // 2))
+    table = rng.integers(0, n_counters, size=(n_kmers, h))
+    table[::13, 2] = table[::13, 0]               # k-mers that hit one counter twice
+    idx = table[rng.integers(0, n_kmers, size=n_ops)]
+    assert np.array_equal(by_levels_on_records(idx, n_counters, thr), serial(idx, n_counters, thr))
