@@ -700,6 +700,17 @@ def main():
                               "replayed_found_settled": c.get("a_settled_hits", 0),
                               "candidates_settled_by_their_kmers_count": c.get("a_counted", 0),
                               "alg_GBps": round((1 + 2 * H) * k["cbf_local"]["units"] / (sa_ms / 1e3) / 1e9, 2)}
+        lv = k.get("cbf_census", {})
+        if lv.get("ms") and not k["cbf_local"]["launches"]:
+            # the census LEVEL BY LEVEL (long batches whose filters stay unsaturated; no cbf_local behind it): its
+            # timer's units are the (read base, k) pairs it decides, priced like every stage-A kernel here
+            lv_bytes = (1 + 2 * H) * lv["units"]
+            out["census_level_by_level"] = {
+                "ms": round(lv["ms"], 3), "operations_decided": int(lv["units"]),
+                "alg_GBps": round(lv_bytes / (lv["ms"] / 1e3) / 1e9, 2),
+                "frac": round(lv_bytes / (lv["ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
+                "note": "thr - 1 passes of census_mark_seg / census_pack over the surviving records; in gp_pipeline it runs "
+                        "beside the back halves of two other sets (about 1.7 x its time alone)"}
         if name == "cbf_local" and kk["ms"]:
             # what bounds this kernel: random memory transactions, one line each -- a look-up in the
             # table of settled k-mers per replayed operation, and for those not found there H counter
